@@ -1,0 +1,168 @@
+"""Pins the CPU oracle (oracle/hg_oracle.c) against the golden vectors produced by running the reference's own
+Homography.js (tests/golden/gen_golden.mjs) and against the reference's known-answer PNG pair.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from hgtest import golden as G
+from hgtest import oracle as O
+
+GOLD = G.load()
+
+
+# ------------------------------------------------------------------ per-function vectors
+
+def test_lcg_image_matches_c_and_numpy():
+    for (w, h, seed) in [(7, 5, 1), (64, 33, 12345), (400, 400, 7)]:
+        assert np.array_equal(G.lcg_image(w, h, seed), O.lcg_image(w, h, seed))
+
+
+def test_js_round_vectors():
+    for v in GOLD["func"]["round"]:
+        x = G.f64_from_hex([v["x"]])[0]
+        want = G.f64_from_hex([v["r"]])[0]
+        got = O.js_round(x)
+        if np.isnan(want):
+            assert np.isnan(got)
+        else:
+            assert got == want, (x, got, want)       # sign of zero is not observable downstream
+
+
+def test_affine_from_triangles_bit_exact():
+    for v in GOLD["func"]["affine"]:
+        got = O.affine_from_triangles(G.f32_from_bits(v["src"]), G.f32_from_bits(v["dst"]))
+        want = G.f32_from_bits(v["out"])
+        assert _same_f32(got, want), (v, got, want)
+
+
+def test_inverse_affine_bit_exact():
+    for v in GOLD["func"]["inv_affine"]:
+        got = O.inverse_affine(G.f32_from_bits(v["m"]))
+        assert _same_f32(got, G.f32_from_bits(v["out"]))
+
+
+def test_projective_from_squares_bit_exact():
+    for v in GOLD["func"]["projective"]:
+        got = O.projective_from_squares(G.f32_from_bits(v["src"]), G.f32_from_bits(v["dst"]))
+        want = G.f64_from_hex(v["out"])
+        assert _same_f64(got, want), (got, want)
+
+
+def test_fill_triangle_maps_bit_exact():
+    for v in GOLD["func"]["fill"]:
+        m = np.full(v["width"] * v["rows"], -1, np.int16)
+        O.fill_triangle(G.f32_from_bits(v["tri"]), v["idx"], v["width"], v["yoff"], m)
+        assert np.array_equal(m, np.array(v["map"], np.int16)), v
+
+
+def test_transform_limits_and_minmax():
+    for v in GOLD["func"]["limits"]:
+        if v["kind"] == "affine":
+            m = G.f32_from_bits(v["m"]).astype(np.float64)
+            got = O.transform_limits(0, m, v["w"], v["h"])
+        else:
+            got = O.transform_limits(1, G.f64_from_hex(v["m"]), v["w"], v["h"])
+        assert _same_f64(got, G.f64_from_hex(v["out"]))
+    for v in GOLD["func"]["minmax"]:
+        assert _same_f64(O.minmax_xy(G.f32_from_bits(v["p"])), G.f64_from_hex(v["out"]))
+
+
+def _same_f32(a, b):
+    a, b = G.bits32(a), G.bits32(b)
+    nan = np.isnan(a.view(np.float32)) & np.isnan(b.view(np.float32))
+    zero = (a.view(np.float32) == 0) & (b.view(np.float32) == 0)
+    return bool(np.all((a == b) | nan | zero))
+
+
+def _same_f64(a, b):
+    a, b = G.bits64(a), G.bits64(b)
+    nan = np.isnan(a.view(np.float64)) & np.isnan(b.view(np.float64))
+    zero = (a.view(np.float64) == 0) & (b.view(np.float64) == 0)
+    return bool(np.all((a == b) | nan | zero))
+
+
+# ------------------------------------------------------------------ end-to-end warps (resolved state -> oracle -> golden output)
+
+SLOW = {"C2_projective_1080p", "C3_piecewise_4k", "C3_piecewise_4k_5000tri", "C5_piecewise_8k"}
+
+
+def _warp_params():
+    ps = []
+    for c in GOLD["cases"]:
+        for k, w in enumerate(c["warps"]):
+            marks = [pytest.mark.slow] if c["name"] in SLOW else []
+            ps.append(pytest.param(c["name"], k, id=f"{c['name']}#{k}", marks=marks))
+    return ps
+
+
+def oracle_run_warp(case, k):
+    """Feeds the golden's resolved low-level state of warp #k to the oracle; returns (rgba, map|None, fwd|None, inv|None)."""
+    w = case["warps"][k]
+    img = G.case_images(case)[G.warp_image_key(case, k)]
+    assert img.shape[1] == w["W"] and img.shape[0] == w["H"]
+    path = w["path"]
+    if w["transform"] == "piecewiseaffine":
+        sp, dp = G.f32_from_bits(w["srcPoints"]), G.f32_from_bits(w["dstPoints"])
+        tris = G.case_triangles(case)
+        if path == "_inversePiecewiseAffineWarp":
+            return O.warp_inverse_piecewise(sp, dp, tris, img, w["minSrcX"], w["minSrcY"], w["xOff"], w["yOff"], w["objW"], w["objH"], taps=True)
+        fwd = O.piecewise_matrices(sp, dp, tris)
+        mw, mh = w["maxSrcX"] - w["minSrcX"], w["maxSrcY"] - w["minSrcY"]
+        fmap = O.build_tri_map(sp, tris, mw, w["minSrcY"], mw * mh)
+        out = O.warp_forward_piecewise(fmap, fwd, img, w["minSrcX"], w["minSrcY"], w["maxSrcX"], w["maxSrcY"], w["xOff"], w["yOff"], w["objW"], w["objH"])
+        return out, fmap, fwd, None
+    kind = 0 if w["transform"] == "affine" else 1
+    if path == "_inverseGeometricWarp":
+        # Q8: the inverse matrix is re-solved from the swapped point sets, :994
+        sp, dp = G.f32_from_bits(w["srcPoints"]), G.f32_from_bits(w["dstPoints"])
+        m = O.affine_from_triangles(dp, sp).astype(np.float64) if kind == 0 else O.projective_from_squares(dp, sp)
+        want_m = G.f32_from_bits(w["invMatrix"]["f32"]).astype(np.float64) if kind == 0 else G.f64_from_hex(w["invMatrix"]["f64"])
+        assert _same_f64(m, want_m)
+        return O.warp_inverse_geometric(kind, m, img, w["xOff"], w["yOff"], w["objW"], w["objH"]), None, None, None
+    m = G.f32_from_bits(w["matrix"]["f32"]).astype(np.float64) if kind == 0 else G.f64_from_hex(w["matrix"]["f64"])
+    return O.warp_forward_geometric(kind, m, img, w["xOff"], w["yOff"], w["objW"], w["objH"]), None, None, None
+
+
+@pytest.mark.parametrize("name,k", _warp_params())
+def test_oracle_reproduces_reference_warp(name, k):
+    case = next(c for c in GOLD["cases"] if c["name"] == name)
+    w = case["warps"][k]
+    out, map_, fwd, inv = oracle_run_warp(case, k)
+    assert out.shape[1] == w["out"]["w"] and out.shape[0] == w["out"]["h"]
+    if "blob" in w["out"]:
+        want = G.blob(w["out"]["blob"], np.uint8).reshape(out.shape)
+        assert np.array_equal(out, want), f"{np.count_nonzero(np.any(out != want, axis=2))} pixels differ"
+    assert G.sha256(out) == w["out"]["sha"]
+    if map_ is not None:
+        assert map_.size == w["map"]["len"]
+        if "blob" in w["map"]:
+            assert np.array_equal(map_, G.blob(w["map"]["blob"], np.int16))
+        assert G.sha256(map_) == w["map"]["sha"]
+    for got, key, shakey in ((fwd, "fwd", "fwdSha"), (inv, "inv", "invSha")):
+        if got is None:
+            continue
+        if key in w:
+            assert _same_f32(got.ravel(), G.blob(w[key], np.float32))
+        if not np.isnan(got).any():                 # NaN payload/sign bits are not observable in JS
+            assert G.sha256(got) == w[shakey]
+
+
+# ------------------------------------------------------------------ the reference's own known-answer fixture (test/nodeTest.js)
+
+def test_known_answer_png_pair():
+    Image = pytest.importorskip("PIL.Image")
+    d = os.path.join(G.GOLDEN_DIR, "ref_fixture")
+    src = np.array(Image.open(os.path.join(d, "testImgLogoBlack.png")).convert("RGBA"))
+    want = np.array(Image.open(os.path.join(d, "transformedImage.png")).convert("RGBA"))
+    W, H = 400, 400
+    # test/nodeTest.js:5-6 (normalised) -> denormalised by _setSrcWidthHeight :652-662 once the image is set
+    sp = (np.array([[0, 0], [0, 1], [1, 0], [1, 1]], np.float32) * np.array([W, H], np.float32)).astype(np.float32)
+    dp = (np.array([[1 / 10, 1 / 2], [0, 1], [9 / 10, 1 / 2], [1, 1]], np.float32) * np.array([W, H], np.float32)).astype(np.float32)
+    fwd = O.projective_from_squares(sp.ravel(), dp.ravel())
+    xo, yo, ow, oh = [int(v) for v in O.transform_limits(1, fwd, W, H)]
+    assert (xo, yo, ow, oh) == (0, 200, 400, 200)
+    inv = O.projective_from_squares(dp.ravel(), sp.ravel())
+    out = O.warp_inverse_geometric(1, inv, src, xo, yo, ow, oh)
+    assert out.shape == want.shape
+    assert np.array_equal(out, want), f"{np.count_nonzero(np.any(out != want, axis=2))} of {ow * oh} pixels differ"
