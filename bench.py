@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X: Mpixels/s warped, piecewise-affine, 4K RGBA.
+
+A "step" is one pass of the hot path over one batch of synthetic input: F destination point sets of the C3 workload
+(3840x2160 RGBA, 11x11-point sinusoidal grid = 200 triangles; frame f uses sin((8 + f mod 4) x / pi), the pattern of the
+reference's own harness test/benchmark.js:68,107-110) on a shared source image.  Per step and per frame the library
+does what the reference redoes per frame (`setDestinyPoints(dst_f); warp()`): per-triangle affine solves + inverses
+(k_tri_setup) and the inverse piecewise warp (k_pw_fused).  Inputs (source RGBA, meshes, destination points) are
+resident in HBM before the timed region; outputs stay in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config C3|C5|C2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Multi-GPU: frames shard across ranks (independent units, weak scaling: F frames per GPU); the only exchange is the
+one-off broadcast of the shared source texture over RCCL (scatter + all_gather so each xGMI link carries 1/N of it),
+done before the timed region and reported as `broadcast_ms`.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "homography.js_amd")
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def _load(name, path):
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def broadcast_source(img_t, rank, world, dist, torch):
+    """Shared source texture, rank 0 -> all: scatter 1/N to each peer, then all_gather (every xGMI link carries 1/N of
+    the image instead of a ring/tree bound by one link).  img_t: uint8 CUDA tensor, same shape everywhere."""
+    if world == 1:
+        return img_t
+    flat = img_t.view(-1)
+    n = flat.numel()
+    chunk = (n + world - 1) // world
+    padded = torch.zeros(chunk * world, dtype=torch.uint8, device=flat.device)
+    if rank == 0:
+        padded[:n] = flat
+    mine = torch.empty(chunk, dtype=torch.uint8, device=flat.device)
+    dist.scatter(mine, list(padded.view(world, chunk).unbind(0)) if rank == 0 else None, src=0)
+    dist.all_gather_into_tensor(padded, mine)
+    return padded[:n].view_as(img_t).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32, help="frames (destination point sets) per GPU per step")
+    ap.add_argument("--config", default="C3", choices=["C3", "C5", "C2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback to measure)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl == RCCL on ROCm
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    hg = _load("hgwarp", os.path.join(PKG, "hgwarp.py"))
+    wl = _load("hg_workloads", os.path.join(PKG, "workloads.py"))
+    cfg = wl.CONFIGS[args.config]
+    W, H, F = cfg["W"], cfg["H"], args.frames
+
+    # ---------------------------------------------------------------- inputs -> HBM (untimed)
+    img_t = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+    if rank == 0:
+        img_t.copy_(torch.from_numpy(wl.lcg_image(W, H, 1)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    img_t = broadcast_source(img_t, rank, world, dist, torch)
+    torch.cuda.synchronize()
+    broadcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else 0.0
+
+    stream = torch.cuda.Stream(device=dev)
+    ctx = hg.Context(local_rank, stream=stream.cuda_stream)
+    ctx.set_image_device(img_t.data_ptr(), W, H)
+
+    piecewise = cfg["kind"] == "piecewise"
+    if piecewise:
+        sp, tris, frames, geoms = wl.piecewise_frames(cfg, F)
+        # different ranks get different frames of the same sequence (frame index = rank*F + f)
+        frames = [wl.sin_dst(sp, cfg["A"], 8 + ((rank * F + f) % 4)) for f in range(F)]
+        geoms = [wl.piecewise_geom(d) for d in frames]
+        msx, msy = wl.src_min(sp)
+        ctx.piecewise_set_mesh(sp, tris, msx, msy)
+        offs, total = hg.pack_offsets(geoms)
+        ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+        run = ctx.warp_inverse_piecewise_frames_device
+        workload = (f"{args.config}: {W}x{H} RGBA piecewise-affine, {cfg['nx']}x{cfg['ny']}-cell sinusoidal grid "
+                    f"({tris.size // 3} triangles), {F} frames/GPU/step on a shared source")
+    else:
+        s4 = wl.corners(W, H)
+        mats, geoms = [], []
+        for f in range(F):
+            d4 = wl.projective_dst(W, H, 0.0125 * ((rank * F + f) % 10))
+            fwd = hg.solve_projective(s4, d4)
+            geoms.append(tuple(int(v) for v in hg.transform_limits(1, fwd, W, H)))
+            mats.append(hg.solve_projective(d4, s4))
+        offs, total = hg.pack_offsets(geoms)
+        ctx.geometric_set_frames(1, np.concatenate(mats), geoms, offs)
+        run = ctx.warp_inverse_geometric_frames_device
+        workload = f"{args.config}: {W}x{H} RGBA projective, 4 corner points, {F} frames/GPU/step on a shared source"
+
+    out_t = torch.empty(total, dtype=torch.uint8, device=dev)
+    d_out = out_t.data_ptr()
+    n_out = [g[2] * g[3] for g in geoms]
+    px_per_step = float(sum(n_out))
+
+    # N_hit per frame (algorithmic read bytes): alpha==255 count when the same frames run on an all-255 source (untimed)
+    solid = torch.full((H, W, 4), 255, dtype=torch.uint8, device=dev)
+    ctx.set_image_device(solid.data_ptr(), W, H)
+    run(d_out)
+    ctx.sync()
+    n_hit = []
+    for f, g in enumerate(geoms):
+        a = out_t[offs[f]: offs[f] + g[2] * g[3] * 4].view(-1, 4)[:, 3]
+        n_hit.append(int((a == 255).sum().item()))
+    ctx.set_image_device(img_t.data_ptr(), W, H)
+    del solid
+    algo_bytes_per_launch = float(sum(4 * no + 4 * nh for no, nh in zip(n_out, n_hit)))
+
+    # ---------------------------------------------------------------- warmup + timed region
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run(d_out)
+    ctx.sync()
+    ctx.set_timing(True)                       # hipEvent pairs around the dominant kernel, on the launch stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run(d_out)
+    ctx.sync()                                 # waits for the stream (and settles any frame the fused path deferred)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k_total_ms, k_launches = ctx.kernel_ms_stats()
+    ctx.set_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        px = torch.tensor([px_per_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(px, op=dist.ReduceOp.SUM)
+        px_all = float(px.item())
+    else:
+        px_all = px_per_step
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = px_all * args.steps / elapsed / 1e6          # Mpixels/s, whole job
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel (rank 0's launches)
+    k_ms = k_total_ms / max(k_launches, 1)
+    achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_pw_fused" if piecewise else "k_geo<projective>",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel_ms": round(k_ms, 5), "launches_timed": k_launches,
+                "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
+                "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel; "
+                        "the shared 4K source stays in the 256 MiB Infinity Cache across frames, so HBM-side traffic is mostly the writes"}
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from hgtest import oracle as O             # checker / baseline only; never on the measured GPU path
+        img = img_t.cpu().numpy()
+        t_budget, n_done, px_done = 12.0, 0, 0
+        t0 = time.perf_counter()
+        max_frames = args.cpu_frames or 10 ** 9
+        while n_done < max_frames and (time.perf_counter() - t0 < t_budget or n_done == 0):
+            f = n_done % F
+            if piecewise:
+                O.warp_inverse_piecewise(sp, frames[f], tris, img, msx, msy, *geoms[f])
+            else:
+                O.warp_inverse_geometric(1, mats[f], img, *geoms[f])
+            px_done += n_out[f]
+            n_done += 1
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(px_done / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+               "sample": f"{n_done} frames of the same workload through oracle/hg_oracle.c (C restatement of the reference's JS loops, "
+                         f"gcc -O2, single thread) in {dt:.1f} s; the reference itself is single-threaded JavaScript "
+                         f"(24.3 Mpix/s on C3 under Node 12, BASELINE.md §2)"}
+
+    if rank == 0:
+        line = {"metric": "Mpixels/s warped (piecewise-affine, 4K RGBA)" if args.config == "C3" else f"Mpixels/s warped ({args.config})",
+                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u8 pixels / f64 coordinates", "data": "synthetic",
+                "config": {"workload": workload, "frames_per_gpu_per_step": F, "output_pixels_per_step_per_gpu": int(px_per_step),
+                           "parallelism": f"frames sharded over {world} GPU(s); source broadcast once (scatter+all_gather over RCCL)",
+                           "broadcast_ms": round(broadcast_ms, 3)},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,693 @@
+// hg_api.hip -- the C ABI of include/hgwarp.h: context / buffer management, host-side solves, kernel orchestration.
+// No torch, no C++ types in the exported signatures.  There is deliberately no CPU warp path in this file.
+#include "../../include/hgwarp.h"
+#include "hg_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hg;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+struct hg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int deferred = HG_OK;
+
+    // source image
+    uint8_t *d_img = nullptr; size_t img_cap = 0; bool img_aliased = false;
+    int W = 0, H = 0;
+
+    // mesh (source side)
+    float *d_src = nullptr; size_t src_cap = 0;
+    uint32_t *d_tris = nullptr; size_t tris_cap = 0;
+    int n_pts = 0, n_tris = 0, min_src_x = 0, min_src_y = 0;
+    bool have_mesh = false;
+
+    // piecewise frames
+    std::vector<FrameDesc> pw_frames;          // host copy
+    FrameDesc *d_pw_frames = nullptr; size_t pw_frames_cap = 0;
+    float *d_dst = nullptr; size_t dst_cap = 0;
+    TriRange *d_trir = nullptr; size_t trir_cap = 0;
+    Seg *d_segs = nullptr; size_t segs_cap = 0;
+    float *d_fwd = nullptr; size_t fwd_cap = 0;
+    float *d_inv = nullptr; size_t inv_cap = 0;
+    int32_t *d_status = nullptr; size_t status_cap = 0;
+    int32_t *h_status = nullptr; size_t h_status_cap = 0;      // pinned
+    bool pw_setup_done = false;                                // k_tri_setup ran for the uploaded frames
+    bool pw_status_pending = false;                            // a fused run's status has not been checked yet
+    uint8_t *pw_last_out = nullptr;
+
+    // geometric frames
+    int geo_kind = 0;
+    std::vector<FrameDesc> geo_frames;
+    FrameDesc *d_geo_frames = nullptr; size_t geo_frames_cap = 0;
+    double *d_mats = nullptr; size_t mats_cap = 0;
+
+    // scratch
+    int32_t *d_map32 = nullptr; size_t map32_cap = 0;
+    int16_t *d_map16 = nullptr; size_t map16_cap = 0;
+    uint8_t *d_out_tmp = nullptr; size_t out_tmp_cap = 0;
+
+    // timing of the dominant kernel: a ring of event pairs recorded around each launch of it
+    static constexpr int kEvRing = 256;
+    bool timing = false;
+    hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
+    long ev_count = 0;                                         // launches recorded since timing was (re)enabled
+};
+
+static int time_begin(hg_ctx *c);
+static int time_end(hg_ctx *c);
+
+static int fail(hg_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail((c), HG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+#define HG_TRY(expr) do { int s_ = (expr); if (s_ != HG_OK) return s_; } while (0)
+
+template <typename T>
+static int ensure(hg_ctx *c, T *&p, size_t &cap, size_t need)
+{
+    if (need <= cap) return HG_OK;
+    if (p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); p = nullptr; cap = 0; }
+    size_t n = std::max(need, cap + cap / 2);
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    p = static_cast<T *>(q); cap = n;
+    return HG_OK;
+}
+
+static int bind(hg_ctx *c)
+{
+    if (!c) return fail(nullptr, HG_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return HG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ library / context
+extern "C" int hg_version(void) { return HG_VERSION; }
+
+extern "C" int hg_device_count(int *count)
+{
+    if (!count) return fail(nullptr, HG_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, HG_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    return HG_OK;
+}
+
+static int create_common(int device_id, void *stream, bool own, hg_ctx **out)
+{
+    if (!out) return fail(nullptr, HG_ERR_INVALID, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, HG_ERR_NO_DEVICE, std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "0 devices") +
+                    "); libhgwarp has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, HG_ERR_NO_DEVICE, "device id out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, HG_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + "; libhgwarp is built for gfx950 (MI355X) only");
+    hg_ctx *c = new hg_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete c; return fail(nullptr, HG_ERR_HIP, "hipSetDevice failed"); }
+    if (own) {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, HG_ERR_HIP, "hipStreamCreate failed"); }
+        c->own_stream = true;
+    } else {
+        c->stream = static_cast<hipStream_t>(stream);
+    }
+    *out = c;
+    return HG_OK;
+}
+
+extern "C" int hg_create(int device_id, hg_ctx **ctx) { return create_common(device_id, nullptr, true, ctx); }
+extern "C" int hg_create_on_stream(int device_id, void *hip_stream, hg_ctx **ctx) { return create_common(device_id, hip_stream, false, ctx); }
+
+extern "C" void hg_destroy(hg_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
+    void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status,
+                     c->d_geo_frames, c->d_mats, c->d_map32, c->d_map16, c->d_out_tmp };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *hg_last_error(const hg_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+extern "C" int hg_device_alloc(hg_ctx *c, size_t bytes, void **dptr)
+{
+    HG_TRY(bind(c));
+    if (!dptr) return fail(c, HG_ERR_INVALID, "dptr is NULL");
+    *dptr = nullptr;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return HG_OK;
+}
+
+extern "C" int hg_device_free(hg_ctx *c, void *dptr)
+{
+    HG_TRY(bind(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (dptr) HIP_TRY(c, hipFree(dptr));
+    return HG_OK;
+}
+
+extern "C" int hg_copy_to_host(hg_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HG_TRY(bind(c));
+    if (!dst || !src) return fail(c, HG_ERR_INVALID, "NULL pointer");
+    HG_TRY(hg_sync(c));
+    HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return HG_OK;
+}
+
+extern "C" int hg_set_timing(hg_ctx *c, int enabled)
+{
+    HG_TRY(bind(c));
+    c->timing = enabled != 0;
+    c->ev_count = 0;
+    if (c->timing && !c->ev0[0]) {
+        for (int i = 0; i < hg_ctx::kEvRing; i++) { HIP_TRY(c, hipEventCreate(&c->ev0[i])); HIP_TRY(c, hipEventCreate(&c->ev1[i])); }
+    }
+    return HG_OK;
+}
+
+static int time_begin(hg_ctx *c)
+{
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0[c->ev_count % hg_ctx::kEvRing], c->stream));
+    return HG_OK;
+}
+
+static int time_end(hg_ctx *c)
+{
+    if (c->timing) { HIP_TRY(c, hipEventRecord(c->ev1[c->ev_count % hg_ctx::kEvRing], c->stream)); c->ev_count++; }
+    return HG_OK;
+}
+
+extern "C" int hg_kernel_ms_stats(hg_ctx *c, double *total_ms, int *launches)
+{
+    HG_TRY(bind(c));
+    if (!total_ms || !launches) return fail(c, HG_ERR_INVALID, "NULL pointer");
+    *total_ms = 0.0; *launches = 0;
+    if (!c->timing || c->ev_count == 0) return HG_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const long n = std::min<long>(c->ev_count, hg_ctx::kEvRing);
+    for (long k = 0; k < n; k++) {
+        const int i = (int)((c->ev_count - 1 - k) % hg_ctx::kEvRing);
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+        *total_ms += ms;
+    }
+    *launches = (int)n;
+    return HG_OK;
+}
+
+extern "C" int hg_last_kernel_ms(hg_ctx *c, float *ms)
+{
+    HG_TRY(bind(c));
+    if (!ms) return fail(c, HG_ERR_INVALID, "ms is NULL");
+    *ms = 0.f;
+    if (!c->timing || c->ev_count == 0) return HG_OK;
+    const int i = (int)((c->ev_count - 1) % hg_ctx::kEvRing);
+    HIP_TRY(c, hipEventSynchronize(c->ev1[i]));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0[i], c->ev1[i]));
+    return HG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host-side solves
+extern "C" double hg_js_round(double x) { return js_round(x); }
+
+extern "C" int hg_solve_affine(const float src[6], const float dst[6], float out[6])
+{
+    if (!src || !dst || !out) return fail(nullptr, HG_ERR_INVALID, "NULL pointer");
+    solve_affine(src, dst, out);
+    return HG_OK;
+}
+
+extern "C" int hg_invert_affine(const float m[6], float out[6])
+{
+    if (!m || !out) return fail(nullptr, HG_ERR_INVALID, "NULL pointer");
+    invert_affine(m, out);
+    return HG_OK;
+}
+
+// projectiveMatrixFromSquares :1320-1333: the 8x8 DLT system, solved exactly as numeric.js does (:1650-1751):
+// Doolittle LU with partial pivoting (strict '<', first maximum wins), rows exchanged by reference, then the
+// permuted forward and the backward substitution.  8x8 once per frame: host side, microseconds.
+extern "C" int hg_solve_projective(const float s[8], const float d[8], double out[8])
+{
+    if (!s || !d || !out) return fail(nullptr, HG_ERR_INVALID, "NULL pointer");
+    double buf[8][8];
+    double *A[8];
+    for (int p = 0; p < 4; p++) {
+        const double x = s[2 * p], y = s[2 * p + 1], u = d[2 * p], v = d[2 * p + 1];
+        const double r0[8] = { x, y, 1, 0, 0, 0, -u * x, -u * y };
+        const double r1[8] = { 0, 0, 0, x, y, 1, -v * x, -v * y };
+        for (int j = 0; j < 8; j++) { buf[2 * p][j] = r0[j]; buf[2 * p + 1][j] = r1[j]; }
+    }
+    for (int i = 0; i < 8; i++) A[i] = buf[i];
+    int P[8];
+    for (int k = 0; k < 8; k++) {
+        int pk = k;
+        double best = fabs(A[k][k]);
+        for (int j = k + 1; j < 8; j++) { const double v = fabs(A[j][k]); if (best < v) { best = v; pk = j; } }
+        P[k] = pk;
+        if (pk != k) std::swap(A[k], A[pk]);
+        const double *Ak = A[k];
+        const double akk = Ak[k];
+        for (int i = k + 1; i < 8; i++) A[i][k] /= akk;
+        for (int i = k + 1; i < 8; i++) { double *Ai = A[i]; for (int j = k + 1; j < 8; j++) Ai[j] -= Ai[k] * Ak[j]; }
+    }
+    double x[8];
+    for (int i = 0; i < 8; i++) x[i] = d[i];
+    for (int i = 0; i < 8; i++) {
+        if (P[i] != i) std::swap(x[i], x[P[i]]);
+        for (int j = 0; j < i; j++) x[i] -= x[j] * A[i][j];
+    }
+    for (int i = 7; i >= 0; i--) {
+        for (int j = i + 1; j < 8; j++) x[i] -= x[j] * A[i][j];
+        x[i] /= A[i][i];
+    }
+    for (int i = 0; i < 8; i++) out[i] = x[i];
+    return HG_OK;
+}
+
+extern "C" int hg_transform_limits(int kind, const double *m, double w, double h, double out[4])
+{
+    if (!m || !out || (kind != HG_AFFINE && kind != HG_PROJECTIVE)) return fail(nullptr, HG_ERR_INVALID, "bad arguments");
+    double px[4], py[4];
+    const double cx[4] = { 0, 0, w, w }, cy[4] = { 0, h, 0, h };        // p0_0, p1_0, p0_1, p1_1 (:1506-1517)
+    for (int i = 0; i < 4; i++) {
+        if (kind == HG_AFFINE) apply_affine(m, cx[i], cy[i], px[i], py[i]); else apply_projective(m, cx[i], cy[i], px[i], py[i]);
+    }
+    auto mn4 = [](const double *v) { return js_min2(js_min2(v[0], v[1]), js_min2(v[2], v[3])); };
+    auto mx4 = [](const double *v) { return js_max2(js_max2(v[0], v[1]), js_max2(v[2], v[3])); };
+    const double xo = mn4(px), yo = mn4(py);
+    out[0] = js_round(xo); out[1] = js_round(yo);                        // :1525
+    out[2] = js_round(mx4(px) - xo); out[3] = js_round(mx4(py) - yo);
+    return HG_OK;
+}
+
+extern "C" int hg_minmax_xy(const float *p, int n, double out[4])
+{
+    if ((!p && n > 0) || !out || n < 0) return fail(nullptr, HG_ERR_INVALID, "bad arguments");
+    double maxX = -INFINITY, maxY = -INFINITY, minX = INFINITY, minY = INFINITY;
+    for (int i = 0; i < n; i++) {
+        const double e = p[i];
+        if ((i & 1) == 0) { if (e > maxX) maxX = e; if (e < minX) minX = e; }
+        else              { if (e > maxY) maxY = e; if (e < minY) minY = e; }
+    }
+    out[0] = js_round(minX); out[1] = js_round(minY); out[2] = js_round(maxX); out[3] = js_round(maxY);
+    return HG_OK;
+}
+
+extern "C" int hg_pack_offsets(const hg_geom *g, int n, size_t *offsets, size_t *total)
+{
+    if ((!g && n > 0) || n < 0) return fail(nullptr, HG_ERR_INVALID, "bad arguments");
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        if (offsets) offsets[i] = off;
+        const size_t bytes = (g[i].obj_w > 0 && g[i].obj_h > 0) ? (size_t)g[i].obj_w * (size_t)g[i].obj_h * 4 : 0;
+        off += (bytes + 255) & ~(size_t)255;
+    }
+    if (total) *total = off;
+    return HG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ source image
+extern "C" int hg_set_image(hg_ctx *c, const uint8_t *rgba, int w, int h)
+{
+    HG_TRY(bind(c));
+    if (!rgba || w <= 0 || h <= 0) return fail(c, HG_ERR_INVALID, "hg_set_image: bad image");
+    const size_t bytes = (size_t)w * h * 4;
+    if (c->img_aliased) { c->d_img = nullptr; c->img_cap = 0; c->img_aliased = false; }
+    HG_TRY(ensure(c, c->d_img, c->img_cap, bytes));
+    HIP_TRY(c, hipMemcpyAsync(c->d_img, rgba, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));       // caller memory is not retained after return
+    c->W = w; c->H = h;
+    return HG_OK;
+}
+
+extern "C" int hg_set_image_device(hg_ctx *c, const void *d_rgba, int w, int h)
+{
+    HG_TRY(bind(c));
+    if (!d_rgba || w <= 0 || h <= 0) return fail(c, HG_ERR_INVALID, "hg_set_image_device: bad image");
+    if (c->d_img && !c->img_aliased) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_img)); }
+    c->d_img = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_rgba));
+    c->img_cap = 0; c->img_aliased = true;
+    c->W = w; c->H = h;
+    return HG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ frames helpers
+static int fill_frames(hg_ctx *c, std::vector<FrameDesc> &v, const hg_geom *geoms, const size_t *offs, int n)
+{
+    v.resize(n);
+    size_t off = 0, moff = 0;
+    for (int i = 0; i < n; i++) {
+        FrameDesc &d = v[i];
+        d.x_off = geoms[i].x_off; d.y_off = geoms[i].y_off; d.obj_w = geoms[i].obj_w; d.obj_h = geoms[i].obj_h;
+        const size_t px = (d.obj_w > 0 && d.obj_h > 0) ? (size_t)d.obj_w * (size_t)d.obj_h : 0;
+        if (px > ((size_t)1 << 31)) return fail(c, HG_ERR_INVALID, "frame larger than 2^31 pixels");
+        d.out_off = offs ? offs[i] : off;
+        if (d.out_off & 3) return fail(c, HG_ERR_INVALID, "output offsets must be multiples of 4 bytes");
+        d.map_off = moff;
+        off += (px * 4 + 255) & ~(size_t)255;
+        moff += px;
+    }
+    return HG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ affine / projective
+extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, const hg_geom *geoms, const size_t *offs, int n)
+{
+    HG_TRY(bind(c));
+    if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m || !geoms || n <= 0) return fail(c, HG_ERR_INVALID, "hg_geometric_set_frames: bad arguments");
+    HG_TRY(fill_frames(c, c->geo_frames, geoms, offs, n));
+    HG_TRY(ensure(c, c->d_geo_frames, c->geo_frames_cap, (size_t)n));
+    HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)n * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, c->geo_frames.data(), sizeof(FrameDesc) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mats, m, sizeof(double) * 8 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->geo_kind = kind;
+    return HG_OK;
+}
+
+extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
+{
+    HG_TRY(bind(c));
+    if (!d_out) return fail(c, HG_ERR_INVALID, "d_out is NULL");
+    if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    if (c->geo_frames.empty()) return fail(c, HG_ERR_STATE, "no frames: call hg_geometric_set_frames first");
+    int mw = 0, mh = 0;
+    for (const FrameDesc &d : c->geo_frames) { mw = std::max(mw, d.obj_w); mh = std::max(mh, d.obj_h); }
+    HG_TRY(time_begin(c));
+    launch_geo(c->geo_kind, c->d_geo_frames, c->d_mats, (int)c->geo_frames.size(), mw, mh, c->d_img, c->W, c->H,
+               static_cast<uint8_t *>(d_out), c->stream);
+    HG_TRY(time_end(c));
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
+extern "C" int hg_warp_inverse_geometric_batch_device(hg_ctx *c, int kind, const double *m, const hg_geom *geoms,
+                                                      const size_t *offs, int n, void *d_out)
+{
+    HG_TRY(hg_geometric_set_frames(c, kind, m, geoms, offs, n));
+    return hg_warp_inverse_geometric_frames_device(c, d_out);
+}
+
+extern "C" int hg_warp_inverse_geometric_device(hg_ctx *c, int kind, const double *m, hg_geom geom, void *d_out)
+{
+    if (!m) return fail(c, HG_ERR_INVALID, "m is NULL");
+    double m8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    std::memcpy(m8, m, sizeof(double) * (kind == HG_AFFINE ? 6 : 8));
+    const size_t zero = 0;
+    return hg_warp_inverse_geometric_batch_device(c, kind, m8, &geom, &zero, 1, d_out);
+}
+
+extern "C" int hg_warp_inverse_geometric(hg_ctx *c, int kind, const double *m, hg_geom geom, uint8_t *out_host)
+{
+    HG_TRY(bind(c));
+    if (!out_host) return fail(c, HG_ERR_INVALID, "out is NULL");
+    if (geom.obj_w <= 0 || geom.obj_h <= 0) return HG_OK;
+    const size_t bytes = (size_t)geom.obj_w * geom.obj_h * 4;
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
+    HG_TRY(hg_warp_inverse_geometric_device(c, kind, m, geom, c->d_out_tmp));
+    HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ piecewise affine
+extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, const uint32_t *tris, int n_tris, int msx, int msy)
+{
+    HG_TRY(bind(c));
+    if (!src || n_pts <= 0 || n_tris < 0 || (!tris && n_tris > 0)) return fail(c, HG_ERR_INVALID, "hg_piecewise_set_mesh: bad arguments");
+    HG_TRY(ensure(c, c->d_src, c->src_cap, (size_t)n_pts * 2));
+    HG_TRY(ensure(c, c->d_tris, c->tris_cap, (size_t)std::max(n_tris, 1) * 3));
+    HIP_TRY(c, hipMemcpyAsync(c->d_src, src, sizeof(float) * 2 * n_pts, hipMemcpyHostToDevice, c->stream));
+    if (n_tris > 0) HIP_TRY(c, hipMemcpyAsync(c->d_tris, tris, sizeof(uint32_t) * 3 * n_tris, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_pts = n_pts; c->n_tris = n_tris; c->min_src_x = msx; c->min_src_y = msy;
+    c->have_mesh = true;
+    c->pw_frames.clear(); c->pw_setup_done = false;
+    return HG_OK;
+}
+
+extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n)
+{
+    HG_TRY(bind(c));
+    if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
+    if (!dst || !geoms || n <= 0) return fail(c, HG_ERR_INVALID, "hg_piecewise_set_frames: bad arguments");
+    HG_TRY(hg_sync(c));                                 // settle a pending run before its inputs are replaced
+    HG_TRY(fill_frames(c, c->pw_frames, geoms, offs, n));
+    const size_t T = (size_t)std::max(c->n_tris, 1), F = (size_t)n;
+    HG_TRY(ensure(c, c->d_pw_frames, c->pw_frames_cap, F));
+    HG_TRY(ensure(c, c->d_dst, c->dst_cap, F * c->n_pts * 2));
+    HG_TRY(ensure(c, c->d_trir, c->trir_cap, F * T));
+    HG_TRY(ensure(c, c->d_segs, c->segs_cap, F * T * 3));
+    HG_TRY(ensure(c, c->d_fwd, c->fwd_cap, F * T * 6));
+    HG_TRY(ensure(c, c->d_inv, c->inv_cap, F * T * kInvStride));
+    HG_TRY(ensure(c, c->d_status, c->status_cap, F));
+    if (F > c->h_status_cap) {
+        if (c->h_status) HIP_TRY(c, hipHostFree(c->h_status));
+        c->h_status = nullptr; c->h_status_cap = 0;
+        void *q = nullptr;
+        HIP_TRY(c, hipHostMalloc(&q, sizeof(int32_t) * F, hipHostMallocDefault));
+        c->h_status = static_cast<int32_t *>(q); c->h_status_cap = F;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, c->pw_frames.data(), sizeof(FrameDesc) * F, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_dst, dst, sizeof(float) * 2 * c->n_pts * F, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pw_setup_done = false;
+    return HG_OK;
+}
+
+extern "C" int hg_piecewise_prepare(hg_ctx *c, const float *dst, hg_geom geom)
+{
+    const size_t zero = 0;
+    return hg_piecewise_set_frames(c, dst, &geom, &zero, 1);
+}
+
+static PwMesh mesh_of(const hg_ctx *c)
+{
+    PwMesh m;
+    m.src_pts = c->d_src; m.tris = c->d_tris; m.n_pts = c->n_pts; m.n_tris = c->n_tris;
+    m.min_src_x = c->min_src_x; m.min_src_y = c->min_src_y; m.img = c->d_img; m.W = c->W; m.H = c->H;
+    return m;
+}
+
+static PwFrames frames_of(const hg_ctx *c)
+{
+    PwFrames f;
+    f.frames = c->d_pw_frames; f.dst_pts = c->d_dst; f.trir = c->d_trir; f.segs = c->d_segs; f.fwd = c->d_fwd; f.inv = c->d_inv;
+    f.status = c->d_status; f.n_frames = (int)c->pw_frames.size();
+    int mh = 0;
+    for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
+    f.max_obj_h = mh;
+    return f;
+}
+
+// per-frame solves (k_tri_setup); status words are reset first
+static int run_setup(hg_ctx *c)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->pw_frames.size(), c->stream));
+    launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->pw_setup_done = true;
+    return HG_OK;
+}
+
+static int check_pw_state(hg_ctx *c)
+{
+    if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
+    if (c->pw_frames.empty()) return fail(c, HG_ERR_STATE, "no frame prepared: call hg_piecewise_prepare / hg_piecewise_set_frames first");
+    return HG_OK;
+}
+
+// one frame through the materialised map (exact for any input)
+static int run_frame_via_map(hg_ctx *c, int f, uint8_t *d_out)
+{
+    const FrameDesc &fd = c->pw_frames[f];
+    const size_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h : 0;
+    if (n == 0) return HG_OK;
+    HG_TRY(ensure(c, c->d_map32, c->map32_cap, n));
+    launch_map_build(mesh_of(c), frames_of(c), f, fd, c->d_map32, c->stream);
+    launch_pw_from_map(mesh_of(c), frames_of(c), f, fd, c->d_map32, d_out, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
+extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
+{
+    HG_TRY(bind(c));
+    if (!d_out) return fail(c, HG_ERR_INVALID, "d_out is NULL");
+    HG_TRY(check_pw_state(c));
+    if (c->pw_status_pending) HG_TRY(hg_sync(c));
+    // The reference recomputes the per-triangle matrices on every setDestinyPoints and the map + inverses on every
+    // warp(): both are part of the per-frame step, so both run here every time.
+    HG_TRY(run_setup(c));
+    HG_TRY(time_begin(c));
+    launch_pw_fused(mesh_of(c), frames_of(c), static_cast<uint8_t *>(d_out), nullptr, c->stream);
+    HG_TRY(time_end(c));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
+    c->pw_status_pending = true;
+    c->pw_last_out = static_cast<uint8_t *>(d_out);
+    return HG_OK;
+}
+
+extern "C" int hg_sync(hg_ctx *c)
+{
+    HG_TRY(bind(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->pw_status_pending) {
+        c->pw_status_pending = false;
+        bool redo = false;
+        for (size_t f = 0; f < c->pw_frames.size(); f++) {
+            if (c->h_status[f] != FRAME_OK) { redo = true; HG_TRY(run_frame_via_map(c, (int)f, c->pw_last_out)); }
+        }
+        if (redo) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    const int d = c->deferred;
+    c->deferred = HG_OK;
+    return d;
+}
+
+extern "C" int hg_warp_inverse_piecewise_batch_device(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n, void *d_out)
+{
+    HG_TRY(hg_piecewise_set_frames(c, dst, geoms, offs, n));
+    return hg_warp_inverse_piecewise_frames_device(c, d_out);
+}
+
+extern "C" int hg_warp_inverse_piecewise_device(hg_ctx *c, void *d_out) { return hg_warp_inverse_piecewise_frames_device(c, d_out); }
+
+static int single_frame_bytes(hg_ctx *c, size_t *bytes)
+{
+    HG_TRY(check_pw_state(c));
+    if (c->pw_frames.size() != 1) return fail(c, HG_ERR_STATE, "this call needs exactly one prepared frame (hg_piecewise_prepare)");
+    const FrameDesc &fd = c->pw_frames[0];
+    *bytes = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h * 4 : 0;
+    return HG_OK;
+}
+
+extern "C" int hg_warp_inverse_piecewise(hg_ctx *c, uint8_t *out_host)
+{
+    HG_TRY(bind(c));
+    if (!out_host) return fail(c, HG_ERR_INVALID, "out is NULL");
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    if (bytes == 0) return HG_OK;
+    const uint64_t keep = c->pw_frames[0].out_off;
+    if (keep != 0) return fail(c, HG_ERR_STATE, "prepared frame has a non-zero output offset");
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
+    HG_TRY(hg_warp_inverse_piecewise_frames_device(c, c->d_out_tmp));
+    HG_TRY(hg_sync(c));
+    HIP_TRY(c, hipMemcpy(out_host, c->d_out_tmp, bytes, hipMemcpyDeviceToHost));
+    return HG_OK;
+}
+
+extern "C" int hg_warp_inverse_piecewise_via_map(hg_ctx *c, uint8_t *out_host)
+{
+    HG_TRY(bind(c));
+    if (!out_host) return fail(c, HG_ERR_INVALID, "out is NULL");
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    if (bytes == 0) return HG_OK;
+    HG_TRY(hg_sync(c));
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
+    HG_TRY(run_setup(c));
+    HG_TRY(run_frame_via_map(c, 0, c->d_out_tmp));
+    HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HG_OK;
+}
+
+extern "C" int hg_get_tri_map(hg_ctx *c, int16_t *out, size_t len)
+{
+    HG_TRY(bind(c));
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    const size_t n = bytes / 4;
+    if (!out || len != n) return fail(c, HG_ERR_INVALID, "hg_get_tri_map: len must be obj_w*obj_h");
+    if (n == 0) return HG_OK;
+    HG_TRY(hg_sync(c));
+    HG_TRY(run_setup(c));
+    HG_TRY(ensure(c, c->d_map32, c->map32_cap, n));
+    HG_TRY(ensure(c, c->d_map16, c->map16_cap, n));
+    launch_map_build(mesh_of(c), frames_of(c), 0, c->pw_frames[0], c->d_map32, c->stream);
+    launch_map_to_i16(c->d_map32, c->d_map16, n, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_map16, n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HG_OK;
+}
+
+extern "C" int hg_get_tri_map_fused(hg_ctx *c, int16_t *out, size_t len)
+{
+    HG_TRY(bind(c));
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    const size_t n = bytes / 4;
+    if (!out || len != n) return fail(c, HG_ERR_INVALID, "hg_get_tri_map_fused: len must be obj_w*obj_h");
+    if (n == 0) return HG_OK;
+    HG_TRY(hg_sync(c));
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
+    HG_TRY(ensure(c, c->d_map16, c->map16_cap, n));
+    HG_TRY(run_setup(c));
+    launch_pw_fused(mesh_of(c), frames_of(c), c->d_out_tmp, c->d_map16, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_status[0] != FRAME_OK)
+        return fail(c, HG_ERR_STATE, c->h_status[0] & FRAME_IRREGULAR ? "frame is irregular: the fused path defers it to the map path"
+                                                                     : "a row overflowed the fused kernel's LDS span list");
+    HIP_TRY(c, hipMemcpy(out, c->d_map16, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return HG_OK;
+}
+
+extern "C" int hg_get_matrices(hg_ctx *c, float *fwd, float *inv)
+{
+    HG_TRY(bind(c));
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    HG_TRY(hg_sync(c));
+    if (!c->pw_setup_done) HG_TRY(run_setup(c));
+    const size_t T = (size_t)c->n_tris;
+    if (T == 0) return HG_OK;
+    if (fwd) HIP_TRY(c, hipMemcpyAsync(fwd, c->d_fwd, sizeof(float) * 6 * T, hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> tmp;
+    if (inv) { tmp.resize(T * kInvStride); HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_inv, sizeof(float) * kInvStride * T, hipMemcpyDeviceToHost, c->stream)); }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (inv) for (size_t t = 0; t < T; t++) std::memcpy(inv + 6 * t, tmp.data() + kInvStride * t, sizeof(float) * 6);
+    return HG_OK;
+}

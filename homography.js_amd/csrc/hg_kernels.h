@@ -1,0 +1,73 @@
+// hg_kernels.h -- device-side data layout and kernel launchers (implemented in hg_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hg_math.h"
+
+namespace hg {
+
+// One output frame (one destination point set / one matrix): the reference's
+// (_xOutputOffset, _yOutputOffset, _objectiveWidth, _objectiveHeight) plus where its RGBA goes.
+struct FrameDesc {
+    int32_t x_off, y_off, obj_w, obj_h;
+    uint64_t out_off;        // byte offset of this frame's RGBA8 in the output allocation
+    uint64_t map_off;        // cell offset of this frame in the optional int16 debug-map allocation
+};
+
+// Per (frame, triangle) raster parameters produced by k_tri_setup.
+//   rows y in [y_min, y_end) are the rows fillTriangle visits (:1113-1120);
+//   a, b bound which output rows a row-y span can touch:  (y - yOff) in [r - a, r - b]  (see DESIGN.md §4.2).
+struct TriRange { int32_t y_min, y_end, a, b; };
+
+// Per-frame status word written by the kernels.
+enum : int32_t {
+    FRAME_OK = 0,
+    FRAME_IRREGULAR = 1,     // a triangle with non-finite / absurd vertices or wider than the whole map: fused path skipped
+    FRAME_LDS_OVERFLOW = 2   // some row crossed more spans than the fused kernel's LDS list holds: frame must be redone
+};
+
+constexpr int kRowSpanCap = 1024;   // spans per output row held in LDS by the fused piecewise kernel
+constexpr int kInvStride = 8;       // floats per inverse matrix on the device (6 used; 32-byte rows)
+
+struct PwMesh {                     // source side of the mesh + source image (shared by all frames)
+    const float *src_pts;           // n_pts x 2
+    const uint32_t *tris;           // n_tris x 3
+    int32_t n_pts, n_tris;
+    int32_t min_src_x, min_src_y;
+    const uint8_t *img;             // RGBA8 source, W*H*4 bytes
+    int32_t W, H;
+};
+
+struct PwFrames {                   // per-frame device arrays, frame-major
+    const FrameDesc *frames;
+    const float *dst_pts;           // F x n_pts x 2
+    TriRange *trir;                 // F x n_tris
+    Seg *segs;                      // F x n_tris x 3
+    float *fwd;                     // F x n_tris x 6
+    float *inv;                     // F x n_tris x kInvStride
+    int32_t *status;                // F
+    int32_t n_frames;
+    int32_t max_obj_h;              // max over frames (grid size)
+};
+
+// k_tri_setup: per (frame, triangle): forward affine (:785-804, :1265-1306), its inverse (:1036-1038, :1345-1365),
+// edge equations (:1141-1151) and row range (:1113-1115).
+void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream);
+
+// k_pw_fused: _inversePiecewiseAffineWarp :1029-1058 for all frames, one workgroup per output row, without a
+// materialised triangle map.  map_out (optional, int16 per output pixel) receives the per-pixel triangle id the
+// lookup resolved == the reference's _trianglesCorrespondencesMatrix.
+void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16_t *map_out, hipStream_t stream);
+
+// Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
+// the pixel loop :1042-1056 reading the map.
+void launch_map_build(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, int32_t *map32, hipStream_t stream);
+void launch_pw_from_map(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, const int32_t *map32,
+                        uint8_t *out, hipStream_t stream);
+void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream_t stream);
+
+// k_geo: _inverseGeometricWarp pixel loop :997-1011 for all frames.  mats = F x 8 doubles (inverse matrices).
+void launch_geo(int kind, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
+                const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
+
+} // namespace hg

@@ -1,0 +1,304 @@
+"""ctypes binding of lib/libhgwarp.so (C ABI: include/hgwarp.h).
+
+Plumbing only: used by tests/, bench.py and __graft_entry__.py.  The product's host side is the drop-in JavaScript
+class js/Homography.mjs over the N-API addon; this module exposes the same C entry points to Python 1:1 and adds
+nothing on top (no CPU fallback: if the library or a gfx950 GPU is missing, calls raise).
+
+The directory name contains a dot, so load this file by path:
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location("hgwarp", ".../homography.js_amd/hgwarp.py")
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libhgwarp.so")
+
+HG_AFFINE, HG_PROJECTIVE = 0, 1
+
+# every symbol include/hgwarp.h declares (tests check that the built library exports all of them)
+EXPORTS = [
+    "hg_version", "hg_device_count", "hg_create", "hg_create_on_stream", "hg_destroy", "hg_last_error", "hg_sync",
+    "hg_device_alloc", "hg_device_free", "hg_copy_to_host",
+    "hg_solve_affine", "hg_invert_affine", "hg_solve_projective", "hg_transform_limits", "hg_minmax_xy", "hg_js_round",
+    "hg_set_image", "hg_set_image_device",
+    "hg_warp_inverse_geometric", "hg_warp_inverse_geometric_device", "hg_geometric_set_frames",
+    "hg_warp_inverse_geometric_frames_device", "hg_warp_inverse_geometric_batch_device", "hg_pack_offsets",
+    "hg_piecewise_set_mesh", "hg_piecewise_prepare", "hg_warp_inverse_piecewise", "hg_warp_inverse_piecewise_device",
+    "hg_piecewise_set_frames", "hg_warp_inverse_piecewise_frames_device", "hg_warp_inverse_piecewise_batch_device",
+    "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats",
+]
+
+
+class Geom(C.Structure):
+    _fields_ = [("x_off", C.c_int32), ("y_off", C.c_int32), ("obj_w", C.c_int32), ("obj_h", C.c_int32)]
+
+
+class HgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hgwarp error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libhgwarp.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HgError(-1, f"{LIB_PATH} is missing: build it with `make -C homography.js_amd` (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    vp, i, sz, d = C.c_void_p, C.c_int, C.c_size_t, C.c_double
+    f32p, f64p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    sig = {
+        "hg_version": (i, []), "hg_device_count": (i, [C.POINTER(i)]),
+        "hg_create": (i, [i, C.POINTER(vp)]), "hg_create_on_stream": (i, [i, vp, C.POINTER(vp)]), "hg_destroy": (None, [vp]),
+        "hg_last_error": (C.c_char_p, [vp]), "hg_sync": (i, [vp]),
+        "hg_device_alloc": (i, [vp, sz, C.POINTER(vp)]), "hg_device_free": (i, [vp, vp]), "hg_copy_to_host": (i, [vp, vp, vp, sz]),
+        "hg_solve_affine": (i, [f32p, f32p, f32p]), "hg_invert_affine": (i, [f32p, f32p]), "hg_solve_projective": (i, [f32p, f32p, f64p]),
+        "hg_transform_limits": (i, [i, f64p, d, d, f64p]), "hg_minmax_xy": (i, [f32p, i, f64p]), "hg_js_round": (d, [d]),
+        "hg_set_image": (i, [vp, u8p, i, i]), "hg_set_image_device": (i, [vp, vp, i, i]),
+        "hg_warp_inverse_geometric": (i, [vp, i, f64p, Geom, u8p]), "hg_warp_inverse_geometric_device": (i, [vp, i, f64p, Geom, vp]),
+        "hg_geometric_set_frames": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i]),
+        "hg_warp_inverse_geometric_frames_device": (i, [vp, vp]),
+        "hg_warp_inverse_geometric_batch_device": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
+        "hg_pack_offsets": (i, [C.POINTER(Geom), i, C.POINTER(sz), C.POINTER(sz)]),
+        "hg_piecewise_set_mesh": (i, [vp, f32p, i, C.POINTER(C.c_uint32), i, i, i]),
+        "hg_piecewise_prepare": (i, [vp, f32p, Geom]),
+        "hg_warp_inverse_piecewise": (i, [vp, u8p]), "hg_warp_inverse_piecewise_device": (i, [vp, vp]),
+        "hg_piecewise_set_frames": (i, [vp, f32p, C.POINTER(Geom), C.POINTER(sz), i]),
+        "hg_warp_inverse_piecewise_frames_device": (i, [vp, vp]),
+        "hg_warp_inverse_piecewise_batch_device": (i, [vp, f32p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
+        "hg_get_tri_map": (i, [vp, C.POINTER(C.c_int16), sz]), "hg_get_tri_map_fused": (i, [vp, C.POINTER(C.c_int16), sz]),
+        "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
+        "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
+        "hg_kernel_ms_stats": (i, [vp, f64p, C.POINTER(i)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _geoms(gs):
+    arr = (Geom * len(gs))(*[Geom(*[int(v) for v in g]) for g in gs])
+    return arr
+
+
+def _check(code, ctx=None):
+    if code != 0:
+        msg = lib().hg_last_error(ctx)
+        raise HgError(code, msg.decode() if msg else "?")
+
+
+# ------------------------------------------------------------------ host-side solves (no GPU needed)
+
+def solve_affine(src, dst):
+    (_, s), (_, d) = _f32(src), _f32(dst)
+    out = np.empty(6, np.float32)
+    _check(lib().hg_solve_affine(s, d, out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def invert_affine(m):
+    _, p = _f32(m)
+    out = np.empty(6, np.float32)
+    _check(lib().hg_invert_affine(p, out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def solve_projective(src, dst):
+    (_, s), (_, d) = _f32(src), _f32(dst)
+    out = np.empty(8, np.float64)
+    _check(lib().hg_solve_projective(s, d, out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def transform_limits(kind, m, w, h):
+    _, p = _f64(m)
+    out = np.empty(4, np.float64)
+    _check(lib().hg_transform_limits(int(kind), p, float(w), float(h), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def minmax_xy(pts):
+    a, p = _f32(pts)
+    out = np.empty(4, np.float64)
+    _check(lib().hg_minmax_xy(p, a.size, out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def js_round(x):
+    return lib().hg_js_round(float(x))
+
+
+def pack_offsets(geoms):
+    g = _geoms(geoms)
+    offs = (C.c_size_t * len(geoms))()
+    total = C.c_size_t(0)
+    _check(lib().hg_pack_offsets(g, len(geoms), offs, C.byref(total)))
+    return list(offs), total.value
+
+
+def device_count():
+    n = C.c_int(0)
+    code = lib().hg_device_count(C.byref(n))
+    return n.value if code == 0 else 0
+
+
+# ------------------------------------------------------------------ context
+
+class Context:
+    """One hg_ctx (one GPU, one stream) == the device side of one Homography instance."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        L = lib()
+        if stream is None:
+            code = L.hg_create(int(device), C.byref(self._h))
+        else:
+            code = L.hg_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(self._h))
+        if code != 0:
+            self._h = C.c_void_p()
+            _check(code)
+
+    def close(self):
+        if self._h:
+            lib().hg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _c(self, code):
+        _check(code, self._h)
+
+    # ---- plumbing
+    def sync(self):
+        self._c(lib().hg_sync(self._h))
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._c(lib().hg_device_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, dptr):
+        self._c(lib().hg_device_free(self._h, C.c_void_p(dptr)))
+
+    def to_host(self, dptr, nbytes, offset=0):
+        out = np.empty(int(nbytes), np.uint8)
+        self._c(lib().hg_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr + offset), int(nbytes)))
+        return out
+
+    def set_timing(self, on=True):
+        self._c(lib().hg_set_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._c(lib().hg_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def kernel_ms_stats(self):
+        """(total ms, launches) of the dominant kernel since set_timing(True)."""
+        tot, n = C.c_double(0), C.c_int(0)
+        self._c(lib().hg_kernel_ms_stats(self._h, C.byref(tot), C.byref(n)))
+        return tot.value, n.value
+
+    # ---- image
+    def set_image(self, rgba):
+        a = np.ascontiguousarray(rgba, dtype=np.uint8)
+        h, w = a.shape[:2]
+        self._c(lib().hg_set_image(self._h, a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h))
+
+    def set_image_device(self, dptr, w, h):
+        self._c(lib().hg_set_image_device(self._h, C.c_void_p(int(dptr)), int(w), int(h)))
+
+    # ---- affine / projective
+    def warp_inverse_geometric(self, kind, m, geom):
+        _, p = _f64(m)
+        g = Geom(*[int(v) for v in geom])
+        out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
+        self._c(lib().hg_warp_inverse_geometric(self._h, int(kind), p, g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def geometric_set_frames(self, kind, mats, geoms, offsets=None):
+        m, p = _f64(mats)
+        assert m.size == 8 * len(geoms)
+        offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
+        self._c(lib().hg_geometric_set_frames(self._h, int(kind), p, _geoms(geoms), offs, len(geoms)))
+
+    def warp_inverse_geometric_frames_device(self, d_out):
+        self._c(lib().hg_warp_inverse_geometric_frames_device(self._h, C.c_void_p(int(d_out))))
+
+    # ---- piecewise
+    def piecewise_set_mesh(self, src_pts, tris, min_src_x, min_src_y):
+        s, sp = _f32(src_pts)
+        t = np.ascontiguousarray(tris, dtype=np.uint32)
+        self._c(lib().hg_piecewise_set_mesh(self._h, sp, s.size // 2, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size // 3,
+                                            int(min_src_x), int(min_src_y)))
+
+    def piecewise_prepare(self, dst_pts, geom):
+        _, dp = _f32(dst_pts)
+        self._geom = Geom(*[int(v) for v in geom])
+        self._c(lib().hg_piecewise_prepare(self._h, dp, self._geom))
+
+    def _out_array(self):
+        g = self._geom
+        return np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
+
+    def warp_inverse_piecewise(self):
+        out = self._out_array()
+        self._c(lib().hg_warp_inverse_piecewise(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def warp_inverse_piecewise_via_map(self):
+        out = self._out_array()
+        self._c(lib().hg_warp_inverse_piecewise_via_map(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def get_tri_map(self, fused=False):
+        g = self._geom
+        m = np.empty(max(g.obj_w, 0) * max(g.obj_h, 0), np.int16)
+        fn = lib().hg_get_tri_map_fused if fused else lib().hg_get_tri_map
+        self._c(fn(self._h, m.ctypes.data_as(C.POINTER(C.c_int16)), m.size))
+        return m
+
+    def get_matrices(self, n_tris):
+        fwd = np.empty((n_tris, 6), np.float32)
+        inv = np.empty((n_tris, 6), np.float32)
+        self._c(lib().hg_get_matrices(self._h, fwd.ctypes.data_as(C.POINTER(C.c_float)), inv.ctypes.data_as(C.POINTER(C.c_float))))
+        return fwd, inv
+
+    def piecewise_set_frames(self, dst_pts, geoms, offsets=None):
+        d, dp = _f32(dst_pts)
+        offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
+        self._c(lib().hg_piecewise_set_frames(self._h, dp, _geoms(geoms), offs, len(geoms)))
+
+    def warp_inverse_piecewise_frames_device(self, d_out):
+        self._c(lib().hg_warp_inverse_piecewise_frames_device(self._h, C.c_void_p(int(d_out))))

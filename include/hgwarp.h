@@ -1,0 +1,158 @@
+/*
+ * hgwarp.h -- C ABI of libhgwarp.so, the MI355X (gfx950) inverse-warp engine that sits behind the Homography.js
+ * `Homography` class for its per-pixel hot path.
+ *
+ * The reference (Eric-Canas/Homography.js v1.8.0) has no FFI seam: the seam is the ES-module class itself.  Each
+ * entry point below therefore names the reference *function* it replaces (file:line into the reference's
+ * Homography.js).  The bindings that call this ABI are
+ *     homography.js_amd/csrc/hgwarp_napi.c   (N-API addon used by the drop-in JS class homography.js_amd/js/Homography.mjs)
+ *     homography.js_amd/hgwarp.py            (ctypes; used by tests/, bench.py and __graft_entry__.py)
+ * and INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns an int status (HG_OK == 0); hg_last_error() gives the text of the last failure;
+ *   - plain pointers + sizes, no C++/torch types; caller memory is never retained after return unless the function
+ *     name ends in `_device` and says "aliased";
+ *   - one hg_ctx per Homography instance; a ctx is bound to one GPU and one HIP stream and is not thread-safe;
+ *     distinct ctxs are independent;
+ *   - images are RGBA8, row-major, 4*W*H bytes (Uint8ClampedArray of an ImageData, reference :297-299);
+ *   - points are interleaved x,y float32 (the reference's Float32Array, :220/:339); triangles are 3 uint32 vertex ids
+ *     each (Delaunator's `.triangles`, :1217); per-triangle matrices are 6 float32 [a,b,c,d,e,f] with
+ *     x' = a*x + c*y + e, y' = b*x + d*y + f (:1297-1304);
+ *   - functions ending in `_device` take/leave data in GPU memory and are asynchronous on the ctx stream
+ *     (hg_sync() waits and reports deferred errors); the others are synchronous like the reference's warp();
+ *   - there is NO CPU fallback: without a usable gfx950 device hg_create() fails and nothing warps.
+ */
+#ifndef HGWARP_H
+#define HGWARP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HG_VERSION 100          /* 0.1.0 */
+
+enum {
+    HG_OK = 0,
+    HG_ERR_INVALID = 1,         /* bad argument (NULL pointer, negative size, unknown kind) */
+    HG_ERR_HIP = 2,             /* a HIP runtime call failed (text in hg_last_error) */
+    HG_ERR_NO_DEVICE = 3,       /* no usable GPU / device id out of range */
+    HG_ERR_STATE = 4,           /* call order: image / mesh / prepared frame missing */
+    HG_ERR_NOMEM = 5
+};
+
+enum { HG_AFFINE = 0, HG_PROJECTIVE = 1 };
+
+typedef struct hg_ctx hg_ctx;
+
+/* Output window of one frame, the reference's (_xOutputOffset, _yOutputOffset, _objectiveWidth, _objectiveHeight). */
+typedef struct hg_geom { int32_t x_off, y_off, obj_w, obj_h; } hg_geom;
+
+/* ------------------------------------------------------------------------------------------------ library / context */
+int hg_version(void);
+int hg_device_count(int *count);
+/* Replaces `new Homography()` (:78) for the device side: owns a stream and the device buffers. */
+int hg_create(int device_id, hg_ctx **ctx);
+/* Same, but launches on a stream owned by the caller (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream). */
+int hg_create_on_stream(int device_id, void *hip_stream, hg_ctx **ctx);
+void hg_destroy(hg_ctx *ctx);
+/* Text of the last error on this ctx (or, with ctx == NULL, of the last failed hg_create / host call of this thread). */
+const char *hg_last_error(const hg_ctx *ctx);
+/* Waits for the ctx stream; returns the first deferred error of the asynchronous `_device` calls since the last sync. */
+int hg_sync(hg_ctx *ctx);
+/* Device scratch/output helpers so that bindings without a device allocator (Node) can keep frames resident. */
+int hg_device_alloc(hg_ctx *ctx, size_t bytes, void **dptr);
+int hg_device_free(hg_ctx *ctx, void *dptr);
+int hg_copy_to_host(hg_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+
+/* ------------------------------------------------------------------------------------------------ host-side solves
+ * Tiny, run on the host in double precision with the reference's exact operation order; no GPU needed. */
+/* affineMatrixFromTriangles :1265-1306 */
+int hg_solve_affine(const float src[6], const float dst[6], float out[6]);
+/* inverseAffineMatrix :1345-1365 */
+int hg_invert_affine(const float m[6], float out[6]);
+/* projectiveMatrixFromSquares :1320-1333 + numeric.js solve/LU/LUsolve :1650-1751; out = h0..h7 (h8 == 1) */
+int hg_solve_projective(const float src[8], const float dst[8], double out[8]);
+/* calculateTransformLimits :1503-1527; kind HG_AFFINE (m[0..5]) / HG_PROJECTIVE (m[0..7]); out = xOff,yOff,objW,objH
+ * as doubles exactly as JS computes them (may be NaN/Inf for degenerate matrices). */
+int hg_transform_limits(int kind, const double *m, double width, double height, double out[4]);
+/* minmaxXYofArray(array, rounded=true) :1558-1589; out = round(minX), round(minY), round(maxX), round(maxY) */
+int hg_minmax_xy(const float *points, int n_values, double out[4]);
+/* Math.round (ties toward +Infinity), exposed so that bindings share one definition. */
+double hg_js_round(double x);
+
+/* ------------------------------------------------------------------------------------------------ source image */
+/* setImage, ImageData branch :297-299: uploads RGBA8 (the reference aliases caller memory and re-reads it on every
+ * warp(); callers that mutate the buffer call this again). */
+int hg_set_image(hg_ctx *ctx, const uint8_t *rgba, int width, int height);
+/* Same, source already in GPU memory (aliased, not copied: it must stay alive and unchanged while warps run).
+ * This is how a source texture received by an RCCL broadcast is attached without another copy. */
+int hg_set_image_device(hg_ctx *ctx, const void *d_rgba, int width, int height);
+
+/* ------------------------------------------------------------------------------------------------ affine / projective
+ * _inverseGeometricWarp pixel loop :997-1011 (+ applyAffineTransformToPoint :1382 / applyProjectiveTransformToPoint
+ * :1401).  `m` is the INVERSE matrix the reference obtains at :994 by re-solving with the point sets swapped
+ * (hg_solve_affine(dst, src) widened to double, or hg_solve_projective(dst, src)): 6 resp. 8 doubles.
+ * Output: 4*obj_w*obj_h bytes, every pixel written (0 where the reference leaves the zero-initialised buffer). */
+int hg_warp_inverse_geometric(hg_ctx *ctx, int kind, const double *m, hg_geom geom, uint8_t *out_host);
+int hg_warp_inverse_geometric_device(hg_ctx *ctx, int kind, const double *m, hg_geom geom, void *d_out);
+/* The caller loop `setDestinyPoints(dst_f); warp()` (test/benchmark.js:107-110) for F frames in one launch:
+ * m = F x 8 doubles (affine uses the first 6 of each 8), geoms = F windows, out_offsets = F byte offsets into d_out
+ * (NULL: packed as hg_pack_offsets does).  set_frames uploads the per-frame inputs (kept until replaced);
+ * frames_device runs all uploaded frames; batch_device = both. */
+int hg_geometric_set_frames(hg_ctx *ctx, int kind, const double *m, const hg_geom *geoms, const size_t *out_offsets, int n_frames);
+int hg_warp_inverse_geometric_frames_device(hg_ctx *ctx, void *d_out);
+int hg_warp_inverse_geometric_batch_device(hg_ctx *ctx, int kind, const double *m, const hg_geom *geoms,
+                                           const size_t *out_offsets, int n_frames, void *d_out);
+/* Packed output layout for n frames: offsets[i] = start of frame i (256-byte aligned), *total = bytes needed. */
+int hg_pack_offsets(const hg_geom *geoms, int n_frames, size_t *offsets, size_t *total);
+
+/* ------------------------------------------------------------------------------------------------ piecewise affine
+ * Source side of the mesh, kept across frames like the reference's cached _srcPoints/_triangles/_minSrcX/_minSrcY
+ * (:742, :758).  min_src_x/min_src_y are the rounded source-point bbox minimum used by the bounds test :1047. */
+int hg_piecewise_set_mesh(hg_ctx *ctx, const float *src_points, int n_points, const uint32_t *triangles, int n_triangles,
+                          int min_src_x, int min_src_y);
+/* Per-frame destination side = what setDestinyPoints + the head of _inversePiecewiseAffineWarp recompute every frame:
+ * _calculatePiecewiseAffineTransformMatrices :785-804 (affineMatrixFromTriangles per triangle, f32),
+ * inverseAffineMatrix per triangle :1036-1038, and the edge equations / row ranges of fillTriangle :1111-1151.
+ * All on the device; dst_points are n_points x,y float32 in pixel coordinates. */
+int hg_piecewise_prepare(hg_ctx *ctx, const float *dst_points, hg_geom geom);
+/* _inversePiecewiseAffineWarp :1029-1058 for the prepared frame.  The triangle-index map of
+ * _buildInverseTrianglesCorrespondencesMatrix :845-861 is not materialised: each output row's triangle spans
+ * (fillTriangle/predictXLimits, with TypedArray.fill index semantics) are rebuilt in LDS and resolved per pixel with
+ * "largest covering id wins", which equals the reference's sequential overwrite. */
+int hg_warp_inverse_piecewise(hg_ctx *ctx, uint8_t *out_host);
+int hg_warp_inverse_piecewise_device(hg_ctx *ctx, void *d_out);
+/* F frames (F destination point sets on the mesh set above) in one pass: dst_points = F x n_points x 2 float32.
+ * set_frames uploads points + windows (kept until replaced; hg_piecewise_prepare == set_frames with one frame);
+ * frames_device runs the per-frame solves and the warp for all uploaded frames; batch_device = both. */
+int hg_piecewise_set_frames(hg_ctx *ctx, const float *dst_points, const hg_geom *geoms, const size_t *out_offsets, int n_frames);
+int hg_warp_inverse_piecewise_frames_device(hg_ctx *ctx, void *d_out);
+int hg_warp_inverse_piecewise_batch_device(hg_ctx *ctx, const float *dst_points, const hg_geom *geoms,
+                                           const size_t *out_offsets, int n_frames, void *d_out);
+/* Parity taps (debug / tests): the Int16Array map the reference would have built for the prepared frame
+ * (len = obj_w*obj_h), via the materialising kernel (atomicMax rasteriser) or via the fused kernel's own lookup;
+ * and the per-triangle forward / inverse matrices (n_triangles x 6 float32 each; either may be NULL). */
+int hg_get_tri_map(hg_ctx *ctx, int16_t *out, size_t len);
+int hg_get_tri_map_fused(hg_ctx *ctx, int16_t *out, size_t len);
+int hg_get_matrices(hg_ctx *ctx, float *fwd, float *inv);
+/* Same warp through the materialised map (map build kernel + map-reading warp kernel).  Always available; it is also
+ * what the library itself re-runs for a frame whose rows overflow the fused kernel's LDS span list. */
+int hg_warp_inverse_piecewise_via_map(hg_ctx *ctx, uint8_t *out_host);
+
+/* ------------------------------------------------------------------------------------------------ measurement aid
+ * hipEvent pairs recorded on the ctx stream around each launch of the dominant kernel (the fused piecewise kernel or
+ * the geometric kernel; not the tiny per-triangle setup).  hg_set_timing(ctx, 1) enables it and resets the counters;
+ * hg_last_kernel_ms = duration of the most recent launch; hg_kernel_ms_stats = sum over (up to the last 256) launches
+ * since the reset and how many that is.  Both wait for the stream. */
+int hg_set_timing(hg_ctx *ctx, int enabled);
+int hg_last_kernel_ms(hg_ctx *ctx, float *ms);
+int hg_kernel_ms_stats(hg_ctx *ctx, double *total_ms, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGWARP_H */
