@@ -41,7 +41,12 @@ struct hg_ctx {
     float *d_inv = nullptr; size_t inv_cap = 0;
     int32_t *d_status = nullptr; size_t status_cap = 0;
     int32_t *h_status = nullptr; size_t h_status_cap = 0;      // pinned
-    bool pw_setup_done = false;                                // k_tri_setup ran for the uploaded frames
+    bool pw_setup_done = false;                                // the per-triangle solves ran for the uploaded frames
+    // fast path: per-output-row span lists
+    int32_t *d_rowcnt = nullptr; size_t rowcnt_cap = 0;
+    RowEnt *d_rowent = nullptr; size_t rowent_cap = 0;
+    int row_cap = 64;                                          // entries per row; grows (sticky) after an overflow
+    bool pw_fast = false;                                      // uploaded frames are eligible for k_tri_spans/k_pw_rows
     bool pw_status_pending = false;                            // a fused run's status has not been checked yet
     uint8_t *pw_last_out = nullptr;
 
@@ -151,7 +156,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
-    void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status,
+    void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent,
                      c->d_geo_frames, c->d_mats, c->d_map32, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -516,14 +521,44 @@ static PwFrames frames_of(const hg_ctx *c)
     return f;
 }
 
-// per-frame solves (k_tri_setup); status words are reset first
+static RowLists rows_of(const hg_ctx *c)
+{
+    RowLists r;
+    r.cnt = c->d_rowcnt; r.ent = c->d_rowent; r.cap = c->row_cap;
+    int mh = 0;
+    for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
+    r.row_stride = std::max(mh, 1);
+    return r;
+}
+
+// per-frame solves; status words are reset first.  Fast path: k_tri_spans (solves + per-row span lists);
+// general path (more than 32767 triangles, huge sources, negative source minimum): k_tri_setup.
 static int run_setup(hg_ctx *c)
 {
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * c->pw_frames.size(), c->stream));
-    launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
+    const size_t F = c->pw_frames.size();
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * F, c->stream));
+    int mw = 0;
+    for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
+    c->pw_fast = pw_fast_ok(mesh_of(c), mw);
+    if (c->pw_fast) {
+        RowLists rl = rows_of(c);
+        HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, F * rl.row_stride));
+        HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, F * (size_t)rl.row_stride * rl.cap));
+        rl = rows_of(c);
+        HIP_TRY(c, hipMemsetAsync(c->d_rowcnt, 0, sizeof(int32_t) * F * rl.row_stride, c->stream));
+        launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
+    } else {
+        launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
+    }
     HIP_TRY(c, hipGetLastError());
     c->pw_setup_done = true;
     return HG_OK;
+}
+
+static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
+{
+    if (c->pw_fast) launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->stream);
+    else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
 }
 
 static int check_pw_state(hg_ctx *c)
@@ -557,7 +592,7 @@ extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
     // warp(): both are part of the per-frame step, so both run here every time.
     HG_TRY(run_setup(c));
     HG_TRY(time_begin(c));
-    launch_pw_fused(mesh_of(c), frames_of(c), static_cast<uint8_t *>(d_out), nullptr, c->stream);
+    run_warp(c, static_cast<uint8_t *>(d_out), nullptr);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
@@ -576,7 +611,10 @@ extern "C" int hg_sync(hg_ctx *c)
         for (size_t f = 0; f < c->pw_frames.size(); f++) {
             if (c->h_status[f] != FRAME_OK) { redo = true; HG_TRY(run_frame_via_map(c, (int)f, c->pw_last_out)); }
         }
-        if (redo) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (redo) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->pw_fast && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // denser mesh than assumed: larger lists next time
+        }
     }
     const int d = c->deferred;
     c->deferred = HG_OK;
@@ -664,7 +702,7 @@ extern "C" int hg_get_tri_map_fused(hg_ctx *c, int16_t *out, size_t len)
     HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
     HG_TRY(ensure(c, c->d_map16, c->map16_cap, n));
     HG_TRY(run_setup(c));
-    launch_pw_fused(mesh_of(c), frames_of(c), c->d_out_tmp, c->d_map16, c->stream);
+    run_warp(c, c->d_out_tmp, c->d_map16);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -26,7 +26,8 @@ enum : int32_t {
     FRAME_LDS_OVERFLOW = 2   // some row crossed more spans than the fused kernel's LDS list holds: frame must be redone
 };
 
-constexpr int kRowSpanCap = 1024;   // spans per output row held in LDS by the fused piecewise kernel
+constexpr int kRowSpanCap = 1024;   // spans per output row held in LDS by the general fused kernel (k_pw_fused)
+constexpr int kRowSpanCapFast = 256; // ... by the fast kernel (k_pw_rows), which also keeps a 48-byte matrix per span
 constexpr int kInvStride = 8;       // floats per inverse matrix on the device (6 used; 32-byte rows)
 
 struct PwMesh {                     // source side of the mesh + source image (shared by all frames)
@@ -50,6 +51,16 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t max_obj_h;              // max over frames (grid size)
 };
 
+// Per-output-row span lists of the fast path (k_tri_spans -> k_pw_rows), in global memory.
+struct RowEnt { uint32_t lo_hi; int32_t id; float m[6]; };      // cells [lo,hi) of the row (16 bits each), triangle id, inverse matrix
+static_assert(sizeof(RowEnt) == 32, "RowEnt must be 32 bytes");
+struct RowLists {
+    int32_t *cnt;            // F x row_stride   (zeroed before every k_tri_spans launch)
+    RowEnt *ent;             // F x row_stride x cap
+    int32_t row_stride;      // >= max obj_h
+    int32_t cap;             // entries per row
+};
+
 // k_tri_setup: per (frame, triangle): forward affine (:785-804, :1265-1306), its inverse (:1036-1038, :1345-1365),
 // edge equations (:1141-1151) and row range (:1113-1115).
 void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream);
@@ -58,6 +69,11 @@ void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream
 // materialised triangle map.  map_out (optional, int16 per output pixel) receives the per-pixel triangle id the
 // lookup resolved == the reference's _trianglesCorrespondencesMatrix.
 void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16_t *map_out, hipStream_t stream);
+
+// Fast path (see hg_kernels.hip): eligibility, span-list build (includes the per-triangle solves), row warp.
+bool pw_fast_ok(const PwMesh &mesh, int max_obj_w);
+void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream);
+void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
 // the pixel loop :1042-1056 reading the map.

@@ -3,6 +3,7 @@
 // with contraction off so that nearest-neighbour source selection is bit-identical to the reference's JS doubles.
 // Citations are file:line into the reference's Homography.js (v1.8.0).  Design notes: DESIGN.md §4.
 #include "hg_kernels.h"
+#include <cstdlib>
 
 namespace hg {
 
@@ -230,6 +231,243 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fast path: k_tri_spans + k_pw_rows
+// Two kernels per batch of frames replace _calculatePiecewiseAffineTransformMatrices (:785-804),
+// _buildInverseTrianglesCorrespondencesMatrix (:845-861), the inverseAffineMatrix loop (:1036-1038) and the pixel loop
+// (:1042-1056) without ever materialising the Int16 map:
+//
+//   k_tri_spans  triangle-major, like the reference's fill loop: one workgroup per (frame, triangle) solves the
+//                triangle's forward/inverse matrices, then one thread per source row y of fillTriangle (:1120) evaluates
+//                predictXLimits + the two flat fill() indices exactly (TypedArray.fill semantics incl. negative-index
+//                wrap) and appends the covered cells, cut at output-row boundaries, to that OUTPUT row's span list
+//                {lo, hi, triangle id, inverse matrix as 6 f32} (32 bytes, global memory, atomic slot counter per row).
+//                Exact for any input; the only limit is the per-row list capacity (overflow -> frame redone via the map).
+//   k_pw_rows    one workgroup per output row: loads the row's list into LDS (matrix widened to f64 and specialised to
+//                this row: {m0, m2*y, m4, m1, m3*y, m5}; m2*y and m3*y are the separately rounded products of :1383-1384),
+//                then each wave walks 256-pixel windows: spans overlapping the window are found with one ballot per 64
+//                spans and every lane keeps the LARGEST covering id per pixel (== the sequential overwrite order of
+//                :852-858), then the pixel body: 1 mul + 2 add per coordinate in fp64, Math.round and the bounds test
+//                :1047 through two round-toward-minus-infinity adds per coordinate (see round_x8), one buffer load whose
+//                hardware range check returns 0 outside the RGBA array (the JS `undefined` -> 0 case), coalesced stores.
+// Requirements checked by pw_fast_ok(): n_tris <= 32767 (ids == their Int16 value), obj_w <= 65535, source < 2^31 bytes,
+// min_src_x/y >= 0 (bounds test done on bit patterns of non-negative doubles).
+
+__device__ __forceinline__ uint32_t dlo(double v) { return (uint32_t)__double2loint(v); }
+
+__global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, RowLists rl)
+{
+    const int t = blockIdx.x, f = blockIdx.y;
+    const FrameDesc fd = fr.frames[f];
+    const float *dp = fr.dst_pts + (size_t)f * mesh.n_pts * 2;
+    float s[6], d[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t v = mesh.tris[3 * (size_t)t + k];
+        if (v < (uint32_t)mesh.n_pts) {
+            s[2 * k] = mesh.src_pts[2 * (size_t)v]; s[2 * k + 1] = mesh.src_pts[2 * (size_t)v + 1];
+            d[2 * k] = dp[2 * (size_t)v];           d[2 * k + 1] = dp[2 * (size_t)v + 1];
+        } else {
+            s[2 * k] = s[2 * k + 1] = d[2 * k] = d[2 * k + 1] = NAN;
+        }
+    }
+    float fwd[6], inv[6];
+    solve_affine(s, d, fwd);                       // every thread redundantly: cheaper than a broadcast through LDS
+    invert_affine(fwd, inv);
+    Seg seg[3];
+    define_seg(d[0], d[1], d[2], d[3], seg[0]);     // p0->p1
+    define_seg(d[0], d[1], d[4], d[5], seg[1]);     // p0->p2
+    define_seg(d[2], d[3], d[4], d[5], seg[2]);     // p1->p2
+    int32_t y_min, y_end;
+    tri_rows(d[1], d[3], d[5], y_min, y_end);
+    const size_t ft = (size_t)f * mesh.n_tris + t;
+    if (threadIdx.x == 0) {                        // taps + inputs of the map path
+#pragma unroll
+        for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
+        fr.segs[ft * 3] = seg[0]; fr.segs[ft * 3 + 1] = seg[1]; fr.segs[ft * 3 + 2] = seg[2];
+        TriRange tr; tr.y_min = y_min; tr.y_end = y_end; tr.a = 0; tr.b = 0;
+        fr.trir[ft] = tr;
+    }
+    const int W = fd.obj_w;
+    if (W <= 0 || fd.obj_h <= 0) return;
+    const int64_t len = (int64_t)W * fd.obj_h;
+    int32_t *__restrict__ rowcnt = rl.cnt + (size_t)f * rl.row_stride;
+    RowEnt *__restrict__ rowent = rl.ent + (size_t)f * rl.row_stride * rl.cap;
+    for (int64_t y = (int64_t)y_min + threadIdx.x; y < y_end; y += 128) {
+        int64_t k, fin;
+        span_cells(seg, (double)y, (double)fd.y_off, (double)W, len, k, fin);
+        if (k >= fin) continue;
+        // usual case: the span sits in output row (y - yOff) (+objH when it wrapped); otherwise divide
+        int64_t r = y - fd.y_off;
+        if (r < 0) r += fd.obj_h;
+        if (r < 0 || r >= fd.obj_h || k < r * W || k >= (r + 1) * W) r = k / W;
+        for (; r * W < fin; r++) {
+            const int64_t lo = (k > r * W ? k : r * W) - r * W, hi = (fin < (r + 1) * W ? fin : (r + 1) * W) - r * W;
+            const int slot = atomicAdd(&rowcnt[r], 1);
+            if (slot < rl.cap) {
+                RowEnt e;
+                e.lo_hi = (uint32_t)lo | ((uint32_t)hi << 16);
+                e.id = t;
+#pragma unroll
+                for (int q = 0; q < 6; q++) e.m[q] = inv[q];
+                uint4 *dst = reinterpret_cast<uint4 *>(rowent + (size_t)r * rl.cap + slot);
+                const uint4 *srcv = reinterpret_cast<const uint4 *>(&e);
+                dst[0] = srcv[0]; dst[1] = srcv[1];
+            }
+        }
+    }
+}
+
+// For 8 doubles: h[i] = RTN(v[i] + 0.5), r[i] = RTN(h[i] + M), M = 1.5 * 2^52, with the fp64 rounding mode switched to
+// round-toward-minus-infinity for exactly these 16 adds.  floor(h) == floor(v + 0.5 exactly) == Math.round(v) for every
+// finite double (RTN never crosses an integer upward; this also gets 0.49999999999999994 right), and it appears as the
+// low dword of r.  h itself serves the bounds test:  a <= v < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).
+__device__ __forceinline__ void round_x8(const double v[8], double h[8], double r[8])
+{
+    const double M = 6755399441055744.0;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %16, 0.5\n\t"  "v_add_f64 %1, %17, 0.5\n\t"  "v_add_f64 %2, %18, 0.5\n\t"  "v_add_f64 %3, %19, 0.5\n\t"
+        "v_add_f64 %4, %20, 0.5\n\t"  "v_add_f64 %5, %21, 0.5\n\t"  "v_add_f64 %6, %22, 0.5\n\t"  "v_add_f64 %7, %23, 0.5\n\t"
+        "v_add_f64 %8, %0, %24\n\t"   "v_add_f64 %9, %1, %24\n\t"   "v_add_f64 %10, %2, %24\n\t"  "v_add_f64 %11, %3, %24\n\t"
+        "v_add_f64 %12, %4, %24\n\t"  "v_add_f64 %13, %5, %24\n\t"  "v_add_f64 %14, %6, %24\n\t"  "v_add_f64 %15, %7, %24\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7]),
+          "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "s"(M));
+}
+
+// lo <= h < hi for doubles with 0 < lo < hi, on the bit patterns (monotonic for non-negative doubles; a negative h has
+// the sign bit set and a NaN an all-ones exponent: both fall outside).
+__device__ __forceinline__ bool in_range_bits(double h, int64_t lo_bits, uint64_t extent_bits)
+{
+    return (uint64_t)(__double_as_longlong(h) - lo_bits) < extent_bits;
+}
+
+template <int CAP, int NB>
+__global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
+                                                 int16_t *__restrict__ map_out, int rows_per_xcd)
+{
+    // 1-D grid decoded so that XCD x (= block id % 8, the observed dispatch order; speed only, never correctness) walks a
+    // contiguous band of rows of one frame: vertically adjacent output rows share source cache lines, which then stay in
+    // that XCD's L2 instead of being fetched by up to 8 of them.
+    const int bid = blockIdx.x, xcd = bid & 7, bi = bid >> 3;
+    const int f = bi / rows_per_xcd;
+    const int r = xcd * rows_per_xcd + (bi - f * rows_per_xcd);
+    const FrameDesc fd = fr.frames[f];
+    if (r >= fd.obj_h || fd.obj_w <= 0) return;
+
+    __shared__ __align__(16) double s_m[CAP * 6];
+    __shared__ int s_lo[CAP], s_hi[CAP], s_id[CAP];
+
+    const int W = fd.obj_w;
+    const int64_t row0 = (int64_t)r * W;
+    const double y = (double)(r + fd.y_off);
+
+    // ---- this row's spans -> LDS (slot CAP-1 is a NaN record that pixels without a triangle point at)
+    const int cnt = rl.cnt[(size_t)f * rl.row_stride + r];
+    if (cnt > rl.cap || cnt > CAP - 1) {
+        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+        return;
+    }
+    const RowEnt *__restrict__ ent = rl.ent + ((size_t)f * rl.row_stride + r) * rl.cap;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const uint4 a = reinterpret_cast<const uint4 *>(ent + i)[0];
+        const uint4 b = reinterpret_cast<const uint4 *>(ent + i)[1];
+        s_lo[i] = (int)(a.x & 0xffffu); s_hi[i] = (int)(a.x >> 16); s_id[i] = (int)a.y;
+        const double m0 = (double)__uint_as_float(a.z), m1 = (double)__uint_as_float(a.w), m2 = (double)__uint_as_float(b.x),
+                     m3 = (double)__uint_as_float(b.y), m4 = (double)__uint_as_float(b.z), m5 = (double)__uint_as_float(b.w);
+        double2 *mrec = reinterpret_cast<double2 *>(s_m + i * 6);
+        mrec[0] = make_double2(m0, m2 * y);
+        mrec[1] = make_double2(m4, m1);
+        mrec[2] = make_double2(m3 * y, m5);
+    }
+    if (threadIdx.x < 3) reinterpret_cast<double2 *>(s_m + (CAP - 1) * 6)[threadIdx.x] = make_double2(NAN, NAN);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwin = (W + 255) >> 8;
+    uint32_t *__restrict__ orow = reinterpret_cast<uint32_t *>(out + fd.out_off) + row0;
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mesh.img), 0,
+                                                                          (int)((int64_t)mesh.W * mesh.H * 4), 0x00020000);
+    // :1047  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= RTN(sx + 0.5) < W + minSrcX + 0.5   (same for y)
+    const int64_t bx = __double_as_longlong((double)mesh.min_src_x + 0.5), by = __double_as_longlong((double)mesh.min_src_y + 0.5);
+    const uint64_t ex = (uint64_t)(__double_as_longlong((double)mesh.W + (double)mesh.min_src_x + 0.5) - bx);
+    const uint64_t ey = (uint64_t)(__double_as_longlong((double)mesh.H + (double)mesh.min_src_y + 0.5) - by);
+    const int pitch4 = mesh.W * 4;
+
+    for (int w0 = wave; w0 < nwin; w0 += 4 * NB) {
+        int best[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) best[b][k] = -1;
+            const int w = w0 + 4 * b;
+            if (w < nwin) {
+                const int c0 = w << 8, cq = c0 + lane;          // lane l owns pixels c0 + l + 64k: every gather instruction
+                for (int j = 0; j < cnt; j += 64) {             // covers 64 consecutive pixels, stores are 256-B coalesced
+                    const int idx = j + lane;
+                    int lo = 0x7fffffff, hi = 0;
+                    if (idx < cnt) { lo = s_lo[idx]; hi = s_hi[idx]; }
+                    unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
+                    while (mask) {
+                        const int bit = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int slot = j + bit;
+                        const int sl = s_lo[slot];
+                        const unsigned span = (unsigned)(s_hi[slot] - sl);
+                        const int key = (s_id[slot] << 8) | slot;       // larger id wins; its slot rides along
+                        const int d = cq - sl;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if ((unsigned)(d + k * 64) < span) best[b][k] = max(best[b][k], key);
+                    }
+                }
+            }
+        }
+        uint32_t px[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int w = w0 + 4 * b;
+            if (w < nwin) {
+                const int cq = (w << 8) + lane;
+                double v[8], h[8], rd[8];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int slot = best[b][k] & (CAP - 1);              // -1 -> CAP-1: the NaN record
+                    const double2 *mrec = reinterpret_cast<const double2 *>(s_m + slot * 6);
+                    const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+                    const double xd = (double)(cq + k * 64 + fd.x_off);
+                    v[2 * k]     = ((m0.x * xd) + m0.y) + m1.x;           // :1383  (m0*x) + (m2*y) + m4
+                    v[2 * k + 1] = ((m1.y * xd) + m2.x) + m2.y;           // :1384  (m1*x) + (m3*y) + m5
+                }
+                round_x8(v, h, rd);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool inb = (int)in_range_bits(h[2 * k], bx, ex) & (int)in_range_bits(h[2 * k + 1], by, ey);   // :1047 (NaN fails)
+                    const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));   // :1048-1049
+                    px[b][k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);       // outside -> 0
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int w = w0 + 4 * b;
+            if (w < nwin) {
+                const int cq = (w << 8) + lane;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (cq + k * 64 < W) orow[cq + k * 64] = px[b][k];
+                if (map_out) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (cq + k * 64 < W) map_out[fd.map_off + row0 + cq + k * 64] = best[b][k] < 0 ? (int16_t)-1 : (int16_t)(best[b][k] >> 8);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ materialised-map path
 // Rasteriser: one workgroup per triangle, one wave per source row y, lanes stride the span's cells.
 // atomicMax over raw ids on a map initialised to -1 == sequential "last writer wins" (Appendix A-Q3).
@@ -335,6 +573,27 @@ void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
     dim3 grid(fr.max_obj_h, fr.n_frames);
     hipLaunchKernelGGL(k_pw_fused, grid, dim3(256), 0, stream, mesh, fr, out, map_out);
+}
+
+bool pw_fast_ok(const PwMesh &mesh, int max_obj_w)
+{
+    return mesh.n_tris > 0 && mesh.n_tris <= 32767 && max_obj_w <= 65535 && (int64_t)mesh.W * mesh.H * 4 < ((int64_t)1 << 31) &&
+           mesh.W < (1 << 21) && mesh.H < (1 << 22) && mesh.min_src_x >= 0 && mesh.min_src_y >= 0 &&
+           mesh.min_src_x < (1 << 22) && mesh.min_src_y < (1 << 22);
+}
+
+void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream)
+{
+    if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
+    hipLaunchKernelGGL(k_tri_spans, dim3(mesh.n_tris, fr.n_frames), dim3(128), 0, stream, mesh, fr, rl);
+}
+
+void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, hipStream_t stream)
+{
+    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
+    const int rpx = (fr.max_obj_h + 7) / 8;
+    dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
+    hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx);
 }
 
 void launch_map_build(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, int32_t *map32, hipStream_t stream)

@@ -166,8 +166,8 @@ def test_batch_frames_equal_single_frames(ctx):
 
 
 def test_irregular_and_overflow_frames_fall_back_to_map_path(ctx):
-    """Frames the fused kernel refuses (a triangle wider than the whole map; > kRowSpanCap spans in a row) are redone
-    by the library through the materialised map and still match the oracle bit for bit."""
+    """Spans wider than the whole map, and rows crossed by more spans than the row lists hold (the frame is then redone
+    by the library through the materialised map): both still match the oracle bit for bit."""
     W, H = 64, 48
     img = G.lcg_image(W, H, 9)
     # (a) output map of 3 rows, triangles wider than len/…: tiny obj_h with x-extent >= len is impossible to reach
@@ -175,15 +175,15 @@ def test_irregular_and_overflow_frames_fall_back_to_map_path(ctx):
     sp = np.array([0, 0, 63, 0, 0, 47, 63, 47], np.float32)
     dp = np.array([0, 0, 300, 0, 0, 2, 300, 2], np.float32)
     tris = np.array([0, 1, 2, 1, 3, 2], np.uint32)
-    geom = (0, 0, 20, 3)          # len = 60 < triangle width 300  -> FRAME_IRREGULAR
+    geom = (0, 0, 20, 3)          # len = 60 < triangle width 300: spans run over several output rows and past the map end
     ctx.set_image(img)
     ctx.piecewise_set_mesh(sp, tris, 0, 0)
     ctx.piecewise_prepare(dp, geom)
-    want = O.warp_inverse_piecewise(sp, dp, tris, img, 0, 0, *geom)
+    want, wmap, _, _ = O.warp_inverse_piecewise(sp, dp, tris, img, 0, 0, *geom, taps=True)
     assert np.array_equal(ctx.warp_inverse_piecewise(), want)
-    with pytest.raises(HG.HgError):
-        ctx.get_tri_map(fused=True)
-    # (b) 1100 thin triangles crossing every row -> more than 1024 spans per row -> FRAME_LDS_OVERFLOW
+    assert np.array_equal(ctx.get_tri_map(fused=True), wmap)
+    assert np.array_equal(ctx.get_tri_map(), wmap)
+    # (b) 1100 thin triangles crossing every row -> more spans per row than the lists hold -> FRAME_LDS_OVERFLOW -> map path
     n = 1100
     W2, H2 = 2400, 8
     img2 = G.lcg_image(W2, H2, 10)
