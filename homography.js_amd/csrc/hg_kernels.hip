@@ -345,7 +345,7 @@ __device__ __forceinline__ bool in_range_bits(double h, int64_t lo_bits, uint64_
     return (uint64_t)(__double_as_longlong(h) - lo_bits) < extent_bits;
 }
 
-template <int CAP, int NB>
+template <int CAP, int ABL>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int rows_per_xcd)
 {
@@ -386,84 +386,70 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     if (threadIdx.x < 3) reinterpret_cast<double2 *>(s_m + (CAP - 1) * 6)[threadIdx.x] = make_double2(NAN, NAN);
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: the window loop runs on the scalar unit
     const int nwin = (W + 255) >> 8;
-    uint32_t *__restrict__ orow = reinterpret_cast<uint32_t *>(out + fd.out_off) + row0;
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mesh.img), 0,
-                                                                          (int)((int64_t)mesh.W * mesh.H * 4), 0x00020000);
-    // :1047  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= RTN(sx + 0.5) < W + minSrcX + 0.5   (same for y)
-    const int64_t bx = __double_as_longlong((double)mesh.min_src_x + 0.5), by = __double_as_longlong((double)mesh.min_src_y + 0.5);
-    const uint64_t ex = (uint64_t)(__double_as_longlong((double)mesh.W + (double)mesh.min_src_x + 0.5) - bx);
-    const uint64_t ey = (uint64_t)(__double_as_longlong((double)mesh.H + (double)mesh.min_src_y + 0.5) - by);
+    // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
+    // from the hardware range check == the JS `undefined` -> 0 of :1051.  Output row: raw buffer of 4*W bytes, so the
+    // ragged last window needs no per-pixel guard (stores past the row end are dropped by the same check).
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mesh.img), 0, mesh.W * mesh.H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + row0 * 4, 0, W * 4, 0x00020000);
+    // :1047 on h = RTN(s + 0.5):  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= hx < W + minSrcX + 0.5, and
+    // minSrcY <= sy <=> minSrcY + 0.5 <= hy.  The upper y bound needs no test: round(sy) >= H puts the byte offset at or
+    // beyond 4*W*H, which reads 0 exactly like the reference (it either fails :1047 or reads past the array).
+    const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
+    const double by_lo = (double)mesh.min_src_y + 0.5;
     const int pitch4 = mesh.W * 4;
 
-    for (int w0 = wave; w0 < nwin; w0 += 4 * NB) {
-        int best[NB][4];
+    for (int w = wave; w < nwin; w += 4) {
+        const int c0 = w << 8, cq = c0 + lane;              // lane l owns pixels c0 + l + 64k: every gather instruction covers
+        int best[4] = { -1, -1, -1, -1 };                   // 64 consecutive pixels and every store instruction 256 contiguous bytes
+        for (int j = 0; j < cnt; j += 64) {
+            const int idx = j + lane;
+            int lo = 0x7fffffff, hi = 0;
+            if (idx < cnt) { lo = s_lo[idx]; hi = s_hi[idx]; }
+            unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
+            while (mask) {
+                const int bit = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int slot = j + bit;
+                const int sl = s_lo[slot];
+                const unsigned span = (unsigned)(s_hi[slot] - sl);
+                const int key = (s_id[slot] << 8) | slot;   // larger id wins (== last writer of :852-858); its slot rides along
+                const int d = cq - sl;
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) best[b][k] = -1;
-            const int w = w0 + 4 * b;
-            if (w < nwin) {
-                const int c0 = w << 8, cq = c0 + lane;          // lane l owns pixels c0 + l + 64k: every gather instruction
-                for (int j = 0; j < cnt; j += 64) {             // covers 64 consecutive pixels, stores are 256-B coalesced
-                    const int idx = j + lane;
-                    int lo = 0x7fffffff, hi = 0;
-                    if (idx < cnt) { lo = s_lo[idx]; hi = s_hi[idx]; }
-                    unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
-                    while (mask) {
-                        const int bit = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        const int slot = j + bit;
-                        const int sl = s_lo[slot];
-                        const unsigned span = (unsigned)(s_hi[slot] - sl);
-                        const int key = (s_id[slot] << 8) | slot;       // larger id wins; its slot rides along
-                        const int d = cq - sl;
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if ((unsigned)(d + k * 64) < span) best[b][k] = max(best[b][k], key);
-                    }
-                }
+                for (int k = 0; k < 4; k++)
+                    if ((unsigned)(d + k * 64) < span) best[k] = max(best[k], key);
             }
         }
-        uint32_t px[NB][4];
+        double v[8], h[8], rd[8];
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const int w = w0 + 4 * b;
-            if (w < nwin) {
-                const int cq = (w << 8) + lane;
-                double v[8], h[8], rd[8];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int slot = best[b][k] & (CAP - 1);              // -1 -> CAP-1: the NaN record
-                    const double2 *mrec = reinterpret_cast<const double2 *>(s_m + slot * 6);
-                    const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                    const double xd = (double)(cq + k * 64 + fd.x_off);
-                    v[2 * k]     = ((m0.x * xd) + m0.y) + m1.x;           // :1383  (m0*x) + (m2*y) + m4
-                    v[2 * k + 1] = ((m1.y * xd) + m2.x) + m2.y;           // :1384  (m1*x) + (m3*y) + m5
-                }
-                round_x8(v, h, rd);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const bool inb = (int)in_range_bits(h[2 * k], bx, ex) & (int)in_range_bits(h[2 * k + 1], by, ey);   // :1047 (NaN fails)
-                    const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));   // :1048-1049
-                    px[b][k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);       // outside -> 0
-                }
-            }
+        for (int k = 0; k < 4; k++) {
+            const int slot = best[k] & (CAP - 1);           // -1 -> CAP-1: the NaN record
+            const double2 *mrec = reinterpret_cast<const double2 *>(s_m + slot * 6);
+            const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+            const double xd = (double)(cq + k * 64 + fd.x_off);
+            // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
+            // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
+            v[2 * k]     = fma(m0.x, xd, m0.y) + m1.x;
+            v[2 * k + 1] = fma(m1.y, xd, m2.x) + m2.y;
         }
+        round_x8(v, h, rd);
+        uint32_t px[4];
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const int w = w0 + 4 * b;
-            if (w < nwin) {
-                const int cq = (w << 8) + lane;
+        for (int k = 0; k < 4; k++) {
+            const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo);   // NaN fails
+            const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));   // :1048-1049
+            px[k] = (ABL & 2) ? (inb ? off : 0u) : __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
+        }
+        if (!(ABL & 4) || (px[0] ^ px[1] ^ px[2] ^ px[3]) == 0x9e3779b9u) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (cq + k * 64 < W) orow[cq + k * 64] = px[b][k];
-                if (map_out) {
+            for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[k], dst, (cq + k * 64) * 4, 0, 0);
+        }
+        if (map_out) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (cq + k * 64 < W) map_out[fd.map_off + row0 + cq + k * 64] = best[b][k] < 0 ? (int16_t)-1 : (int16_t)(best[b][k] >> 8);
-                }
-            }
+            for (int k = 0; k < 4; k++)
+                if (cq + k * 64 < W) map_out[fd.map_off + row0 + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> 8);
         }
     }
 }
@@ -579,7 +565,8 @@ bool pw_fast_ok(const PwMesh &mesh, int max_obj_w)
 {
     return mesh.n_tris > 0 && mesh.n_tris <= 32767 && max_obj_w <= 65535 && (int64_t)mesh.W * mesh.H * 4 < ((int64_t)1 << 31) &&
            mesh.W < (1 << 21) && mesh.H < (1 << 22) && mesh.min_src_x >= 0 && mesh.min_src_y >= 0 &&
-           mesh.min_src_x < (1 << 22) && mesh.min_src_y < (1 << 22);
+           mesh.min_src_x < (1 << 22) && mesh.min_src_y < (1 << 22) &&
+           ((int64_t)mesh.H + mesh.min_src_y + 2) * mesh.W + mesh.min_src_x < ((int64_t)1 << 31);   // record index stays in 32 bits
 }
 
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream)
@@ -593,7 +580,13 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
     const int rpx = (fr.max_obj_h + 7) / 8;
     dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
-    hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx);
+    static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;      // experiments only
+    switch (abl) {
+    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    }
 }
 
 void launch_map_build(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, int32_t *map32, hipStream_t stream)
