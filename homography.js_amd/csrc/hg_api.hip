@@ -58,6 +58,7 @@ struct hg_ctx {
 
     // scratch
     int32_t *d_map32 = nullptr; size_t map32_cap = 0;
+    int32_t *d_win32 = nullptr; size_t win32_cap = 0;
     int16_t *d_map16 = nullptr; size_t map16_cap = 0;
     uint8_t *d_out_tmp = nullptr; size_t out_tmp_cap = 0;
 
@@ -157,7 +158,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
     void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent,
-                     c->d_geo_frames, c->d_mats, c->d_map32, c->d_map16, c->d_out_tmp };
+                     c->d_geo_frames, c->d_mats, c->d_map32, c->d_win32, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -727,5 +728,68 @@ extern "C" int hg_get_matrices(hg_ctx *c, float *fwd, float *inv)
     if (inv) { tmp.resize(T * kInvStride); HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_inv, sizeof(float) * kInvStride * T, hipMemcpyDeviceToHost, c->stream)); }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (inv) for (size_t t = 0; t < T; t++) std::memcpy(inv + 6 * t, tmp.data() + kInvStride * t, sizeof(float) * 6);
+    return HG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward (scatter) paths
+extern "C" int hg_warp_forward_geometric(hg_ctx *c, int kind, const double *m, hg_geom geom, uint8_t *out_host)
+{
+    HG_TRY(bind(c));
+    if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m || !out_host) return fail(c, HG_ERR_INVALID, "hg_warp_forward_geometric: bad arguments");
+    if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    if (geom.obj_w <= 0 || geom.obj_h <= 0) return HG_OK;
+    HG_TRY(hg_sync(c));
+    const size_t n = (size_t)geom.obj_w * geom.obj_h;
+    double m8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    std::memcpy(m8, m, sizeof(double) * (kind == HG_AFFINE ? 6 : 8));
+    HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)8));
+    HG_TRY(ensure(c, c->d_win32, c->win32_cap, n));
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, n * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mats, m8, sizeof(m8), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->geo_frames.clear();                               // the uploaded geometric frame set was overwritten
+    FrameDesc fd; fd.x_off = geom.x_off; fd.y_off = geom.y_off; fd.obj_w = geom.obj_w; fd.obj_h = geom.obj_h; fd.out_off = 0; fd.map_off = 0;
+    launch_fwd_geo(kind, c->d_mats, c->d_img, c->W, c->H, fd, c->d_win32, c->d_out_tmp, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HG_OK;
+}
+
+extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host)
+{
+    HG_TRY(bind(c));
+    if (!dst_points || !out_host) return fail(c, HG_ERR_INVALID, "hg_warp_forward_piecewise: bad arguments");
+    if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
+    if (geom.obj_w <= 0 || geom.obj_h <= 0) return HG_OK;
+    const int map_w = max_src_x - c->min_src_x, map_h = max_src_y - c->min_src_y;
+    const size_t n = (size_t)geom.obj_w * geom.obj_h;
+    const size_t n_map = (map_w > 0 && map_h > 0) ? (size_t)map_w * map_h : 0;
+    // (A) forward triangle map over the source bbox: _buildTrianglesCorrespondencesMatrix :817-832 == the same
+    //     rasteriser on the SOURCE triangles with width maxSrcX-minSrcX and y offset minSrcY
+    std::vector<float> src_host((size_t)c->n_pts * 2);
+    HIP_TRY(c, hipMemcpy(src_host.data(), c->d_src, sizeof(float) * src_host.size(), hipMemcpyDeviceToHost));
+    hg_geom gmap = { 0, c->min_src_y, map_w, map_h };
+    const size_t zero = 0;
+    if (n_map) {
+        HG_TRY(hg_piecewise_set_frames(c, src_host.data(), &gmap, &zero, 1));
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t), c->stream));
+        launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
+        HG_TRY(ensure(c, c->d_map32, c->map32_cap, n_map));
+        launch_map_build(mesh_of(c), frames_of(c), 0, c->pw_frames[0], c->d_map32, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    }
+    // (B) forward matrices of the real frame (:785-804), then scatter + gather
+    HG_TRY(hg_piecewise_set_frames(c, dst_points, &geom, &zero, 1));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t), c->stream));
+    launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
+    c->pw_setup_done = false;
+    HG_TRY(ensure(c, c->d_win32, c->win32_cap, n));
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, n * 4));
+    launch_fwd_pw(c->d_map32, c->d_fwd, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, map_w, map_h, c->pw_frames[0], c->d_win32, c->d_out_tmp, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HG_OK;
 }

@@ -86,4 +86,9 @@ void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream
 void launch_geo(int kind, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
                 const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
 
+// Forward (scatter) paths, SURVEY.md §8f-1: winner buffer `win` = obj_w*obj_h int32 scratch.
+void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, int H, const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);
+void launch_fwd_pw(const int32_t *fmap, const float *fwd, const uint8_t *img, int W, int H, int min_src_x, int min_src_y, int map_w, int map_h,
+                   const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);
+
 } // namespace hg

@@ -545,6 +545,77 @@ __global__ __launch_bounds__(256) void k_geo(const FrameDesc *__restrict__ frame
     store_quad(orow, cq, OW, vec_ok, px);
 }
 
+// ------------------------------------------------------------------------------------------------ forward (scatter) paths
+// _geometricWarp :911-932 and _piecewiseAffineWarp :948-972 write each SOURCE pixel to its transformed position; where
+// several land on one output pixel the sequential loops keep the last writer in raster order.  On the GPU:
+//   pass 1  every source pixel computes its flat destination index exactly as the JS does (Math.round, `<< 2` on
+//           ToInt32, typed-array stores outside the array are dropped) and atomicMax-es its raster rank into a
+//           per-output-pixel winner word (-1 = never written);
+//   pass 2  every output pixel copies its winner's source pixel (0 when that read is outside the source array: the
+//           reference then stores `undefined` -> 0, which still overwrites earlier writers).
+// Deterministic and bit-identical to the sequential result.
+
+__device__ __forceinline__ int64_t fwd_dst_pixel(double nx, double ny, int x_off, int y_off, int obj_w, int64_t n_dst_px)
+{
+    nx = js_round(nx - (double)x_off);                                  // :924 / :962
+    ny = js_round(ny - (double)y_off);
+    const double dst_row = (double)((int64_t)obj_w << 2);
+    const int32_t sh = (int32_t)((uint32_t)js_to_int32(nx) << 2);      // `newX << 2`
+    const double idx = (ny * dst_row) + (double)sh;                    // :926 / :964
+    if (!(idx >= 0.0) || !(idx + 3.0 < (double)(n_dst_px * 4))) return -1;
+    return (int64_t)idx >> 2;                                           // idx is a multiple of 4 whenever it is finite
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_fwd_scatter_geo(const double *__restrict__ mat, int W, int H, FrameDesc fd, int32_t *__restrict__ win)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    double m[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) m[k] = mat[k];
+    double nx, ny;
+    if (KIND == 0) apply_affine(m, (double)x, (double)y, nx, ny); else apply_projective(m, (double)x, (double)y, nx, ny);   // :923
+    const int64_t n_dst = (int64_t)fd.obj_w * fd.obj_h;
+    const int64_t p = fwd_dst_pixel(nx, ny, fd.x_off, fd.y_off, fd.obj_w, n_dst);
+    if (p >= 0) atomicMax(&win[p], y * W + x);
+}
+
+__global__ __launch_bounds__(256) void k_fwd_scatter_pw(const int32_t *__restrict__ fmap, const float *__restrict__ fwd, int min_src_x, int min_src_y,
+                                                        int map_w, int map_h, FrameDesc fd, int32_t *__restrict__ win)
+{
+    const int mx = blockIdx.x * 256 + threadIdx.x, my = blockIdx.y;
+    if (mx >= map_w) return;
+    const int cell = my * map_w + mx;
+    const int t16 = (int)(int16_t)fmap[cell];                           // :957 (Int16Array value)
+    if (t16 <= -1) return;
+    const float *mf = fwd + (size_t)t16 * 6;
+    const double m[6] = { mf[0], mf[1], mf[2], mf[3], mf[4], mf[5] };
+    double nx, ny;
+    apply_affine(m, (double)(mx + min_src_x), (double)(my + min_src_y), nx, ny);                                            // :961
+    const int64_t n_dst = (int64_t)fd.obj_w * fd.obj_h;
+    const int64_t p = fwd_dst_pixel(nx, ny, fd.x_off, fd.y_off, fd.obj_w, n_dst);
+    if (p >= 0) atomicMax(&win[p], cell);                               // raster rank of (x, y) in the loops :955-956
+}
+
+// win holds source linear indices (geometric: y*W + x; piecewise: cell of the source-bbox map)
+__global__ __launch_bounds__(256) void k_fwd_gather(const int32_t *__restrict__ win, const uint8_t *__restrict__ img, int W, int H, int piecewise,
+                                                    int min_src_x, int min_src_y, int map_w, FrameDesc fd, uint8_t *__restrict__ out)
+{
+    const int64_t n = (int64_t)fd.obj_w * fd.obj_h;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int w = win[i];
+    uint32_t px = 0u;
+    if (w >= 0) {
+        int64_t sidx;
+        if (piecewise) { const int my = w / map_w, mx = w - my * map_w; sidx = (int64_t)(my + min_src_y) * W + (mx + min_src_x); }   // :960
+        else sidx = w;
+        if (sidx >= 0 && sidx < (int64_t)W * H) px = reinterpret_cast<const uint32_t *>(img)[sidx];
+    }
+    reinterpret_cast<uint32_t *>(out + fd.out_off)[i] = px;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 
 void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream)
@@ -622,6 +693,30 @@ void launch_geo(int kind, const FrameDesc *frames, const double *mats, int n_fra
     dim3 grid((max_w + 255) / 256, (max_h + 3) / 4, n_frames);
     if (kind == 0) hipLaunchKernelGGL(k_geo<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
     else           hipLaunchKernelGGL(k_geo<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+}
+
+void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, int H, const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream)
+{
+    const int64_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (int64_t)fd.obj_w * fd.obj_h : 0;
+    if (n == 0) return;
+    const int fb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_fill_i32, dim3(fb), dim3(256), 0, stream, win, (size_t)n, (int32_t)-1);
+    dim3 grid((W + 255) / 256, H);
+    if (kind == 0) hipLaunchKernelGGL(k_fwd_scatter_geo<0>, grid, dim3(256), 0, stream, d_mat, W, H, fd, win);
+    else           hipLaunchKernelGGL(k_fwd_scatter_geo<1>, grid, dim3(256), 0, stream, d_mat, W, H, fd, win);
+    hipLaunchKernelGGL(k_fwd_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, win, img, W, H, 0, 0, 0, 1, fd, out);
+}
+
+void launch_fwd_pw(const int32_t *fmap, const float *fwd, const uint8_t *img, int W, int H, int min_src_x, int min_src_y, int map_w, int map_h,
+                   const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream)
+{
+    const int64_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (int64_t)fd.obj_w * fd.obj_h : 0;
+    if (n == 0) return;
+    const int fb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_fill_i32, dim3(fb), dim3(256), 0, stream, win, (size_t)n, (int32_t)-1);
+    if (map_w > 0 && map_h > 0)
+        hipLaunchKernelGGL(k_fwd_scatter_pw, dim3((map_w + 255) / 256, map_h), dim3(256), 0, stream, fmap, fwd, min_src_x, min_src_y, map_w, map_h, fd, win);
+    hipLaunchKernelGGL(k_fwd_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, win, img, W, H, 1, min_src_x, min_src_y, map_w > 0 ? map_w : 1, fd, out);
 }
 
 } // namespace hg

@@ -256,6 +256,37 @@ static napi_value fn_warp_inverse_piecewise(napi_env env, napi_callback_info inf
     return r;
 }
 
+static napi_value fn_warp_forward_geometric(napi_env env, napi_callback_info info)
+{
+    napi_value a[7];
+    if (!get_args(env, info, 7, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    int kind; size_t n; hg_geom g;
+    if (!get_i32(env, a[1], &kind)) return NULL;
+    double *m = (double *)get_typed(env, a[2], napi_float64_array, &n, "matrix"); if (!m) return NULL;
+    if (n < (size_t)(kind == HG_AFFINE ? 6 : 8)) return throw_str(env, "hgwarp: matrix too short");
+    if (!get_geom(env, a + 3, &g)) return NULL;
+    const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
+    void *out; napi_value r = make_typed(env, napi_uint8_clamped_array, px * 4, 1, &out); if (!r) return NULL;
+    if (px) HG_CALL(h->ctx, "hg_warp_forward_geometric", hg_warp_forward_geometric(h->ctx, kind, m, g, (uint8_t *)out));
+    return r;
+}
+
+static napi_value fn_warp_forward_piecewise(napi_env env, napi_callback_info info)
+{
+    napi_value a[8];
+    if (!get_args(env, info, 8, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    size_t n; int mx, my; hg_geom g;
+    float *dst = (float *)get_typed(env, a[1], napi_float32_array, &n, "dstPoints"); if (!dst) return NULL;
+    if (!get_i32(env, a[2], &mx) || !get_i32(env, a[3], &my)) return NULL;
+    if (!get_geom(env, a + 4, &g)) return NULL;
+    const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
+    void *out; napi_value r = make_typed(env, napi_uint8_clamped_array, px * 4, 1, &out); if (!r) return NULL;
+    if (px) HG_CALL(h->ctx, "hg_warp_forward_piecewise", hg_warp_forward_piecewise(h->ctx, dst, mx, my, g, (uint8_t *)out));
+    return r;
+}
+
 /* parity taps */
 static napi_value fn_get_tri_map(napi_env env, napi_callback_info info)
 {
@@ -335,6 +366,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "piecewiseSetMesh", fn_piecewise_set_mesh }, { "piecewisePrepare", fn_piecewise_prepare },
         { "warpInversePiecewise", fn_warp_inverse_piecewise }, { "getTriMap", fn_get_tri_map }, { "getMatrices", fn_get_matrices },
         { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch },
+        { "warpForwardGeometric", fn_warp_forward_geometric }, { "warpForwardPiecewise", fn_warp_forward_piecewise },
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -29,6 +29,7 @@ EXPORTS = [
     "hg_piecewise_set_mesh", "hg_piecewise_prepare", "hg_warp_inverse_piecewise", "hg_warp_inverse_piecewise_device",
     "hg_piecewise_set_frames", "hg_warp_inverse_piecewise_frames_device", "hg_warp_inverse_piecewise_batch_device",
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
+    "hg_warp_forward_geometric", "hg_warp_forward_piecewise",
     "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats",
 ]
 
@@ -79,6 +80,8 @@ def lib():
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
         "hg_kernel_ms_stats": (i, [vp, f64p, C.POINTER(i)]),
+        "hg_warp_forward_geometric": (i, [vp, i, f64p, Geom, u8p]),
+        "hg_warp_forward_piecewise": (i, [vp, f32p, i, i, Geom, u8p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -245,6 +248,20 @@ class Context:
         g = Geom(*[int(v) for v in geom])
         out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
         self._c(lib().hg_warp_inverse_geometric(self._h, int(kind), p, g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def warp_forward_geometric(self, kind, m, geom):
+        _, p = _f64(m)
+        g = Geom(*[int(v) for v in geom])
+        out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
+        self._c(lib().hg_warp_forward_geometric(self._h, int(kind), p, g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def warp_forward_piecewise(self, dst_pts, max_src_x, max_src_y, geom):
+        _, dp = _f32(dst_pts)
+        g = Geom(*[int(v) for v in geom])
+        out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
+        self._c(lib().hg_warp_forward_piecewise(self._h, dp, int(max_src_x), int(max_src_y), g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
     def geometric_set_frames(self, kind, mats, geoms, offsets=None):

@@ -1,0 +1,410 @@
+// Homography.mjs -- drop-in `Homography` class for Node.js whose per-pixel work runs on an AMD MI355X (gfx950).
+//
+// Same public surface and state machine as Eric-Canas/Homography.js v1.8.0 (`import {Homography} from ...`):
+//     new Homography(transform = 'auto', width = null, height = null)
+//     setReferencePoints / setSourcePoints / setDestinyPoints / setImage / setTriangles / warp
+//     getTransformationMatrixAsCSS
+// Images are ImageData-shaped `{data: Uint8ClampedArray, width, height}` (what the reference accepts in Node, :297-299)
+// and warp() returns the same shape.  The pixel loops, the triangle map and the per-triangle solves are NOT done in
+// JavaScript: they go through the N-API addon lib/hgwarp.node -> C ABI libhgwarp.so -> HIP kernels.  There is no CPU
+// fallback: without the addon or without a gfx950 GPU, construction throws.
+//
+// file:line comments cite the reference's Homography.js for the behaviour each method reproduces.  Reference quirks
+// that are observable through the API are kept (SURVEY.md Appendix A), e.g. normalisation auto-detect (> 8.0), in-place
+// (de)normalisation of caller-owned typed arrays, re-solving the inverse from swapped point sets.
+//
+// Differences, all Node-only consequences of having no DOM:
+//   * HTMLImageElement inputs / asHTMLPromise / transformHTMLElement throw (the reference needs a browser for them too);
+//   * Delaunator is not bundled: `Homography.triangulate` (default: ./delaunay.mjs, own Bowyer-Watson) supplies triangles;
+//     parity of the triangulation with delaunator@5.0.0 is NOT claimed (its source is absent from the reference tree);
+//     pass your own with setTriangles() or by assigning Homography.triangulate.
+import { createRequire } from 'module';
+import { fileURLToPath } from 'url';
+import path from 'path';
+import { triangulate as defaultTriangulate } from './delaunay.mjs';
+
+const require = createRequire(import.meta.url);
+const HERE = path.dirname(fileURLToPath(import.meta.url));
+
+let native = null;
+function addon() {
+    if (native === null) {
+        const p = process.env.HGWARP_ADDON || path.join(HERE, '..', 'lib', 'hgwarp.node');
+        try { native = require(p); } catch (e) {
+            throw (`hgwarp: cannot load the native addon ${p} (${e && e.message ? e.message : e}); build it with \`make -C homography.js_amd\` -- there is no CPU fallback`);
+        }
+    }
+    return native;
+}
+
+const TRANSFORMS = ['auto', 'piecewiseaffine', 'affine', 'projective'];
+const CSS_DECIMALS = 5;                 // :31
+const NORMALIZED_MAX = 8.0;             // :36  anything above is taken as pixel coordinates
+const AFFINE = 0, PROJECTIVE = 1;
+
+class WarpedImage {                     // ImageData-shaped result for runtimes without a global ImageData
+    constructor(data, width, height) { this.data = data; this.width = width; this.height = height; }
+}
+const makeImageData = (data, w, h) => (typeof ImageData !== 'undefined' ? new ImageData(data, w, h) : new WarpedImage(data, w, h));
+
+const anyAbove = (arr, limit) => { for (let i = 0; i < arr.length; i++) if (arr[i] > limit) return true; return false; };   // :1539
+const toF32 = (points) => (ArrayBuffer.isView(points) ? points : new Float32Array(points.flat()));                          // :220 / :339
+function scalePoints(p, sx, sy) { for (let i = 0; i < p.length; i++) p[i] = (i % 2) === 0 ? p[i] * sx : p[i] * sy; }       // :1603
+function unscalePoints(p, sx, sy) { for (let i = 0; i < p.length; i++) p[i] = (i % 2) === 0 ? p[i] / sx : p[i] / sy; }     // :1621
+const asF32 = (p) => (p instanceof Float32Array ? p : Float32Array.from(p));     // what the native side needs (values are already f32 when typed Float32Array)
+
+class Homography {
+    constructor(transform = 'auto', width = null, height = null, options = {}) {
+        if (width !== null) width = Math.round(width);          // :80-81
+        if (height !== null) height = Math.round(height);
+        this._width = width; this._height = height;
+        this._objectiveWidth = null; this._objectiveHeight = null;
+        this._xOutputOffset = undefined; this._yOutputOffset = undefined;
+        this._srcPoints = null; this._dstPoints = null;
+        this.firstTransformSelected = transform.toLowerCase();
+        this.transform = transform.toLowerCase();
+        this._image = null;
+        this._maxSrcX = null; this._maxSrcY = null; this._minSrcX = null; this._minSrcY = null;
+        this._srcPointsAreNormalized = true; this._dstPointsAreNormalized = true;
+        // The reference caches an Int16Array here; its null-ness steers re-triangulation (:252, :756).  We keep only that
+        // fact (and which map it would hold); the map itself lives on the GPU and is rebuilt per warp, as in :1033.
+        this._mapState = null;                                  // null | 'forward' | 'inverse'
+        this._triangles = null;
+        this._transformMatrix = null;
+        this._piecewiseReady = false;                           // reference: _piecewiseMatrices !== null
+        this._lastPath = null;
+        this._native = addon();                                 // throws if the addon is missing: there is no JS fallback
+        this._device = options.device === undefined ? 0 : options.device;
+        this._ctxHandle = null;                                 // GPU context, created at the first warp
+    }
+
+    /** GPU context of this instance (one hg_ctx per Homography).  Throws a string without a usable gfx950 device. */
+    get _ctx() {
+        if (this._ctxHandle === null) this._ctxHandle = this._native.create(this._device);
+        return this._ctxHandle;
+    }
+
+    /** Frees the GPU context (optional; it is also released when the object is garbage-collected). */
+    close() { if (this._ctxHandle) { this._native.destroy(this._ctxHandle); this._ctxHandle = null; } }
+
+    // ------------------------------------------------------------------------------------------------ public setters
+    setReferencePoints(srcPoints, dstPoints, image = null, width = null, height = null, srcPointsAreNormalized = null, dstPointsAreNormalized = null) {   // :173-182
+        if (typeof (srcPoints) === 'undefined' || typeof (dstPoints) === 'undefined') {
+            throw ("Source and Destiny points must be defined when calling setReferencePoints().");
+        }
+        this._dstPoints = null;
+        this.setSourcePoints(srcPoints, image, width, height, srcPointsAreNormalized);
+        this.setDestinyPoints(dstPoints, dstPointsAreNormalized);
+    }
+
+    setSourcePoints(points, image = null, width = null, height = null, pointsAreNormalized = null) {    // :218-265
+        points = toF32(points);
+        this._srcPoints = points;
+        this._srcPointsAreNormalized = pointsAreNormalized === null ? !anyAbove(points, NORMALIZED_MAX) : pointsAreNormalized;
+        this._transformMatrix = null;
+        this.transform = selectTransform(this.firstTransformSelected, points);
+        this._objectiveWidth = null; this._objectiveHeight = null;
+        if (image !== null) this.setImage(image, width, height);
+        else if (width !== null || height !== null) this._setSourceSize(width, height);
+        if (this._width !== null && this._height !== null && this._srcPointsAreNormalized) {
+            scalePoints(this._srcPoints, this._width, this._height);
+            this._srcPointsAreNormalized = false;
+        }
+        if (this._dstPoints !== null && this.transform !== 'piecewiseaffine') {
+            this._transformMatrix = this._solve(this._srcPoints, this._dstPoints);
+        }
+        if (this.transform === 'piecewiseaffine' && this._mapState === null) {
+            this._triangles = null;                             // :254 (_initialTriangles is never set by the reference)
+            this._piecewiseReady = false;
+            if (!this._srcPointsAreNormalized || (this._width > 0 && this._height > 0)) this._refreshPiecewise();
+            else if (this._triangles === null) this._triangles = Homography.triangulate(this._srcPoints);
+        }
+    }
+
+    setImage(image, width = null, height = null) {                                                      // :290-316
+        if (!image || !ArrayBuffer.isView(image.data)) {
+            throw ("hgwarp: setImage() needs an ImageData-shaped {data: Uint8ClampedArray, width, height}; HTMLImageElement inputs need a browser DOM");
+        }
+        this._image = image.data;                               // aliased, not copied (:298): re-read (re-uploaded) on every warp()
+        this._setSourceSize(image.width, image.height);
+        if (this._srcPoints !== null && this.transform === 'piecewiseaffine') this._refreshPiecewise();
+        if (this._dstPoints !== null && (this._objectiveWidth <= 0 || this._objectiveHeight <= 0)) this._deriveOutputWindow();
+    }
+
+    setDestinyPoints(points, pointsAreNormalized = null) {                                              // :337-380
+        points = toF32(points);
+        if (this._srcPoints !== null && points.length !== this._srcPoints.length) {
+            throw (`It must be the same amount of destiny points (${points.length / 2}) than source points (${this._srcPoints.length / 2})`);
+        }
+        this._dstPoints = points;
+        this._dstPointsAreNormalized = pointsAreNormalized === null ? !anyAbove(points, NORMALIZED_MAX) : pointsAreNormalized;
+        if (this.transform !== 'piecewiseaffine') {
+            if (this._dstPointsAreNormalized && this._width > 0 && this._height > 0 && this.transform === 'projective') {
+                scalePoints(this._dstPoints, this._width, this._height);
+                this._dstPointsAreNormalized = false;
+            }
+            this._alignRanges();
+            this._transformMatrix = this._solve(this._srcPoints, this._dstPoints);
+        } else {
+            this._piecewiseReady = false;
+        }
+        if (this._image !== null || (this.transform === 'piecewiseaffine' && this._width > 0 && this._height > 0)) this._deriveOutputWindow();
+        if (this.transform === 'piecewiseaffine' && this._width > 0 && this._height > 0) {
+            if (this._dstPointsAreNormalized) { scalePoints(this._dstPoints, this._width, this._height); this._dstPointsAreNormalized = false; }
+            this._refreshPiecewise();
+        }
+    }
+
+    setTriangles(triangles) {                                                                           // :517-524
+        this._triangles = triangles;
+        if ((!this._srcPointsAreNormalized || (this._width > 0 && this._height > 0)) && this._srcPoints !== null) this._refreshPiecewise();
+    }
+
+    // ------------------------------------------------------------------------------------------------ warp
+    warp(image = null, asHTMLPromise = false, applyAlwaysInverse = false) {                             // :408-446
+        if (image !== null) this.setImage(image);
+        else if (this._image === null) {
+            throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
+        }
+        if (asHTMLPromise) throw ("hgwarp: asHTMLPromise needs a browser DOM; use the returned ImageData-shaped object");
+        let out;
+        switch (this.transform) {
+            case 'piecewiseaffine':
+                out = (applyAlwaysInverse || (this._objectiveWidth > this._width || this._objectiveHeight > this._height ||
+                       this._objectiveWidth * 1.2 < this._width || this._objectiveHeight * 1.2 < this._height))
+                    ? this._inversePiecewise() : this._forwardPiecewise();
+                break;
+            case 'affine':
+                out = (applyAlwaysInverse || (this._objectiveWidth !== this._width || this._objectiveHeight !== this._height))
+                    ? this._inverseGeometric() : this._forwardGeometric();
+                break;
+            case 'projective':
+                out = this._inverseGeometric();
+                break;
+        }
+        const area = this._objectiveWidth * this._objectiveHeight;
+        if (area >= 1 && !isNaN(area)) return makeImageData(out, this._objectiveWidth, this._objectiveHeight);
+        return makeImageData(new Uint8ClampedArray(4), 1, 1);                                           // :440
+    }
+
+    /**
+     * The benchmarked caller loop `for (f) { setDestinyPoints(dst[f]); warp(); }` (test/benchmark.js:107-110) for a
+     * piecewise mesh, as ONE GPU pass.  dstPointSets: array of point sets (pixel coordinates).  Returns an array of
+     * ImageData-shaped frames, each identical to what the loop would return with applyAlwaysInverse = true.
+     */
+    warpBatch(dstPointSets) {
+        if (this.transform !== 'piecewiseaffine') throw ("hgwarp: warpBatch() is for the piecewise affine transform");
+        if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
+        const F = dstPointSets.length, n = this._srcPoints.length;
+        const all = new Float32Array(F * n), geoms = new Int32Array(F * 4);
+        for (let f = 0; f < F; f++) {
+            const p = toF32(dstPointSets[f]);
+            if (p.length !== n) throw (`It must be the same amount of destiny points (${p.length / 2}) than source points (${n / 2})`);
+            all.set(p, f * n);
+            const mm = this._native.minmaxXY(asF32(p));                                                 // :706-710
+            geoms.set([mm[0], mm[1], mm[2] - mm[0], mm[3] - mm[1]], f * 4);
+        }
+        this._uploadImage();
+        this._uploadMesh();
+        const datas = this._native.warpInversePiecewiseBatch(this._ctx, all, geoms);
+        return datas.map((d, f) => makeImageData(d, geoms[4 * f + 2], geoms[4 * f + 3]));
+    }
+
+    getTransformationMatrixAsCSS(srcPoints = null, dstPoints = null, width = null, height = null) {     // :548-587
+        if (width !== null || height !== null) this._setSourceSize(width, height);
+        if (srcPoints !== null) this.setSourcePoints(srcPoints, null, width, height);
+        if (dstPoints !== null) this.setDestinyPoints(dstPoints);
+        if (this._srcPoints === null) throw ("Impossible to calculate a transform when srcPoints are not set");
+        else if (this._dstPoints === null) throw ("Impossible to calculate a transform when dstPoints are not set");
+        else if (this._transformMatrix === null) throw ("Transform matrix can not be calculated");
+        const m = this._transformMatrix, fx = (v) => v.toFixed(CSS_DECIMALS);
+        if (this.transform === 'affine') return `matrix(${Array.from(m, fx).join(', ')})`;
+        if (this.transform === 'projective') {
+            const cells = [];
+            let i = 0;
+            for (let row = 0; row < 4; row++) for (let col = 0; col < 4; col++) {
+                if ((row === 2 && col === 2) || (row === 3 && col === 3)) cells.push('1');
+                else if (row === 2 || col === 2) cells.push('0');
+                else cells.push(fx(m[((i++) * 3) % 8]));
+            }
+            return `matrix3d(${cells.join(', ')})`;
+        }
+        throw (`Only "affine" or "projective" transforms can be applied on the CSS transform property, but ${this.transform} selected`);
+    }
+
+    HTMLImageElementFromImageData() { throw ("hgwarp: HTMLImageElementFromImageData() needs a browser DOM"); }
+    transformHTMLElement() { throw ("hgwarp: transformHTMLElement() needs a browser DOM"); }
+
+    // ------------------------------------------------------------------------------------------------ parity taps (debug)
+    /** Int16Array the reference's _buildInverseTrianglesCorrespondencesMatrix would hold for the last inverse piecewise warp. */
+    triangleMap(fused = true) { return this._native.getTriMap(this._ctx, !!fused); }
+    /** {forward, inverse}: per-triangle Float32Array(6 T) of the last piecewise warp. */
+    piecewiseMatrices() { return this._native.getMatrices(this._ctx, this._triangles.length / 3); }
+
+    // ------------------------------------------------------------------------------------------------ private
+    _solve(from, to) {                                                                                   // :1237-1250
+        const a = asF32(from), b = asF32(to);
+        if (this.transform === 'affine') return this._native.solveAffine(a, b);                          // Float32Array(6)
+        if (this.transform === 'projective') return Array.from(this._native.solveProjective(a, b));      // plain Array(8) of doubles, as numeric.js returns
+        throw (`${this.transform} transform does not exist`);
+    }
+
+    _setSourceSize(width, height) {                                                                      // :637-679
+        const lastW = this._width, lastH = this._height;
+        this._width = width; this._height = height;
+        if (lastW === width && lastH === height) return;
+        this._width = Math.round(width); this._height = Math.round(height);
+        this._mapState = null;
+        if (this.transform === 'projective') {
+            if (this._srcPoints !== null && this._srcPointsAreNormalized) { scalePoints(this._srcPoints, this._width, this._height); this._srcPointsAreNormalized = false; }
+            if (this._dstPoints !== null && this._dstPointsAreNormalized) { scalePoints(this._dstPoints, this._width, this._height); this._dstPointsAreNormalized = false; }
+            if (this._dstPoints !== null && this._srcPoints !== null) {
+                this._transformMatrix = this._solve(this._srcPoints, this._dstPoints);
+                this._deriveOutputWindow();
+            }
+        }
+        if (this._srcPoints !== null && this.transform === 'piecewiseaffine') this._refreshPiecewise();
+    }
+
+    _deriveOutputWindow() {                                                                              // :693-725
+        if (this.transform === 'affine' || this.transform === 'projective') {
+            if (this._transformMatrix === null) {
+                if (this._srcPointsAreNormalized !== this._dstPointsAreNormalized) this._alignRanges();
+                this._transformMatrix = this._solve(this._srcPoints, this._dstPoints);
+            }
+            const lim = this._native.transformLimits(this.transform === 'affine' ? AFFINE : PROJECTIVE, Float64Array.from(this._transformMatrix), this._width, this._height);
+            [this._xOutputOffset, this._yOutputOffset, this._objectiveWidth, this._objectiveHeight] = lim;
+        } else if (!this._dstPointsAreNormalized) {
+            const mm = this._native.minmaxXY(asF32(this._dstPoints));                                    // rounded min/max, then subtract (:707-710)
+            this._xOutputOffset = mm[0]; this._yOutputOffset = mm[1];
+            this._objectiveWidth = mm[2] - mm[0]; this._objectiveHeight = mm[3] - mm[1];
+        } else if (this._width > 0 && this._height > 0) {
+            let minX = Infinity, minY = Infinity, maxX = -Infinity, maxY = -Infinity;                    // unrounded (:714-718)
+            const p = this._dstPoints;
+            for (let i = 0; i < p.length; i++) {
+                if ((i % 2) === 0) { if (p[i] > maxX) maxX = p[i]; if (p[i] < minX) minX = p[i]; }
+                else { if (p[i] > maxY) maxY = p[i]; if (p[i] < minY) minY = p[i]; }
+            }
+            this._xOutputOffset = Math.round(minX); this._yOutputOffset = Math.round(minY);
+            this._objectiveWidth = Math.round((maxX - minX) * this._width);
+            this._objectiveHeight = Math.round((maxY - minY) * this._height);
+        } else {
+            throw ("Trying to calculate a the output width and height of a Piecewise Affine transform but source width and height are not set");
+        }
+    }
+
+    _refreshPiecewise() {                                                                                // :738-774
+        if (this._srcPoints === null) throw ("Trying to set the Piecewise Affine Transform parameters before setting the Source Points.");
+        if (this._triangles === null) this._triangles = Homography.triangulate(this._srcPoints);
+        if (this._srcPointsAreNormalized) {
+            if (this._width > 0 && this._height > 0) { scalePoints(this._srcPoints, this._width, this._height); this._srcPointsAreNormalized = false; }
+            else throw ("Trying to set the Piecewise Affine Transform parameters without knowing the source points ranges");
+        }
+        if (!this._srcPointsAreNormalized && (this._triangles === null || this._mapState === null)) {
+            const mm = this._native.minmaxXY(asF32(this._srcPoints));                                    // :758
+            [this._minSrcX, this._minSrcY, this._maxSrcX, this._maxSrcY] = mm;
+            this._mapState = 'forward';                                                                  // :759 (built on the GPU when a forward warp needs it)
+        }
+        if (this._dstPoints !== null && !this._piecewiseReady && this._triangles !== null) {
+            if (this._dstPointsAreNormalized) { scalePoints(this._dstPoints, this._width, this._height); this._dstPointsAreNormalized = false; }
+            if (this._srcPointsAreNormalized !== this._dstPointsAreNormalized) this._alignRanges();     // :787-789
+            this._piecewiseReady = true;                                                                 // :769 (the per-triangle solves run on the GPU with the warp)
+        }
+    }
+
+    _alignRanges() {                                                                                     // :876-896
+        if (this._dstPointsAreNormalized === this._srcPointsAreNormalized) return;
+        if (this._dstPointsAreNormalized && this._width > 0 && this._height > 0) {
+            unscalePoints(this._srcPoints, this._width, this._height);
+            this._srcPointsAreNormalized = true;
+        } else if (this._srcPointsAreNormalized && this._width > 0 && this._height > 0) {
+            scalePoints(this._srcPoints, this._width, this._height);
+            this._srcPointsAreNormalized = false;
+        } else {
+            throw ("Impossible to put source and destiny points in the same range. Possible solutions: \n" +
+                   "1. Give a source width/height when calling setSrcPoints.\n" +
+                   "2. Set the input image before.\n" +
+                   "3. Give Source and Destiny points in the same range (both normalized or both in image dimensions)");
+        }
+    }
+
+    _uploadImage() {
+        // The reference re-reads the caller's buffer on every warp (:298), so a mutated buffer must show up: upload every time.
+        this._native.setImage(this._ctx, this._image, this._width, this._height);
+    }
+
+    _uploadMesh() {
+        const tris = this._triangles instanceof Uint32Array ? this._triangles : Uint32Array.from(this._triangles);
+        this._native.piecewiseSetMesh(this._ctx, asF32(this._srcPoints), tris, this._minSrcX, this._minSrcY);
+    }
+
+    _window() { return [this._xOutputOffset, this._yOutputOffset, this._objectiveWidth, this._objectiveHeight]; }
+
+    _inverseGeometric() {                                                                                // :987-1013
+        this._lastPath = '_inverseGeometricWarp';
+        this._alignRanges();
+        const inv = this._solve(this._dstPoints, this._srcPoints);                                       // re-solved from the swapped sets (:994)
+        this._uploadImage();
+        const [xo, yo, ow, oh] = this._window();
+        if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        return this._native.warpInverseGeometric(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, Float64Array.from(inv), xo, yo, ow, oh);
+    }
+
+    _inversePiecewise() {                                                                                // :1029-1058
+        this._lastPath = '_inversePiecewiseAffineWarp';
+        const [xo, yo, ow, oh] = this._window();
+        this._mapState = 'inverse';                                                                      // :848 (the reference reuses the same field)
+        if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        this._uploadImage();
+        this._uploadMesh();
+        this._native.piecewisePrepare(this._ctx, asF32(this._dstPoints), xo, yo, ow, oh);
+        return this._native.warpInversePiecewise(this._ctx);
+    }
+
+    _forwardGeometric() {                                                                                // :911-932
+        this._lastPath = '_geometricWarp';
+        if (!this._native.warpForwardGeometric) throw ("hgwarp: the forward (source-to-destiny) affine path is not built into this addon; call warp(image, false, true)");
+        this._uploadImage();
+        const [xo, yo, ow, oh] = this._window();
+        if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        return this._native.warpForwardGeometric(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, Float64Array.from(this._transformMatrix), xo, yo, ow, oh);
+    }
+
+    _forwardPiecewise() {                                                                                // :948-972
+        this._lastPath = '_piecewiseAffineWarp';
+        if (!this._native.warpForwardPiecewise) throw ("hgwarp: the forward (source-to-destiny) piecewise path is not built into this addon; call warp(image, false, true)");
+        if (this._mapState !== 'forward') throw ("hgwarp: forward piecewise warp after an inverse one reuses a stale triangle map in the reference (undefined behaviour); set the source points again");
+        this._uploadImage();
+        this._uploadMesh();
+        const [xo, yo, ow, oh] = this._window();
+        if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        return this._native.warpForwardPiecewise(this._ctx, asF32(this._dstPoints), this._maxSrcX, this._maxSrcY, xo, yo, ow, oh);
+    }
+}
+
+function selectTransform(transform, points) {                                                            // :1444-1481
+    switch (transform) {
+        case 'auto':
+            if (points.length === 6) return 'affine';
+            if (points.length === 8) return 'projective';
+            if (points.length > 8) return 'piecewiseaffine';
+            throw (`Transforms must contain at least 3 points but only ${points.length / 2} were given`);
+        case 'piecewiseaffine':
+            if (points.length < 6) throw (`A piecewise (or affine) transform needs to determine least three reference points but only ${points.length / 2} were given`);
+            return transform;
+        case 'affine':
+            if (points.length !== 6) throw (`An affine transform needs to determine exactly three reference points but ${points.length / 2} were given`);
+            return transform;
+        case 'projective':
+            if (points.length !== 8) throw (`A projective transform needs to determine exactly four reference points but ${points.length / 2} were given`);
+            return transform;
+        default:
+            throw (`Transform "${transform}" is unknown`);
+    }
+}
+
+/** Triangulator used where the reference calls `new Delaunator(points).triangles` (:1216-1218).  Replaceable. */
+Homography.triangulate = defaultTriangulate;
+Homography.availableTransforms = TRANSFORMS;
+
+export { Homography };

@@ -143,6 +143,16 @@ int hg_get_matrices(hg_ctx *ctx, float *fwd, float *inv);
  * what the library itself re-runs for a frame whose rows overflow the fused kernel's LDS span list. */
 int hg_warp_inverse_piecewise_via_map(hg_ctx *ctx, uint8_t *out_host);
 
+/* ------------------------------------------------------------------------------------------------ forward (scatter) paths
+ * What warp() dispatches to when the output is not larger than the input (:421, :426).  `m` is the FORWARD matrix
+ * (_transformMatrix).  Sequential "last writer in raster order wins" is reproduced deterministically (atomicMax of the
+ * raster rank per output pixel, then a gather).  Synchronous, host output of 4*obj_w*obj_h bytes. */
+/* _geometricWarp :911-932 */
+int hg_warp_forward_geometric(hg_ctx *ctx, int kind, const double *m, hg_geom geom, uint8_t *out_host);
+/* _piecewiseAffineWarp :948-972 on the mesh of hg_piecewise_set_mesh (whose min_src_x/y are the loop origin);
+ * max_src_x/y = rounded source-point bbox maximum (:758); the forward triangle map :817-832 is rebuilt on the device. */
+int hg_warp_forward_piecewise(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host);
+
 /* ------------------------------------------------------------------------------------------------ measurement aid
  * hipEvent pairs recorded on the ctx stream around each launch of the dominant kernel (the fused piecewise kernel or
  * the geometric kernel; not the tiny per-triangle setup).  hg_set_timing(ctx, 1) enables it and resets the counters;

@@ -1,0 +1,71 @@
+// Host-side (no GPU) checks of the drop-in class's JavaScript: own Delaunay triangulator, error behaviour, CSS export.
+import { triangulate, gridTriangles } from '../../homography.js_amd/js/delaunay.mjs';
+import { Homography } from '../../homography.js_amd/js/Homography.mjs';
+
+const fails = [];
+const ok = (c, m) => { if (!c) fails.push(m); };
+function rng(seed) { let s = seed >>> 0 || 1; return () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s / 4294967296; }; }
+function hullArea(P) {
+    const p = P.map((q) => q.slice()).sort((a, b) => a[0] - b[0] || a[1] - b[1]);
+    const cross = (o, a, b) => (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]);
+    const lo = [], up = [];
+    for (const q of p) { while (lo.length >= 2 && cross(lo[lo.length - 2], lo[lo.length - 1], q) <= 0) lo.pop(); lo.push(q); }
+    for (const q of p.reverse()) { while (up.length >= 2 && cross(up[up.length - 2], up[up.length - 1], q) <= 0) up.pop(); up.push(q); }
+    const h = lo.slice(0, -1).concat(up.slice(0, -1));
+    let a = 0; for (let i = 0; i < h.length; i++) { const j = (i + 1) % h.length; a += h[i][0] * h[j][1] - h[j][0] * h[i][1]; }
+    return Math.abs(a) / 2;
+}
+function checkDelaunay(P, tag) {
+    const t = triangulate(P);
+    ok(t instanceof Uint32Array && t.length % 3 === 0 && t.length > 0, `${tag}: output type`);
+    let area = 0;
+    for (let i = 0; i < t.length; i += 3) {
+        const [a, b, c] = [P[t[i]], P[t[i + 1]], P[t[i + 2]]];
+        const d = 2 * (a[0] * (b[1] - c[1]) + b[0] * (c[1] - a[1]) + c[0] * (a[1] - b[1]));
+        area += Math.abs(d) / 4;
+        if (Math.abs(d) < 1e-12) { fails.push(`${tag}: degenerate triangle`); continue; }
+        const ux = ((a[0] ** 2 + a[1] ** 2) * (b[1] - c[1]) + (b[0] ** 2 + b[1] ** 2) * (c[1] - a[1]) + (c[0] ** 2 + c[1] ** 2) * (a[1] - b[1])) / d;
+        const uy = ((a[0] ** 2 + a[1] ** 2) * (c[0] - b[0]) + (b[0] ** 2 + b[1] ** 2) * (a[0] - c[0]) + (c[0] ** 2 + c[1] ** 2) * (b[0] - a[0])) / d;
+        const r2 = (a[0] - ux) ** 2 + (a[1] - uy) ** 2;
+        for (let q = 0; q < P.length; q++) {
+            if (q === t[i] || q === t[i + 1] || q === t[i + 2]) continue;
+            if ((P[q][0] - ux) ** 2 + (P[q][1] - uy) ** 2 < r2 * (1 - 1e-9)) { fails.push(`${tag}: point ${q} inside circumcircle of triangle ${i / 3}`); break; }
+        }
+    }
+    const ha = hullArea(P);
+    ok(Math.abs(area - ha) <= 1e-6 * ha, `${tag}: triangles cover ${area}, hull is ${ha}`);
+    return t;
+}
+for (let k = 0; k < 12; k++) {
+    const r = rng(900 + k), n = 5 + Math.floor(r() * 120), P = [];
+    for (let i = 0; i < n; i++) P.push([r() * 1000, r() * 700]);
+    checkDelaunay(P, `random${k}`);
+}
+{   // the 68-landmark style layout and a regular grid (co-circular quads)
+    const G = []; for (let j = 0; j <= 5; j++) for (let i = 0; i <= 7; i++) G.push([i * 50, j * 40]);
+    const t = checkDelaunay(G, 'grid');
+    ok(t.length / 3 === 2 * 7 * 5, `grid: ${t.length / 3} triangles`);
+    ok(gridTriangles(7, 5).length === 7 * 5 * 6, 'gridTriangles length');
+    ok(triangulate(Float32Array.from([0, 0, 10, 0, 0, 10])).length === 3, 'typed-array input');
+    ok(triangulate([[0, 0], [1, 1]]).length === 0, 'fewer than 3 points');
+}
+{   // state-machine errors are bare strings, like the reference's throw("...")
+    const expectThrow = (fn, part, tag) => { try { fn(); fails.push(`${tag}: did not throw`); } catch (e) { ok(typeof e === 'string' && e.includes(part), `${tag}: threw ${typeof e} ${e}`); } };
+    expectThrow(() => new Homography('affine').setSourcePoints([[0, 0], [1, 1]]), 'exactly three reference points', 'affine with 2 points');
+    expectThrow(() => new Homography('auto').setSourcePoints([[0, 0], [1, 1]]), 'at least 3 points', 'auto with 2 points');
+    expectThrow(() => new Homography('nope').setSourcePoints([[0, 0], [1, 1], [2, 2]]), 'is unknown', 'unknown transform');
+    expectThrow(() => new Homography().warp(), 'warp() must receive an image', 'warp without image');
+    expectThrow(() => new Homography().setReferencePoints(undefined, [[0, 0]]), 'must be defined', 'undefined points');
+    expectThrow(() => { const h = new Homography('affine'); h.setSourcePoints([[0, 0], [0, 1], [1, 0]]); h.setDestinyPoints([[0, 0], [0, 1]]); }, 'same amount of destiny points', 'length mismatch');
+    expectThrow(() => { const h = new Homography('affine'); h.setSourcePoints([[0, 0], [0, 400], [400, 0]]); h.setDestinyPoints([[0, 0], [0, 1], [1, 0]]); }, 'Impossible to put source and destiny points in the same range', 'mixed ranges without size');
+    expectThrow(() => new Homography('piecewiseaffine').setImage({ width: 4, height: 4 }), 'ImageData-shaped', 'HTMLImageElement-like input');
+    // CSS export: affine / projective strings with 5 decimals (:548-587)
+    const a = new Homography('affine'); a.setReferencePoints([[0, 0], [0, 1], [1, 0]], [[0, 0], [1 / 2, 1], [1, 1 / 8]]);
+    ok(a.getTransformationMatrixAsCSS() === 'matrix(1.00000, 0.12500, 0.50000, 1.00000, 0.00000, 0.00000)', `affine css ${a.getTransformationMatrixAsCSS()}`);
+    const p = new Homography('projective'); p.setReferencePoints([[0, 0], [0, 1], [1, 0], [1, 1]], [[0, 0], [0, 1], [1, 0.1], [1, 1]]);
+    const css = p.getTransformationMatrixAsCSS();
+    ok(css.startsWith('matrix3d(') && css.split(',').length === 16, `projective css ${css}`);
+    expectThrow(() => new Homography('piecewiseaffine').getTransformationMatrixAsCSS([[0, 0], [0, 1], [1, 0], [1, 1], [2, 2]], [[0, 0], [0, 1], [1, 0], [1, 1], [2, 2]], 10, 10), 'Transform matrix can not be calculated', 'css piecewise');
+}
+console.log(JSON.stringify({ failures: fails }));
+process.exit(fails.length ? 1 : 0);

@@ -23,12 +23,7 @@ def ctx():
 
 
 def _inverse_warps():
-    ps = []
-    for c in GOLD["cases"]:
-        for k, w in enumerate(c["warps"]):
-            if w["path"] in ("_inverseGeometricWarp", "_inversePiecewiseAffineWarp"):
-                ps.append(pytest.param(c["name"], k, id=f"{c['name']}#{k}"))
-    return ps
+    return [pytest.param(c["name"], k, id=f"{c['name']}#{k}") for c in GOLD["cases"] for k, w in enumerate(c["warps"])]
 
 
 def _nan_eq(a, b):
@@ -42,6 +37,13 @@ def hip_run_warp(ctx, case, k, taps=False):
     ctx.set_image(img)
     geom = (w["xOff"], w["yOff"], w["objW"], w["objH"])
     sp, dp = G.f32_from_bits(w["srcPoints"]), G.f32_from_bits(w["dstPoints"])
+    if w["path"] == "_piecewiseAffineWarp":         # forward scatter (what warp() picks when the output is not larger)
+        ctx.piecewise_set_mesh(sp, G.case_triangles(case), w["minSrcX"], w["minSrcY"])
+        return ctx.warp_forward_piecewise(dp, w["maxSrcX"], w["maxSrcY"], geom)
+    if w["path"] == "_geometricWarp":
+        kind = 0 if w["transform"] == "affine" else 1
+        m = G.f32_from_bits(w["matrix"]["f32"]).astype(np.float64) if kind == 0 else G.f64_from_hex(w["matrix"]["f64"])
+        return ctx.warp_forward_geometric(kind, m, geom)
     if w["transform"] == "piecewiseaffine":
         tris = G.case_triangles(case)
         ctx.piecewise_set_mesh(sp, tris, w["minSrcX"], w["minSrcY"])
@@ -60,7 +62,7 @@ def hip_run_warp(ctx, case, k, taps=False):
 def test_hip_matches_reference_golden(ctx, name, k):
     case = next(c for c in GOLD["cases"] if c["name"] == name)
     w = case["warps"][k]
-    pw = w["transform"] == "piecewiseaffine"
+    pw = w["path"] == "_inversePiecewiseAffineWarp"
     res = hip_run_warp(ctx, case, k, taps=pw)
     out = res[0] if pw else res
     assert out.shape == (w["out"]["h"], w["out"]["w"], 4)
@@ -118,6 +120,38 @@ def test_hip_matches_oracle_on_fresh_seeds(ctx):
         lim = [int(v) for v in O.transform_limits(0, fa, W, H)]
         ia = O.affine_from_triangles(d4[:6], s4[:6]).astype(np.float64)
         assert np.array_equal(ctx.warp_inverse_geometric(0, ia, lim), O.warp_inverse_geometric(0, ia, img, *lim))
+
+
+def test_forward_scatter_matches_oracle(ctx):
+    """_geometricWarp / _piecewiseAffineWarp (last writer in raster order wins) against the sequential oracle."""
+    rng = np.random.default_rng(77)
+    for trial in range(10):
+        W, H = int(rng.integers(30, 200)), int(rng.integers(20, 150))
+        img = G.lcg_image(W, H, 700 + trial)
+        ctx.set_image(img)
+        s3 = np.array([0, 0, 0, H, W, 0], np.float32)
+        d3 = (s3.reshape(3, 2) * rng.uniform(0.4, 1.1, 2) + rng.uniform(-20, 30, 2) + rng.uniform(-10, 10, (3, 2))).astype(np.float32).ravel()
+        fa = O.affine_from_triangles(s3, d3).astype(np.float64)
+        lim = [int(v) for v in O.transform_limits(0, fa, W, H)]
+        assert np.array_equal(ctx.warp_forward_geometric(0, fa, lim), O.warp_forward_geometric(0, fa, img, *lim)), ("affine", trial)
+        s4 = np.array([0, 0, 0, H, W, 0, W, H], np.float32)
+        d4 = (s4.reshape(4, 2) * rng.uniform(0.5, 1.0, 2) + rng.uniform(-5, 5, (4, 2))).astype(np.float32).ravel()
+        fp = O.projective_from_squares(s4, d4)
+        lim = [int(v) for v in O.transform_limits(1, fp, W, H)]
+        assert np.array_equal(ctx.warp_forward_geometric(1, fp, lim), O.warp_forward_geometric(1, fp, img, *lim)), ("projective", trial)
+        nx, ny = int(rng.integers(1, 7)), int(rng.integers(1, 6))
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        if trial % 3 == 0:
+            sp = (sp.reshape(-1, 2) * 0.8 + [W * 0.1 - 4, H * 0.1 + 3]).astype(np.float32).ravel()      # source bbox off the image corner
+        dp = ((sp.reshape(-1, 2) + rng.uniform(-0.25, 0.25, (sp.size // 2, 2)) * [W / nx, H / ny]) * rng.uniform(0.5, 1.0, 2) + rng.uniform(0, 12, 2)).astype(np.float32).ravel()
+        ms, md = O.minmax_xy(sp), O.minmax_xy(dp)
+        geom = (int(md[0]), int(md[1]), int(md[2] - md[0]), int(md[3] - md[1]))
+        mw, mh = int(ms[2] - ms[0]), int(ms[3] - ms[1])
+        fwd = O.piecewise_matrices(sp, dp, tris)
+        fmap = O.build_tri_map(sp, tris, mw, int(ms[1]), mw * mh)
+        want = O.warp_forward_piecewise(fmap, fwd, img, int(ms[0]), int(ms[1]), int(ms[2]), int(ms[3]), *geom)
+        ctx.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
+        assert np.array_equal(ctx.warp_forward_piecewise(dp, int(ms[2]), int(ms[3]), geom), want), ("piecewise", trial)
 
 
 def test_batch_frames_equal_single_frames(ctx):

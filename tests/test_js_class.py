@@ -1,0 +1,56 @@
+"""The drop-in JavaScript `Homography` class (homography.js_amd/js/Homography.mjs) under Node.
+CPU: state machine replay of every golden script (path chosen, output window, points, matrices), own Delaunay,
+error strings, CSS export, loud failure without a GPU.  GPU: full replay incl. RGBA + triangle-map hashes."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+ADDON = os.path.join(ROOT, "homography.js_amd", "lib", "hgwarp.node")
+
+pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON), reason="node or the N-API addon is missing")
+
+
+def _node(script, *args, timeout=900):
+    p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert line, f"no JSON from {script}: rc={p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
+    return p.returncode, json.loads(line[-1])
+
+
+def test_state_machine_replay_matches_reference():
+    rc, res = _node("replay_golden.mjs", "--dry")
+    assert res["failures"] == [] and rc == 0
+    assert res["cases"] >= 78 and res["warps"] >= 83
+
+
+def test_host_side_javascript():
+    rc, res = _node("test_host.mjs")
+    assert res["failures"] == [] and rc == 0
+
+
+def test_warp_without_gpu_throws_a_string():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    code = """
+import { Homography } from './homography.js_amd/js/Homography.mjs';
+const h = new Homography('affine');
+h.setReferencePoints([[0,0],[0,1],[1,0]], [[0,0],[0,2],[2,0]]);
+try { h.warp({data: new Uint8ClampedArray(16*16*4), width: 16, height: 16}); console.log(JSON.stringify({threw: false})); }
+catch (e) { console.log(JSON.stringify({threw: true, type: typeof e, msg: String(e)})); }
+"""
+    p = subprocess.run([NODE, "--input-type=module", "-e", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["threw"] and res["type"] == "string" and "no CPU fallback" in res["msg"]
+
+
+@pytest.mark.gpu
+def test_full_replay_on_gpu_matches_reference_hashes():
+    rc, res = _node("replay_golden.mjs", timeout=1500)
+    assert res["failures"] == [] and rc == 0
+    assert res["mode"] == "gpu" and res["warps"] >= 83
