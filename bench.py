@@ -4,8 +4,8 @@
 A "step" is one pass of the hot path over one batch of synthetic input: F destination point sets of the C3 workload
 (3840x2160 RGBA, 11x11-point sinusoidal grid = 200 triangles; frame f uses sin((8 + f mod 4) x / pi), the pattern of the
 reference's own harness test/benchmark.js:68,107-110) on a shared source image.  Per step and per frame the library
-does what the reference redoes per frame (`setDestinyPoints(dst_f); warp()`): per-triangle affine solves + inverses
-(k_tri_setup) and the inverse piecewise warp (k_pw_fused).  Inputs (source RGBA, meshes, destination points) are
+does what the reference redoes per frame (`setDestinyPoints(dst_f); warp()`): per-triangle affine solves + inverses +
+triangle spans (k_tri_spans) and the inverse piecewise warp (k_pw_rows, the dominant kernel).  Inputs (source RGBA, meshes, destination points) are
 resident in HBM before the timed region; outputs stay in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config C3|C5|C2]
@@ -41,21 +41,17 @@ def _load(name, path):
     return mod
 
 
-def broadcast_source(img_t, rank, world, dist, torch):
-    """Shared source texture, rank 0 -> all: scatter 1/N to each peer, then all_gather (every xGMI link carries 1/N of
-    the image instead of a ring/tree bound by one link).  img_t: uint8 CUDA tensor, same shape everywhere."""
-    if world == 1:
-        return img_t
-    flat = img_t.view(-1)
-    n = flat.numel()
-    chunk = (n + world - 1) // world
-    padded = torch.zeros(chunk * world, dtype=torch.uint8, device=flat.device)
-    if rank == 0:
-        padded[:n] = flat
-    mine = torch.empty(chunk, dtype=torch.uint8, device=flat.device)
-    dist.scatter(mine, list(padded.view(world, chunk).unbind(0)) if rank == 0 else None, src=0)
-    dist.all_gather_into_tensor(padded, mine)
-    return padded[:n].view_as(img_t).contiguous()
+def _pmc_traffic(config, frames, piecewise):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, profiles/hbm_traffic.json), when they were collected for this very workload; else null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            t = json.load(f)
+        if piecewise and t.get("config") == config and t.get("frames_per_launch") == frames:
+            return int(t["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -86,6 +82,7 @@ def main():
 
     hg = _load("hgwarp", os.path.join(PKG, "hgwarp.py"))
     wl = _load("hg_workloads", os.path.join(PKG, "workloads.py"))
+    hgdist = _load("hg_dist", os.path.join(PKG, "dist.py"))
     cfg = wl.CONFIGS[args.config]
     W, H, F = cfg["W"], cfg["H"], args.frames
 
@@ -95,7 +92,7 @@ def main():
         img_t.copy_(torch.from_numpy(wl.lcg_image(W, H, 1)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    img_t = broadcast_source(img_t, rank, world, dist, torch)
+    img_t = hgdist.broadcast_source(img_t, rank, world, dist)
     torch.cuda.synchronize()
     broadcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else 0.0
 
@@ -183,9 +180,9 @@ def main():
     # ---------------------------------------------------------------- roofline of the dominant kernel (rank 0's launches)
     k_ms = k_total_ms / max(k_launches, 1)
     achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_pw_fused" if piecewise else "k_geo<projective>",
+    roofline = {"bound": "hbm", "kernel": "k_pw_rows" if piecewise else "k_geo<projective>",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel_ms": round(k_ms, 5), "launches_timed": k_launches,
+                "traffic": _pmc_traffic(args.config, F, piecewise), "kernel_ms": round(k_ms, 5), "launches_timed": k_launches,
                 "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
                 "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel; "
                         "the shared 4K source stays in the 256 MiB Infinity Cache across frames, so HBM-side traffic is mostly the writes"}

@@ -1,0 +1,69 @@
+"""N > 1 path on CPU (gloo, world_size 2): frame sharding covers every frame exactly once and the scatter + all-gather
+source broadcast delivers the root's texture bit-for-bit to every rank."""
+import importlib.util
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "homography.js_amd", rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_shard_frames_partition():
+    D = _load("hg_dist", "dist.py")
+    for n in (0, 1, 7, 8, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            owned = [list(D.shard_frames(n, r, world)) for r in range(world)]
+            flat = [f for o in owned for f in o]
+            assert flat == list(range(n))
+            assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+
+
+def _worker(rank, world, port, shape, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = _load("hg_dist", "dist.py")
+        WL = _load("hg_workloads", "workloads.py")
+        h, w = shape
+        want = torch.from_numpy(WL.lcg_image(w, h, 5))
+        img = want.clone() if rank == 0 else torch.zeros_like(want)
+        got = D.broadcast_source(img, rank, world, dist)
+        ok = bool(torch.equal(got, want))
+        frames = list(D.shard_frames(11, rank, world))
+        q.put((rank, ok, frames))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (64, 64)])       # a size that does not divide by the world size, and one that does
+def test_broadcast_source_gloo_world2(shape):
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert sorted(f for _, _, fr in res for f in fr) == list(range(11))

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 sqlite outputs (kernel trace stats + PMC passes) as plain text."""
+import glob
+import os
+import sqlite3
+import sys
+
+out = sys.argv[1]
+for db in sorted(glob.glob(os.path.join(out, "trace", "*.db"))):
+    con = sqlite3.connect(db)
+    print("== rocprofv3 --kernel-trace --stats  (top kernels; durations in us)")
+    print(f"{'calls':>7} {'total_us':>12} {'avg_us':>10} {'pct':>6}  kernel")
+    for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 12"):
+        print(f"{calls:7d} {total/1e3 if total > 1e6 else total:12.1f} {avg/1e3 if avg > 1e5 else avg:10.2f} {pct:6.2f}  {name[:110]}")
+    print("   (units as reported by rocprofv3's top_kernels view)")
+    try:
+        rows = con.execute("select kernel_name, count(*), avg(end-start), min(end-start), max(end-start) from kernels where kernel_name like '%hg::%' group by kernel_name").fetchall()
+        print("== per-dispatch durations of the hg kernels (ns)")
+        for r in rows:
+            print(f"  {r[0][:70]:70s} n={r[1]:4d} avg={r[2]:12.0f} min={r[3]:12.0f} max={r[4]:12.0f}")
+    except Exception as e:  # schema differs between rocprof versions
+        print("  (kernels view unavailable:", e, ")")
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for db in glob.glob(os.path.join(d, "*.db")):
+        con = sqlite3.connect(db)
+        print(f"== PMC pass {os.path.basename(d)}  (average per dispatch)")
+        q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+             "where kernel_name like '%hg::%' group by kernel_name, counter_name")
+        for kn, cn, n, v in con.execute(q):
+            print(f"  {kn[:44]:44s} {cn:24s} n={n:3d} avg={v:.6g}")
+for log in sorted(glob.glob(os.path.join(out, "*.log"))):
+    tail = open(log, errors="replace").read().strip().splitlines()[-1:]
+    print(f"-- {os.path.basename(log)}: {tail[0][:300] if tail else ''}")
