@@ -52,6 +52,7 @@ struct hg_ctx {
 
     // geometric frames
     int geo_kind = 0;
+    bool geo_f32_exact = false;                                // affine matrices hold float values, |x| < 2^28
     std::vector<FrameDesc> geo_frames;
     FrameDesc *d_geo_frames = nullptr; size_t geo_frames_cap = 0;
     double *d_mats = nullptr; size_t mats_cap = 0;
@@ -404,6 +405,12 @@ extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, con
     HIP_TRY(c, hipMemcpyAsync(c->d_mats, m, sizeof(double) * 8 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->geo_kind = kind;
+    bool exact = kind == HG_AFFINE;
+    for (int f = 0; f < n && exact; f++) {
+        for (int k = 0; k < 6; k++) exact = exact && (double)(float)m[8 * f + k] == m[8 * f + k];
+        exact = exact && std::abs((int64_t)geoms[f].x_off) + std::max(geoms[f].obj_w, 0) < (1 << 28);
+    }
+    c->geo_f32_exact = exact;
     return HG_OK;
 }
 
@@ -416,7 +423,7 @@ extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
     int mw = 0, mh = 0;
     for (const FrameDesc &d : c->geo_frames) { mw = std::max(mw, d.obj_w); mh = std::max(mh, d.obj_h); }
     HG_TRY(time_begin(c));
-    launch_geo(c->geo_kind, c->d_geo_frames, c->d_mats, (int)c->geo_frames.size(), mw, mh, c->d_img, c->W, c->H,
+    launch_geo(c->geo_kind, c->geo_f32_exact, c->d_geo_frames, c->d_mats, (int)c->geo_frames.size(), mw, mh, c->d_img, c->W, c->H,
                static_cast<uint8_t *>(d_out), c->stream);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());

@@ -83,7 +83,8 @@ void launch_pw_from_map(const PwMesh &mesh, const PwFrames &fr, int f, const Fra
 void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream_t stream);
 
 // k_geo: _inverseGeometricWarp pixel loop :997-1011 for all frames.  mats = F x 8 doubles (inverse matrices).
-void launch_geo(int kind, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
+// f32_exact: every affine matrix entry is a float value and |x| < 2^28 (lets the kernel use an exact-product fma).
+void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
                 const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
 
 // Forward (scatter) paths, SURVEY.md §8f-1: winner buffer `win` = obj_w*obj_h int32 scratch.

@@ -345,7 +345,7 @@ __device__ __forceinline__ bool in_range_bits(double h, int64_t lo_bits, uint64_
     return (uint64_t)(__double_as_longlong(h) - lo_bits) < extent_bits;
 }
 
-template <int CAP, int ABL>
+template <int CAP, int ABL, int NB>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int rows_per_xcd)
 {
@@ -401,9 +401,11 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     const double by_lo = (double)mesh.min_src_y + 0.5;
     const int pitch4 = mesh.W * 4;
 
-    for (int w = wave; w < nwin; w += 4) {
+    // One window up to (not including) its gathers: triangle per pixel, transform, round, bounds -> 4 source byte offsets.
+    auto resolve = [&](int w, int best[4], uint32_t off[4]) {
         const int c0 = w << 8, cq = c0 + lane;              // lane l owns pixels c0 + l + 64k: every gather instruction covers
-        int best[4] = { -1, -1, -1, -1 };                   // 64 consecutive pixels and every store instruction 256 contiguous bytes
+#pragma unroll                                              // 64 consecutive pixels and every store instruction 256 contiguous bytes
+        for (int k = 0; k < 4; k++) best[k] = -1;
         for (int j = 0; j < cnt; j += 64) {
             const int idx = j + lane;
             int lo = 0x7fffffff, hi = 0;
@@ -435,13 +437,19 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
             v[2 * k + 1] = fma(m1.y, xd, m2.x) + m2.y;
         }
         round_x8(v, h, rd);
-        uint32_t px[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo);   // NaN fails
-            const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));   // :1048-1049
-            px[k] = (ABL & 2) ? (inb ? off : 0u) : __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
+            const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
+            off[k] = inb ? o : 0xffffffffu;
         }
+    };
+    auto gather = [&](const uint32_t off[4], uint32_t px[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) px[k] = (ABL & 2) ? off[k] : __builtin_amdgcn_raw_buffer_load_b32(src, off[k], 0, 0);   // outside the array -> 0
+    };
+    auto emit = [&](int w, const uint32_t px[4], const int best[4]) {
+        const int cq = (w << 8) + lane;
         if (!(ABL & 4) || (px[0] ^ px[1] ^ px[2] ^ px[3]) == 0x9e3779b9u) {
 #pragma unroll
             for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[k], dst, (cq + k * 64) * 4, 0, 0);
@@ -450,6 +458,23 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (cq + k * 64 < W) map_out[fd.map_off + row0 + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> 8);
+        }
+    };
+
+    // Two windows per iteration, straight-line on each path: the gathers of window A are in flight while window B is
+    // resolved (hipcc's waitcnt insertion is exact inside a basic block; across merges it drains everything).
+    for (int w = wave; w < nwin; w += 4 * NB) {
+        int bestA[4], bestB[4];
+        uint32_t offA[4], offB[4], pxA[4], pxB[4];
+        resolve(w, bestA, offA);
+        gather(offA, pxA);
+        if (NB > 1 && w + 4 < nwin) {
+            resolve(w + 4, bestB, offB);
+            gather(offB, pxB);
+            emit(w, pxA, bestA);
+            emit(w + 4, pxB, bestB);
+        } else {
+            emit(w, pxA, bestA);
         }
     }
 }
@@ -543,6 +568,68 @@ __global__ __launch_bounds__(256) void k_geo(const FrameDesc *__restrict__ frame
             px[k] = fetch_src(img32, n_src_px, W, round_inbounds(sx), round_inbounds(sy));       // :1005-1007
     }
     store_quad(orow, cq, OW, vec_ok, px);
+}
+
+// k_geo_fast: same loop with the k_pw_rows pixel body (requirements checked by geo_fast_ok(): source < 2^31 bytes).
+//   * lane l owns pixels c0 + l + 64k of its row: a gather instruction covers 64 consecutive output pixels;
+//   * row-constant terms are computed once per lane: fl(m1*y), fl(m4*y), fl(m7*y) (projective) / fl(m2*y), fl(m3*y) (affine);
+//   * affine: the matrix holds f32 values, m0*x is exact in fp64, so fma(m0, x, fl(m2*y)) rounds exactly where JS does;
+//     projective: the matrix is full double, every product rounds: plain mul/add and two IEEE divides per pixel;
+//   * Math.round + bounds :1001 via two round-toward-minus-infinity adds per coordinate (round_x8), source through a
+//     range-checked buffer load (0 outside the array), stores through a per-row buffer descriptor (no tail guards).
+template <int KIND>
+__global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ frames, const double *__restrict__ mats,
+                                                  const uint8_t *__restrict__ img, int W, int H, uint8_t *__restrict__ out)
+{
+    const FrameDesc fd = frames[blockIdx.z];
+    const int r = blockIdx.y * 4 + threadIdx.y;            // one wave per row of the block
+    const int lane = threadIdx.x;
+    const int c0 = blockIdx.x << 8;
+    const int OW = fd.obj_w;
+    if (r >= fd.obj_h || c0 >= OW) return;
+    const double *__restrict__ mp = mats + (size_t)blockIdx.z * 8;
+    double m[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) m[k] = mp[k];
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), 0, W * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r * OW * 4, 0, OW * 4, 0x00020000);
+    const double y = (double)(r + fd.y_off);
+    const double bx_hi = (double)W + 0.5;
+    const int pitch4 = W * 4;
+    double v[8], h[8], rd[8];
+    if (KIND == 0 || KIND == 2) {
+        const double cx = m[2] * y, cy = m[3] * y;                         // :1383-1384
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double x = (double)(c0 + lane + k * 64 + fd.x_off);
+            if (KIND == 0) {                                               // f32-valued matrix: exact product, fma == mul then add
+                v[2 * k] = fma(m[0], x, cx) + m[4];
+                v[2 * k + 1] = fma(m[1], x, cy) + m[5];
+            } else {                                                       // arbitrary doubles: keep both roundings
+                v[2 * k] = ((m[0] * x) + cx) + m[4];
+                v[2 * k + 1] = ((m[1] * x) + cy) + m[5];
+            }
+        }
+    } else {
+        const double ax = m[1] * y, ay = m[4] * y, ad = m[7] * y;          // :1402-1403
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double x = (double)(c0 + lane + k * 64 + fd.x_off);
+            const double den = ((m[6] * x) + ad) + 1.0;
+            v[2 * k] = (((m[0] * x) + ax) + m[2]) / den;
+            v[2 * k + 1] = (((m[3] * x) + ay) + m[5]) / den;
+        }
+    }
+    round_x8(v, h, rd);
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool inb = (int)(h[2 * k] >= 0.5) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= 0.5);     // :1001 (NaN fails; sy < H via the range check)
+        const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2)); // :1005
+        px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[k], dst, (c0 + lane + k * 64) * 4, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------ forward (scatter) paths
@@ -652,11 +739,15 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const int rpx = (fr.max_obj_h + 7) / 8;
     dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;      // experiments only
+    static const int nb = getenv("HG_NB") ? atoi(getenv("HG_NB")) : 1;
     switch (abl) {
-    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    default:
+        if (nb == 2) hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, 2>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx);
+        else         hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx);
+        break;
     }
 }
 
@@ -686,11 +777,18 @@ void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream
     hipLaunchKernelGGL(k_map_to_i16, dim3(blocks), dim3(256), 0, stream, map32, map16, n);
 }
 
-void launch_geo(int kind, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
+void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
                 const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream)
 {
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     dim3 grid((max_w + 255) / 256, (max_h + 3) / 4, n_frames);
+    const bool fast = ((int64_t)H + 2) * W * 4 < ((int64_t)1 << 31) && W < (1 << 21) && H < (1 << 22) && max_w < (1 << 28);
+    if (fast) {
+        if (kind == 1)      hipLaunchKernelGGL(k_geo_fast<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+        else if (f32_exact) hipLaunchKernelGGL(k_geo_fast<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+        else                hipLaunchKernelGGL(k_geo_fast<2>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+        return;
+    }
     if (kind == 0) hipLaunchKernelGGL(k_geo<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
     else           hipLaunchKernelGGL(k_geo<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
 }

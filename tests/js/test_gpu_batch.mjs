@@ -1,0 +1,48 @@
+// GPU: warpBatch() (the setDestinyPoints+warp loop as one pass) equals per-frame warp(…, applyAlwaysInverse = true),
+// repeated warps on one instance, mutation of the caller's image buffer is seen by the next warp (the reference aliases it).
+import crypto from 'crypto';
+import { Homography } from '../../homography.js_amd/js/Homography.mjs';
+import { gridTriangles } from '../../homography.js_amd/js/delaunay.mjs';
+
+const fails = [];
+const ok = (c, m) => { if (!c) fails.push(m); };
+const sha = (t) => crypto.createHash('sha256').update(Buffer.from(t.buffer, t.byteOffset, t.byteLength)).digest('hex');
+function lcgImage(w, h, seed) {
+    const data = new Uint8ClampedArray(w * h * 4);
+    let s = seed >>> 0;
+    for (let i = 0; i < data.length; i++) { s = (Math.imul(s, 1664525) + 1013904223) >>> 0; data[i] = s >>> 24; }
+    return { data, width: w, height: h };
+}
+const W = 512, H = 288, nx = 8, ny = 6, A = 9;
+const src = [], sets = [];
+for (let j = 0; j <= ny; j++) for (let i = 0; i <= nx; i++) src.push([i * W / nx, j * H / ny]);
+for (let f = 0; f < 5; f++) sets.push(src.map(([x, y]) => [x * (1 + 0.1 * f), A + y + Math.sin(((8 + f) * x) / Math.PI) * A]));
+const img = lcgImage(W, H, 21);
+Homography.triangulate = () => gridTriangles(nx, ny);
+const h = new Homography('piecewiseaffine');
+h.setSourcePoints(src, img, W, H, false);
+const single = sets.map((d) => { h.setDestinyPoints(d, false); return h.warp(null, false, true); });
+const batch = h.warpBatch(sets);
+ok(batch.length === sets.length, 'batch length');
+batch.forEach((b, f) => {
+    ok(b.width === single[f].width && b.height === single[f].height, `frame ${f} size`);
+    ok(sha(b.data) === sha(single[f].data), `frame ${f} differs between warpBatch and warp`);
+    ok(b.data instanceof Uint8ClampedArray && b.data.length === 4 * b.width * b.height, `frame ${f} type`);
+});
+// the caller mutates its buffer in place: the next warp must see it (reference re-reads image.data every warp, :298)
+h.setDestinyPoints(sets[0], false);
+const before = sha(h.warp(null, false, true).data);
+img.data.fill(7);
+const after = h.warp(null, false, true);
+ok(sha(after.data) !== before, 'mutated source buffer was not picked up');
+ok(after.data.every((v) => v === 7 || v === 0), 'mutated source: output should only hold 7 or 0');
+// affine + projective on the same instance type, output identical across repeated calls
+const g = new Homography('projective');
+g.setReferencePoints([[0, 0], [0, 1], [1, 0], [1, 1]], [[1 / 10, 1 / 2], [0, 1], [9 / 10, 1 / 2], [1, 1]]);
+const img2 = lcgImage(400, 400, 1);
+const o1 = g.warp(img2), o2 = g.warp();
+ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'projective repeat');
+h.close(); g.close();
+ok((() => { try { h.warp(); return true; } catch (e) { return false; } })(), 'warp after close() re-creates the context');
+console.log(JSON.stringify({ failures: fails }));
+process.exit(fails.length ? 1 : 0);

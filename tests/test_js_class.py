@@ -54,3 +54,9 @@ def test_full_replay_on_gpu_matches_reference_hashes():
     rc, res = _node("replay_golden.mjs", timeout=1500)
     assert res["failures"] == [] and rc == 0
     assert res["mode"] == "gpu" and res["warps"] >= 83
+
+
+@pytest.mark.gpu
+def test_batch_and_buffer_aliasing_on_gpu():
+    rc, res = _node("test_gpu_batch.mjs", timeout=600)
+    assert res["failures"] == [] and rc == 0
