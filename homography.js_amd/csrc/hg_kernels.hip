@@ -345,7 +345,7 @@ __device__ __forceinline__ bool in_range_bits(double h, int64_t lo_bits, uint64_
     return (uint64_t)(__double_as_longlong(h) - lo_bits) < extent_bits;
 }
 
-template <int CAP, int ABL, int NB>
+template <int CAP, int ABL>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int rows_per_xcd)
 {
@@ -461,21 +461,15 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
         }
     };
 
-    // Two windows per iteration, straight-line on each path: the gathers of window A are in flight while window B is
-    // resolved (hipcc's waitcnt insertion is exact inside a basic block; across merges it drains everything).
-    for (int w = wave; w < nwin; w += 4 * NB) {
-        int bestA[4], bestB[4];
-        uint32_t offA[4], offB[4], pxA[4], pxB[4];
-        resolve(w, bestA, offA);
-        gather(offA, pxA);
-        if (NB > 1 && w + 4 < nwin) {
-            resolve(w + 4, bestB, offB);
-            gather(offB, pxB);
-            emit(w, pxA, bestA);
-            emit(w + 4, pxB, bestB);
-        } else {
-            emit(w, pxA, bestA);
-        }
+    // One window per iteration.  Measured alternatives: two windows in flight per wave (74 VGPRs, 6
+    // waves/SIMD) and a phased variant (4 windows resolved, then 16 gathers, then 16 stores) are both ~4 % slower: with
+    // 8 waves/SIMD the other waves already cover a window's memory latency, and reads + writes together run at ~5.2 TB/s.
+    for (int w = wave; w < nwin; w += 4) {
+        int best[4];
+        uint32_t off[4], px[4];
+        resolve(w, best, off);
+        gather(off, px);
+        emit(w, px, best);
     }
 }
 
@@ -739,15 +733,11 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const int rpx = (fr.max_obj_h + 7) / 8;
     dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;      // experiments only
-    static const int nb = getenv("HG_NB") ? atoi(getenv("HG_NB")) : 1;
     switch (abl) {
-    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    default:
-        if (nb == 2) hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, 2>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx);
-        else         hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx);
-        break;
+    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
     }
 }
 

@@ -33,6 +33,11 @@ def test_host_side_javascript():
     assert res["failures"] == [] and rc == 0
 
 
+def test_png_codec_on_reference_fixture():
+    rc, res = _node("test_png.mjs")
+    assert res["failures"] == [] and rc == 0
+
+
 def test_warp_without_gpu_throws_a_string():
     import torch
     if torch.cuda.is_available():
@@ -59,4 +64,11 @@ def test_full_replay_on_gpu_matches_reference_hashes():
 @pytest.mark.gpu
 def test_batch_and_buffer_aliasing_on_gpu():
     rc, res = _node("test_gpu_batch.mjs", timeout=600)
+    assert res["failures"] == [] and rc == 0
+
+
+@pytest.mark.gpu
+def test_reference_known_answer_png_through_js_class_on_gpu():
+    """test/nodeTest.js flow on the reference's own input PNG == the reference's own expected output PNG, byte for byte."""
+    rc, res = _node("test_png.mjs", "--gpu", timeout=600)
     assert res["failures"] == [] and rc == 0
