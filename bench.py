@@ -208,7 +208,21 @@ def main():
         cpu = {"value": round(px_done / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
                "sample": f"{n_done} frames of the same workload through oracle/hg_oracle.c (C restatement of the reference's JS loops, "
                          f"gcc -O2, single thread) in {dt:.1f} s; the reference itself is single-threaded JavaScript "
-                         f"(24.3 Mpix/s on C3 under Node 12, BASELINE.md §2)"}
+                         f"(24.3 Mpix/s on C3 under Node 12, BASELINE.md \u00a72)"}
+        # the same algorithm as plain JavaScript under this box's Node (what the reference's own loops achieve here)
+        if piecewise and args.config in ("C3", "C5"):
+            import shutil
+            import subprocess
+            node = shutil.which("node")
+            if node:
+                try:
+                    p = subprocess.run([node, os.path.join(ROOT, "oracle", "hg_oracle_js.mjs"), "bench", args.config, "8"],
+                                       capture_output=True, text=True, timeout=120)
+                    j = json.loads(p.stdout.strip().splitlines()[-1])
+                    cpu["node"] = {"value": j["mpix_per_s"], "unit": "Mpixels/s", "cores": 1, "node": j["node"],
+                                   "sample": f"{j['frames']} frames in {j['seconds']} s through oracle/hg_oracle_js.mjs (JS restatement, pinned to the goldens)"}
+                except Exception as e:                      # noqa: BLE001 - the baseline is informative only
+                    cpu["node"] = {"error": str(e)[:200]}
 
     if rank == 0:
         line = {"metric": "Mpixels/s warped (piecewise-affine, 4K RGBA)" if args.config == "C3" else f"Mpixels/s warped ({args.config})",

@@ -166,3 +166,17 @@ def test_known_answer_png_pair():
     out = O.warp_inverse_geometric(1, inv, src, xo, yo, ow, oh)
     assert out.shape == want.shape
     assert np.array_equal(out, want), f"{np.count_nonzero(np.any(out != want, axis=2))} of {ow * oh} pixels differ"
+
+
+def test_js_oracle_pinned_to_goldens():
+    """oracle/hg_oracle_js.mjs (used only to time the algorithm under Node next to the GPU numbers) reproduces the goldens."""
+    import json
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node missing")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([node, os.path.join(root, "oracle", "hg_oracle_js.mjs"), "check"], capture_output=True, text=True, timeout=600)
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["failures"] == [] and res["checked"] >= 30 and p.returncode == 0
