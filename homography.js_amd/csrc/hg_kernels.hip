@@ -350,7 +350,26 @@ __device__ __forceinline__ bool in_range_bits(double h, int64_t lo_bits, uint64_
     return (uint64_t)(__double_as_longlong(h) - lo_bits) < extent_bits;
 }
 
-template <int CAP, int ABL>
+// best[k] = max(best[k], key) for the pixels k = 0..3 (at d + 64k relative to the span start) that lie inside the span,
+// i.e. (unsigned)(d + 64k) < len.  Two VALU instructions per pixel: the compare writes EXEC directly (v_cmpx) and the
+// max runs under it; a compare + select + max sequence (what the compiler emits) needs three.  All 64 lanes are active
+// here (uniform control flow, 256-thread blocks), EXEC is restored from the saved copy after every pixel.
+__device__ __forceinline__ void span_max4(int best[4], int d, int len, int key)
+{
+    const int d1 = d + 64, d2 = d + 128, d3 = d + 192;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d0], %[len]\n\t" "v_max_i32_e32 %[b0], %[b0], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d1], %[len]\n\t" "v_max_i32_e32 %[b1], %[b1], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d2], %[len]\n\t" "v_max_i32_e32 %[b2], %[b2], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d3], %[len]\n\t" "v_max_i32_e32 %[b3], %[b3], %[key]\n\t" "s_mov_b64 exec, %[sv]"
+        : [b0] "+v"(best[0]), [b1] "+v"(best[1]), [b2] "+v"(best[2]), [b3] "+v"(best[3]), [sv] "=&s"(sv)
+        : [d0] "v"(d), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [len] "v"(len), [key] "v"(key)
+        : "vcc");
+}
+
+template <int CAP, int ABL, bool MAP>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int rows_per_xcd)
 {
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     if (r >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_m[CAP * 6];
-    __shared__ int s_lo[CAP], s_hi[CAP], s_id[CAP];
+    __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, id << 8 | slot
 
     const int W = fd.obj_w;
     const int64_t row0 = (int64_t)r * W;
@@ -380,7 +399,8 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const uint4 a = reinterpret_cast<const uint4 *>(ent + i)[0];
         const uint4 b = reinterpret_cast<const uint4 *>(ent + i)[1];
-        s_lo[i] = (int)(a.x & 0xffffu); s_hi[i] = (int)(a.x >> 16); s_id[i] = (int)a.y;
+        const int elo = (int)(a.x & 0xffffu), ehi = (int)(a.x >> 16);
+        s_lo[i] = elo; s_hi[i] = ehi; s_len[i] = ehi - elo; s_key[i] = ((int)a.y << 8) | i;
         const double m0 = (double)__uint_as_float(a.z), m1 = (double)__uint_as_float(a.w), m2 = (double)__uint_as_float(b.x),
                      m3 = (double)__uint_as_float(b.y), m4 = (double)__uint_as_float(b.z), m5 = (double)__uint_as_float(b.w);
         double2 *mrec = reinterpret_cast<double2 *>(s_m + i * 6);
@@ -421,13 +441,8 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
                 const int bit = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const int slot = j + bit;
-                const int sl = s_lo[slot];
-                const unsigned span = (unsigned)(s_hi[slot] - sl);
-                const int key = (s_id[slot] << 8) | slot;   // larger id wins (== last writer of :852-858); its slot rides along
-                const int d = cq - sl;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if ((unsigned)(d + k * 64) < span) best[k] = max(best[k], key);
+                const int d = cq - s_lo[slot];
+                span_max4(best, d, s_len[slot], s_key[slot]);   // larger id wins (== last writer of :852-858); its slot rides along
             }
         }
         double v[8], h[8], rd[8];
@@ -460,7 +475,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
 #pragma unroll
             for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[k], dst, (cq + k * 64) * 4, 0, kStoreNT);
         }
-        if (map_out) {
+        if (MAP) {                                          // parity tap (hg_get_tri_map_fused): a separate instantiation
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (cq + k * 64 < W) map_out[fd.map_off + row0 + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> 8);
@@ -738,14 +753,15 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
     const int rpx = (fr.max_obj_h + 7) / 8;
     dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
+    if (map_out) { hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); return; }
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;      // experiments only
     switch (abl) {
-    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
     }
 }
 
