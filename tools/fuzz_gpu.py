@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""One-off wide fuzz of the HIP path against the CPU oracle (run on the GPU box): tools/fuzz_gpu.py [trials] [seed]."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from hgtest import golden as G, hip, oracle as O, workloads as WL  # noqa: E402
+
+HG = hip.load()
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = HG.Context(0)
+bad = 0
+overflow = 0
+for t in range(trials):
+    W, H = int(rng.integers(8, 700)), int(rng.integers(8, 400))
+    img = G.lcg_image(W, H, 9000 + t)
+    nx, ny = int(rng.integers(1, 24)), int(rng.integers(1, 16))
+    sp = WL.grid_points(W, H, nx, ny).reshape(-1, 2).astype(np.float64)
+    tris = WL.grid_triangles(nx, ny)
+    mode = t % 6
+    if mode == 1:
+        sp = sp * rng.uniform(0.3, 0.9) + rng.uniform(0, 0.3) * np.array([W, H])        # minSrc > 0
+    elif mode == 2:
+        sp = sp * 1.3 - np.array([W, H]) * 0.15                                            # minSrc < 0 (general kernel)
+    jit = rng.uniform(0, 0.45)
+    dp = (sp + rng.uniform(-jit, jit, sp.shape) * [W / nx, H / ny]) * rng.uniform(0.3, 3.0, 2) + rng.uniform(-80, 120, 2)
+    if mode == 3:
+        dp[:, 1] += np.sin(dp[:, 0] * 0.37) * rng.uniform(1, 40)                            # steep shear
+    if mode == 4:
+        dp = np.round(dp * 2) / 2                                                           # .0 / .5 vertices (ties)
+    if mode == 5:
+        perm = rng.permutation(tris.size // 3)                                              # shuffled triangle order + a fold
+        tris = tris.reshape(-1, 3)[perm].ravel()
+        dp[rng.integers(0, dp.shape[0])] += rng.uniform(-60, 60, 2)
+    sp32, dp32 = sp.astype(np.float32).ravel(), dp.astype(np.float32).ravel()
+    ms, md = O.minmax_xy(sp32), O.minmax_xy(dp32)
+    geom = (int(md[0]), int(md[1]), int(md[2] - md[0]), int(md[3] - md[1]))
+    if geom[2] <= 0 or geom[3] <= 0 or geom[2] * geom[3] > 6_000_000:
+        continue
+    want, wmap, wfwd, winv = O.warp_inverse_piecewise(sp32, dp32, tris, img, int(ms[0]), int(ms[1]), *geom, taps=True)
+    ctx.set_image(img)
+    ctx.piecewise_set_mesh(sp32, tris, int(ms[0]), int(ms[1]))
+    ctx.piecewise_prepare(dp32, geom)
+    got = ctx.warp_inverse_piecewise()
+    ok = np.array_equal(got, want) and np.array_equal(ctx.get_tri_map(), wmap)
+    try:
+        ok = ok and np.array_equal(ctx.get_tri_map(fused=True), wmap)
+    except HG.HgError:
+        overflow += 1          # more spans in a row than the fused kernel's LDS list: the warp itself went through the map path
+    # geometric kernels on the same image
+    d4 = (WL.corners(W, H).reshape(4, 2) * rng.uniform(0.4, 2.0, 2) + rng.uniform(-0.2, 0.2, (4, 2)) * [W, H] + rng.uniform(-50, 50, 2)).astype(np.float32).ravel()
+    s4 = WL.corners(W, H)
+    fw = O.projective_from_squares(s4, d4)
+    lim = O.transform_limits(1, fw, W, H)
+    if np.all(np.isfinite(lim)) and 0 < lim[2] * lim[3] < 6_000_000:
+        lim = [int(v) for v in lim]
+        inv = O.projective_from_squares(d4, s4)
+        ok = ok and np.array_equal(ctx.warp_inverse_geometric(1, HG.solve_projective(d4, s4), lim), O.warp_inverse_geometric(1, inv, img, *lim))
+    fa = O.affine_from_triangles(s4[:6], d4[:6]).astype(np.float64)
+    lim = O.transform_limits(0, fa, W, H)
+    if np.all(np.isfinite(lim)) and 0 < lim[2] * lim[3] < 6_000_000:
+        lim = [int(v) for v in lim]
+        ia = O.affine_from_triangles(d4[:6], s4[:6]).astype(np.float64)
+        ok = ok and np.array_equal(ctx.warp_inverse_geometric(0, ia, lim), O.warp_inverse_geometric(0, ia, img, *lim))
+    if not ok:
+        bad += 1
+        print("MISMATCH trial", t, "mode", mode, W, H, nx, ny, geom, flush=True)
+print(f"fuzz done: {trials} trials, {bad} mismatches, {overflow} frames through the map-path fallback")
+sys.exit(1 if bad else 0)
