@@ -40,6 +40,7 @@ struct hg_ctx {
     float *d_fwd = nullptr; size_t fwd_cap = 0;
     float *d_inv = nullptr; size_t inv_cap = 0;
     int32_t *d_status = nullptr; size_t status_cap = 0;
+    int32_t *status_ptr = nullptr;                             // where this frame set's status words live (d_status, or the tail of d_rowcnt)
     int32_t *h_status = nullptr; size_t h_status_cap = 0;      // pinned
     bool pw_setup_done = false;                                // the per-triangle solves ran for the uploaded frames
     // fast path: per-output-row span lists
@@ -522,7 +523,7 @@ static PwFrames frames_of(const hg_ctx *c)
 {
     PwFrames f;
     f.frames = c->d_pw_frames; f.dst_pts = c->d_dst; f.trir = c->d_trir; f.segs = c->d_segs; f.fwd = c->d_fwd; f.inv = c->d_inv;
-    f.status = c->d_status; f.n_frames = (int)c->pw_frames.size();
+    f.status = c->status_ptr ? c->status_ptr : c->d_status; f.n_frames = (int)c->pw_frames.size();
     int mh = 0;
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     f.max_obj_h = mh;
@@ -544,18 +545,21 @@ static RowLists rows_of(const hg_ctx *c)
 static int run_setup(hg_ctx *c)
 {
     const size_t F = c->pw_frames.size();
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * F, c->stream));
     int mw = 0;
     for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
     c->pw_fast = pw_fast_ok(mesh_of(c), mw);
     if (c->pw_fast) {
         RowLists rl = rows_of(c);
-        HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, F * rl.row_stride));
+        // row counters and the per-frame status words share one allocation: one memset per step
+        HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, F * rl.row_stride + F));
         HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, F * (size_t)rl.row_stride * rl.cap));
         rl = rows_of(c);
-        HIP_TRY(c, hipMemsetAsync(c->d_rowcnt, 0, sizeof(int32_t) * F * rl.row_stride, c->stream));
+        c->status_ptr = c->d_rowcnt + F * rl.row_stride;
+        HIP_TRY(c, hipMemsetAsync(c->d_rowcnt, 0, sizeof(int32_t) * (F * rl.row_stride + F), c->stream));
         launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
     } else {
+        c->status_ptr = c->d_status;
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * F, c->stream));
         launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
     }
     HIP_TRY(c, hipGetLastError());
@@ -603,7 +607,7 @@ extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
     run_warp(c, static_cast<uint8_t *>(d_out), nullptr);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
     c->pw_status_pending = true;
     c->pw_last_out = static_cast<uint8_t *>(d_out);
     return HG_OK;
@@ -712,7 +716,7 @@ extern "C" int hg_get_tri_map_fused(hg_ctx *c, int16_t *out, size_t len)
     HG_TRY(run_setup(c));
     run_warp(c, c->d_out_tmp, c->d_map16);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->h_status[0] != FRAME_OK)
         return fail(c, HG_ERR_STATE, c->h_status[0] & FRAME_IRREGULAR ? "frame is irregular: the fused path defers it to the map path"
@@ -781,6 +785,7 @@ extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int
     const size_t zero = 0;
     if (n_map) {
         HG_TRY(hg_piecewise_set_frames(c, src_host.data(), &gmap, &zero, 1));
+        c->status_ptr = c->d_status;
         HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t), c->stream));
         launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
         HG_TRY(ensure(c, c->d_map32, c->map32_cap, n_map));
@@ -789,6 +794,7 @@ extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int
     }
     // (B) forward matrices of the real frame (:785-804), then scatter + gather
     HG_TRY(hg_piecewise_set_frames(c, dst_points, &geom, &zero, 1));
+    c->status_ptr = c->d_status;
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t), c->stream));
     launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
     c->pw_setup_done = false;
