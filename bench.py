@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=32, help="frames (destination point sets) per GPU per step")
-    ap.add_argument("--config", default="C3", choices=["C3", "C5", "C2"])
+    ap.add_argument("--config", default="C3", choices=["C3", "C5", "C2", "C5flat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
     args = ap.parse_args()

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
 //                :1047 through two round-toward-minus-infinity adds per coordinate (see round_x8), one buffer load whose
 //                hardware range check returns 0 outside the RGBA array (the JS `undefined` -> 0 case), coalesced stores.
 // Requirements checked by pw_fast_ok(): n_tris <= 32767 (ids == their Int16 value), obj_w <= 65535, source < 2^31 bytes,
-// min_src_x/y >= 0 (bounds test done on bit patterns of non-negative doubles).
+// min_src_x/y >= 0 (so that the upper y bound can be left to the buffer range check).
 
 __device__ __forceinline__ uint32_t dlo(double v) { return (uint32_t)__double2loint(v); }
 
@@ -341,13 +341,6 @@ __device__ __forceinline__ void round_x8(const double v[8], double h[8], double 
         : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7]),
           "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "s"(M));
-}
-
-// lo <= h < hi for doubles with 0 < lo < hi, on the bit patterns (monotonic for non-negative doubles; a negative h has
-// the sign bit set and a NaN an all-ones exponent: both fall outside).
-__device__ __forceinline__ bool in_range_bits(double h, int64_t lo_bits, uint64_t extent_bits)
-{
-    return (uint64_t)(__double_as_longlong(h) - lo_bits) < extent_bits;
 }
 
 // best[k] = max(best[k], key) for the pixels k = 0..3 (at d + 64k relative to the span start) that lie inside the span,
