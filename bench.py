@@ -8,7 +8,7 @@ does what the reference redoes per frame (`setDestinyPoints(dst_f); warp()`): pe
 triangle spans (k_tri_spans) and the inverse piecewise warp (k_pw_rows, the dominant kernel).  Inputs (source RGBA, meshes, destination points) are
 resident in HBM before the timed region; outputs stay in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config C3|C5|C2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config C3|C4|C5|C2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Multi-GPU: frames shard across ranks (independent units, weak scaling: F frames per GPU); the only exchange is the
@@ -57,10 +57,10 @@ def _pmc_traffic(config, frames, piecewise):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=32, help="frames (destination point sets) per GPU per step")
-    ap.add_argument("--config", default="C3", choices=["C3", "C5", "C2", "C5flat"])
+    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C5", "C2", "C5flat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
     args = ap.parse_args()
@@ -100,18 +100,26 @@ def main():
     ctx = hg.Context(local_rank, stream=stream.cuda_stream)
     ctx.set_image_device(img_t.data_ptr(), W, H)
 
-    piecewise = cfg["kind"] == "piecewise"
+    piecewise = cfg["kind"] in ("piecewise", "face")
     if piecewise:
-        sp, tris, frames, geoms = wl.piecewise_frames(cfg, F)
         # different ranks get different frames of the same sequence (frame index = rank*F + f)
-        frames = [wl.sin_dst(sp, cfg["A"], 8 + ((rank * F + f) % 4)) for f in range(F)]
+        if cfg["kind"] == "face":
+            sp = wl.face_mesh(W, H, cfg["landmarks"])
+            tris = hg.triangulate(sp)                                  # host Delaunay, where the reference calls Delaunator
+            seq = wl.face_frames(sp, W, cfg["total_frames"])
+            frames = [seq[(rank * F + f) % len(seq)] for f in range(F)]
+            mesh_txt = f"{cfg['landmarks']}-landmark face mesh"
+        else:
+            sp, tris = wl.grid_points(W, H, cfg["nx"], cfg["ny"]), wl.grid_triangles(cfg["nx"], cfg["ny"])
+            frames = [wl.sin_dst(sp, cfg["A"], 8 + ((rank * F + f) % 4)) for f in range(F)]
+            mesh_txt = f"{cfg['nx']}x{cfg['ny']}-cell sinusoidal grid"
         geoms = [wl.piecewise_geom(d) for d in frames]
         msx, msy = wl.src_min(sp)
         ctx.piecewise_set_mesh(sp, tris, msx, msy)
         offs, total = hg.pack_offsets(geoms)
         ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
         run = ctx.warp_inverse_piecewise_frames_device
-        workload = (f"{args.config}: {W}x{H} RGBA piecewise-affine, {cfg['nx']}x{cfg['ny']}-cell sinusoidal grid "
+        workload = (f"{args.config}: {W}x{H} RGBA piecewise-affine, {mesh_txt} "
                     f"({tris.size // 3} triangles), {F} frames/GPU/step on a shared source")
     else:
         s4 = wl.corners(W, H)
@@ -209,6 +217,25 @@ def main():
                "sample": f"{n_done} frames of the same workload through oracle/hg_oracle.c (C restatement of the reference's JS loops, "
                          f"gcc -O2, single thread) in {dt:.1f} s; the reference itself is single-threaded JavaScript "
                          f"(24.3 Mpix/s on C3 under Node 12, BASELINE.md \u00a72)"}
+        # the same C restatement on every host core: one frame per thread (ctypes releases the GIL), ~6 s sample
+        if piecewise:
+            from concurrent.futures import ThreadPoolExecutor
+            cores = os.cpu_count() or 1
+            per_thread = max(1, int(6.0 / max(dt / n_done, 1e-3)))
+
+            def _work(k):
+                done = 0
+                for j in range(per_thread):
+                    f = (k + j) % F
+                    O.warp_inverse_piecewise(sp, frames[f], tris, img, msx, msy, *geoms[f])
+                    done += n_out[f]
+                return done
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                px_mt = sum(ex.map(_work, range(cores)))
+            dt_mt = time.perf_counter() - t1
+            cpu["all_cores"] = {"value": round(px_mt / dt_mt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                                "sample": f"{cores} threads x {per_thread} frames (one frame per thread at a time) in {dt_mt:.1f} s"}
         # the same algorithm as plain JavaScript under this box's Node (what the reference's own loops achieve here)
         if piecewise and args.config in ("C3", "C5"):
             import shutil

@@ -28,6 +28,7 @@ struct hg_ctx {
     // mesh (source side)
     float *d_src = nullptr; size_t src_cap = 0;
     uint32_t *d_tris = nullptr; size_t tris_cap = 0;
+    std::vector<uint32_t> h_tris;                              // host copy (row-density estimate in hg_piecewise_set_frames)
     int n_pts = 0, n_tris = 0, min_src_x = 0, min_src_y = 0;
     bool have_mesh = false;
 
@@ -48,6 +49,7 @@ struct hg_ctx {
     RowEnt *d_rowent = nullptr; size_t rowent_cap = 0;
     int row_cap = 64;                                          // entries per row; grows (sticky) after an overflow
     bool pw_fast = false;                                      // uploaded frames are eligible for k_tri_spans/k_pw_rows
+    int pw_row_group = kRowGroup;                              // output rows per k_pw_rows workgroup (4, or 1 for dense meshes)
     bool pw_status_pending = false;                            // a fused run's status has not been checked yet
     uint8_t *pw_last_out = nullptr;
 
@@ -471,9 +473,44 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
     if (n_tris > 0) HIP_TRY(c, hipMemcpyAsync(c->d_tris, tris, sizeof(uint32_t) * 3 * n_tris, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_pts = n_pts; c->n_tris = n_tris; c->min_src_x = msx; c->min_src_y = msy;
+    c->h_tris.assign(tris, tris + (size_t)3 * n_tris);
     c->have_mesh = true;
     c->pw_frames.clear(); c->pw_setup_done = false;
     return HG_OK;
+}
+
+// Largest number of triangles whose fillTriangle row range (:1113-1120) covers one output row, over the uploaded frames:
+// an estimate of the longest per-row span list, used ONLY to pick k_pw_rows' layout (4 rows per workgroup with 64 LDS
+// slots each, or 1 row with all 256); the kernel checks the real counts and is exact either way.
+static int max_row_cover(const hg_ctx *c, const float *dst)
+{
+    int worst = 0;
+    std::vector<int> diff;
+    for (size_t f = 0; f < c->pw_frames.size(); f++) {
+        const FrameDesc &fd = c->pw_frames[f];
+        if (fd.obj_w <= 0 || fd.obj_h <= 0) continue;
+        const float *dp = dst + f * (size_t)c->n_pts * 2;
+        diff.assign((size_t)fd.obj_h + 2, 0);
+        for (int t = 0; t < c->n_tris; t++) {
+            double lo = INFINITY, hi = -INFINITY;
+            bool ok = true;
+            for (int k = 0; k < 3; k++) {
+                const uint32_t v = c->h_tris[3 * (size_t)t + k];
+                if (v >= (uint32_t)c->n_pts) { ok = false; break; }
+                const double y = dp[2 * (size_t)v + 1];
+                if (!(y == y)) { ok = false; break; }
+                lo = std::min(lo, y); hi = std::max(hi, y);
+            }
+            if (!ok) continue;
+            // rows [trunc(minY), ceil(maxY)) - yOff, one more below for spans that spill over the row end (x-offset quirk)
+            const double a = std::max(std::trunc(lo) - fd.y_off, 0.0), b = std::min(std::ceil(hi) - fd.y_off + 1.0, (double)fd.obj_h);
+            if (!(a < b)) continue;
+            diff[(size_t)a] += 1; diff[(size_t)b] -= 1;
+        }
+        int run = 0;
+        for (int r = 0; r < fd.obj_h; r++) { run += diff[r]; worst = std::max(worst, run); }
+    }
+    return worst;
 }
 
 extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n)
@@ -500,6 +537,7 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, c->pw_frames.data(), sizeof(FrameDesc) * F, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_dst, dst, sizeof(float) * 2 * c->n_pts * F, hipMemcpyHostToDevice, c->stream));
+    c->pw_row_group = max_row_cover(c, dst) <= 56 ? kRowGroup : 1;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pw_setup_done = false;
     return HG_OK;
@@ -527,6 +565,7 @@ static PwFrames frames_of(const hg_ctx *c)
     int mh = 0;
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     f.max_obj_h = mh;
+    f.row_group = c->pw_row_group;
     return f;
 }
 

@@ -28,6 +28,7 @@ enum : int32_t {
 
 constexpr int kRowSpanCap = 1024;   // spans per output row held in LDS by the general fused kernel (k_pw_fused)
 constexpr int kRowSpanCapFast = 256; // ... by the fast kernel (k_pw_rows), which also keeps a 48-byte matrix per span
+constexpr int kRowGroup = 4;            // output rows per k_pw_rows workgroup (64 LDS slots each in packed mode)
 constexpr int kInvStride = 8;       // floats per inverse matrix on the device (6 used; 32-byte rows)
 
 struct PwMesh {                     // source side of the mesh + source image (shared by all frames)
@@ -49,6 +50,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t *status;                // F
     int32_t n_frames;
     int32_t max_obj_h;              // max over frames (grid size)
+    int32_t row_group;              // output rows per k_pw_rows workgroup: kRowGroup (sparse rows) or 1 (dense meshes)
 };
 
 // Per-output-row span lists of the fast path (k_tri_spans -> k_pw_rows), in global memory.

@@ -253,6 +253,11 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
 // min_src_x/y >= 0 (so that the upper y bound can be left to the buffer range check).
 
 __device__ __forceinline__ uint32_t dlo(double v) { return (uint32_t)__double2loint(v); }
+// a wave-uniform double moved to scalar registers (v_cmp_f64 takes it as its scalar operand): frees two VGPRs each
+__device__ __forceinline__ double sgpr_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // Output pixels are written once and never re-read by these kernels: non-temporal stores (aux bit 1 = nt) keep the
 // 34 MB-per-frame output stream from displacing the shared source image in L2 / Infinity Cache (measured -13 % kernel
@@ -324,23 +329,24 @@ __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
     }
 }
 
-// For 8 doubles: h[i] = RTN(v[i] + 0.5), r[i] = RTN(h[i] + M), M = 1.5 * 2^52, with the fp64 rounding mode switched to
-// round-toward-minus-infinity for exactly these 16 adds.  floor(h) == floor(v + 0.5 exactly) == Math.round(v) for every
-// finite double (RTN never crosses an integer upward; this also gets 0.49999999999999994 right), and it appears as the
-// low dword of r.  h itself serves the bounds test:  a <= v < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).
-__device__ __forceinline__ void round_x8(const double v[8], double h[8], double r[8])
+// For 8 doubles, in place: h[i] = RTN(h[i] + 0.5), then r[i] = RTN(h[i] + M), M = 1.5 * 2^52, with the fp64 rounding mode
+// switched to round-toward-minus-infinity for exactly these 16 adds.  floor(h) == floor(v + 0.5 exactly) == Math.round(v)
+// for every finite double (RTN never crosses an integer upward; this also gets 0.49999999999999994 right), and it appears
+// as the low dword of r.  h itself serves the bounds test:  a <= v < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).
+// (h is an in/out operand so that the 8 inputs and the 8 h share registers: 32 VGPRs for the block instead of 48.)
+__device__ __forceinline__ void round_x8(double h[8], double r[8])
 {
     const double M = 6755399441055744.0;
     asm volatile(
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
-        "v_add_f64 %0, %16, 0.5\n\t"  "v_add_f64 %1, %17, 0.5\n\t"  "v_add_f64 %2, %18, 0.5\n\t"  "v_add_f64 %3, %19, 0.5\n\t"
-        "v_add_f64 %4, %20, 0.5\n\t"  "v_add_f64 %5, %21, 0.5\n\t"  "v_add_f64 %6, %22, 0.5\n\t"  "v_add_f64 %7, %23, 0.5\n\t"
-        "v_add_f64 %8, %0, %24\n\t"   "v_add_f64 %9, %1, %24\n\t"   "v_add_f64 %10, %2, %24\n\t"  "v_add_f64 %11, %3, %24\n\t"
-        "v_add_f64 %12, %4, %24\n\t"  "v_add_f64 %13, %5, %24\n\t"  "v_add_f64 %14, %6, %24\n\t"  "v_add_f64 %15, %7, %24\n\t"
+        "v_add_f64 %0, %0, 0.5\n\t"  "v_add_f64 %1, %1, 0.5\n\t"  "v_add_f64 %2, %2, 0.5\n\t"  "v_add_f64 %3, %3, 0.5\n\t"
+        "v_add_f64 %4, %4, 0.5\n\t"  "v_add_f64 %5, %5, 0.5\n\t"  "v_add_f64 %6, %6, 0.5\n\t"  "v_add_f64 %7, %7, 0.5\n\t"
+        "v_add_f64 %8, %0, %16\n\t"  "v_add_f64 %9, %1, %16\n\t"  "v_add_f64 %10, %2, %16\n\t" "v_add_f64 %11, %3, %16\n\t"
+        "v_add_f64 %12, %4, %16\n\t" "v_add_f64 %13, %5, %16\n\t" "v_add_f64 %14, %6, %16\n\t" "v_add_f64 %15, %7, %16\n\t"
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
-        : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7]),
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]),
           "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
-        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "s"(M));
+        : "s"(M));
 }
 
 // best[k] = max(best[k], key) for the pixels k = 0..3 (at d + 64k relative to the span start) that lie inside the span,
@@ -364,126 +370,148 @@ __device__ __forceinline__ void span_max4(int best[4], int d, int len, int key)
 
 template <int CAP, int ABL, bool MAP>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
-                                                 int16_t *__restrict__ map_out, int rows_per_xcd)
+                                                 int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group)
 {
-    // 1-D grid decoded so that XCD x (= block id % 8, the observed dispatch order; speed only, never correctness) walks a
-    // contiguous band of rows of one frame: vertically adjacent output rows share source cache lines, which then stay in
-    // that XCD's L2 instead of being fetched by up to 8 of them.
+    // A workgroup owns rows_per_group consecutive output rows: kRowGroup = 4 when the host expects short span lists, 1
+    // for dense meshes (there, rows that share source lines should run side by side in different workgroups).  1-D grid decoded so that XCD x (= block id % 8, the observed
+    // dispatch order; speed only, never correctness) walks a contiguous band of rows of one frame: vertically adjacent
+    // output rows share source cache lines, which then stay in that XCD's L2 instead of being fetched by up to 8 of them.
     const int bid = blockIdx.x, xcd = bid & 7, bi = bid >> 3;
-    const int f = bi / rows_per_xcd;
-    const int r = xcd * rows_per_xcd + (bi - f * rows_per_xcd);
+    const int f = bi / groups_per_xcd;
+    const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * rows_per_group;
     const FrameDesc fd = fr.frames[f];
-    if (r >= fd.obj_h || fd.obj_w <= 0) return;
+    if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_m[CAP * 6];
     __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, id << 8 | slot
+    static_assert(CAP == 64 * kRowGroup, "packed mode gives each of the 4 rows a 64-slot block");
 
     const int W = fd.obj_w;
-    const int64_t row0 = (int64_t)r * W;
-    const double y = (double)(r + fd.y_off);
-
-    // ---- this row's spans -> LDS (slot CAP-1 is a NaN record that pixels without a triangle point at)
-    const int cnt = rl.cnt[(size_t)f * rl.row_stride + r];
-    if (cnt > rl.cap || cnt > CAP - 1) {
-        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
-        return;
-    }
-    const RowEnt *__restrict__ ent = rl.ent + ((size_t)f * rl.row_stride + r) * rl.cap;
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-        const uint4 a = reinterpret_cast<const uint4 *>(ent + i)[0];
-        const uint4 b = reinterpret_cast<const uint4 *>(ent + i)[1];
-        const int elo = (int)(a.x & 0xffffu), ehi = (int)(a.x >> 16);
-        s_lo[i] = elo; s_hi[i] = ehi; s_len[i] = ehi - elo; s_key[i] = ((int)a.y << 8) | i;
-        const double m0 = (double)__uint_as_float(a.z), m1 = (double)__uint_as_float(a.w), m2 = (double)__uint_as_float(b.x),
-                     m3 = (double)__uint_as_float(b.y), m4 = (double)__uint_as_float(b.z), m5 = (double)__uint_as_float(b.w);
-        double2 *mrec = reinterpret_cast<double2 *>(s_m + i * 6);
-        mrec[0] = make_double2(m0, m2 * y);
-        mrec[1] = make_double2(m4, m1);
-        mrec[2] = make_double2(m3 * y, m5);
-    }
-    if (threadIdx.x < 3) reinterpret_cast<double2 *>(s_m + (CAP - 1) * 6)[threadIdx.x] = make_double2(NAN, NAN);
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: the window loop runs on the scalar unit
     const int nwin = (W + 255) >> 8;
+    const int nrows = min(rows_per_group, fd.obj_h - r0);
+
+    // ---- span counts of the group's rows.  Packed mode (every row has at most 63 spans: the common case): all four
+    // lists are loaded at once, one barrier, then wave j walks row r0 + j alone -- the list-load latency is paid once per
+    // four rows and a row's span scan is a single ballot.  Otherwise the rows are taken one after the other with the
+    // whole LDS (up to CAP - 1 spans) and the windows of a row are dealt to the four waves.
+    const int *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    int cnts[kRowGroup], cmax = 0;
+#pragma unroll
+    for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
+    if (cmax > rl.cap || cmax > CAP - 1) {
+        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+        return;
+    }
+    const bool packed = rows_per_group == kRowGroup && __builtin_amdgcn_readfirstlane(cmax) <= 63;
+
     // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
-    // from the hardware range check == the JS `undefined` -> 0 of :1051.  Output row: raw buffer of 4*W bytes, so the
-    // ragged last window needs no per-pixel guard (stores past the row end are dropped by the same check).
+    // from the hardware range check == the JS `undefined` -> 0 of :1051.
     const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mesh.img), 0, mesh.W * mesh.H * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + row0 * 4, 0, W * 4, 0x00020000);
     // :1047 on h = RTN(s + 0.5):  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= hx < W + minSrcX + 0.5, and
     // minSrcY <= sy <=> minSrcY + 0.5 <= hy.  The upper y bound needs no test: round(sy) >= H puts the byte offset at or
     // beyond 4*W*H, which reads 0 exactly like the reference (it either fails :1047 or reads past the array).
-    const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
-    const double by_lo = (double)mesh.min_src_y + 0.5;
+    const double bx_lo = sgpr_f64((double)mesh.min_src_x + 0.5), bx_hi = sgpr_f64((double)mesh.W + (double)mesh.min_src_x + 0.5);
+    const double by_lo = sgpr_f64((double)mesh.min_src_y + 0.5);
     const int pitch4 = mesh.W * 4;
 
-    // One window up to (not including) its gathers: triangle per pixel, transform, round, bounds -> 4 source byte offsets.
-    auto resolve = [&](int w, int best[4], uint32_t off[4]) {
-        const int c0 = w << 8, cq = c0 + lane;              // lane l owns pixels c0 + l + 64k: every gather instruction covers
-#pragma unroll                                              // 64 consecutive pixels and every store instruction 256 contiguous bytes
-        for (int k = 0; k < 4; k++) best[k] = -1;
-        if (ABL & 8) { best[0] = best[1] = best[2] = best[3] = (w % (cnt > 0 ? cnt : 1)); }     // (experiments only) no triangle search
-        else for (int j = 0; j < cnt; j += 64) {
-            const int idx = j + lane;
-            int lo = 0x7fffffff, hi = 0;
-            if (idx < cnt) { lo = s_lo[idx]; hi = s_hi[idx]; }
-            unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
-            while (mask) {
-                const int bit = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int slot = j + bit;
-                const int d = cq - s_lo[slot];
-                span_max4(best, d, s_len[slot], s_key[slot]);   // larger id wins (== last writer of :852-858); its slot rides along
+    // row `row` of the group -> LDS slots [base, base + cnt) (+ a NaN record in slot base + nan_slot that pixels without a
+    // triangle point at); threads t0, t0 + step, ... of the caller's thread set do the copying
+    auto load_row = [&](int row, int cnt, int base, int nan_slot, int t0, int step) {
+        const double y = (double)(r0 + row + fd.y_off);
+        const RowEnt *__restrict__ ent = rl.ent + ((size_t)f * rl.row_stride + r0 + row) * rl.cap;
+        for (int i = t0; i < cnt; i += step) {
+            const uint4 a = reinterpret_cast<const uint4 *>(ent + i)[0];
+            const uint4 b = reinterpret_cast<const uint4 *>(ent + i)[1];
+            const int elo = (int)(a.x & 0xffffu), ehi = (int)(a.x >> 16);
+            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)a.y << 8) | i;
+            const double m0 = (double)__uint_as_float(a.z), m1 = (double)__uint_as_float(a.w), m2 = (double)__uint_as_float(b.x),
+                         m3 = (double)__uint_as_float(b.y), m4 = (double)__uint_as_float(b.z), m5 = (double)__uint_as_float(b.w);
+            double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
+            mrec[0] = make_double2(m0, m2 * y);              // {m0, m2*y, m4, m1, m3*y, m5}: m2*y and m3*y are the separately
+            mrec[1] = make_double2(m4, m1);                  // rounded products of :1383-1384
+            mrec[2] = make_double2(m3 * y, m5);
+        }
+        if (t0 < 3) reinterpret_cast<double2 *>(s_m + (base + nan_slot) * 6)[t0] = make_double2(NAN, NAN);
+    };
+
+    // All 256-pixel windows w0, w0 + wstep, ... of one row whose spans sit in LDS slots [base, base + cnt).
+    auto do_row = [&](int row, int cnt, int base, int smask, int w0, int wstep) {
+        const int r = r0 + row;
+        const int64_t row_px = (int64_t)r * W;
+        // Output row: raw buffer of 4*W bytes, so the ragged last window needs no per-pixel guard (stores past the row
+        // end are dropped by the hardware range check).
+        const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + row_px * 4, 0, W * 4, 0x00020000);
+        for (int w = w0; w < nwin; w += wstep) {
+            const int c0 = w << 8, cq = c0 + lane;          // lane l owns pixels c0 + l + 64k: every gather instruction covers
+            int best[4];                                    // 64 consecutive pixels and every store instruction 256 contiguous bytes
+            uint32_t px[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) best[k] = -1;
+            unsigned long long any = (ABL & 8) ? 1ull : 0ull;
+            if (ABL & 8) { best[0] = best[1] = best[2] = best[3] = (w % (cnt > 0 ? cnt : 1)); }     // (experiments only) no triangle search
+            else for (int j = 0; j < cnt; j += 64) {
+                const int idx = j + lane;
+                int lo = 0x7fffffff, hi = 0;
+                if (idx < cnt) { lo = s_lo[base + idx]; hi = s_hi[base + idx]; }
+                unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
+                any |= mask;
+                while (mask) {
+                    const int bit = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const int slot = base + j + bit;
+                    const int d = cq - s_lo[slot];
+                    span_max4(best, d, s_len[slot], s_key[slot]);   // larger id wins (== last writer of :852-858); its slot rides along
+                }
             }
-        }
-        double v[8], h[8], rd[8];
+            if (any == 0) px[0] = px[1] = px[2] = px[3] = 0u;       // no span of this row reaches the window (wave-uniform)
+            else {
+                double h[8], rd[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int slot = best[k] & (CAP - 1);           // -1 -> CAP-1: the NaN record
-            const double2 *mrec = reinterpret_cast<const double2 *>(s_m + slot * 6);
-            const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-            const double xd = (double)(cq + k * 64 + fd.x_off);
-            // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
-            // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
-            v[2 * k]     = fma(m0.x, xd, m0.y) + m1.x;
-            v[2 * k + 1] = fma(m1.y, xd, m2.x) + m2.y;
-        }
-        round_x8(v, h, rd);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t slot = (uint32_t)(best[k] & smask) | (uint32_t)base;      // -1 -> the NaN record (base is a multiple of 64)
+                    const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + __umul24(slot, 48u));
+                    const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+                    const double xd = (double)(cq + k * 64 + fd.x_off);
+                    // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
+                    // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
+                    h[2 * k]     = fma(m0.x, xd, m0.y) + m1.x;
+                    h[2 * k + 1] = fma(m1.y, xd, m2.x) + m2.y;
+                }
+                round_x8(h, rd);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo);   // NaN fails
-            const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
-            off[k] = inb ? o : 0xffffffffu;
-        }
-    };
-    auto gather = [&](const uint32_t off[4], uint32_t px[4]) {
+                for (int k = 0; k < 4; k++) {
+                    const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo);   // NaN fails
+                    const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
+                    const uint32_t off = inb ? o : 0xffffffffu;
+                    px[k] = (ABL & 2) ? off : __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0);       // outside the array -> 0
+                }
+            }
+            if (!(ABL & 4) || (px[0] ^ px[1] ^ px[2] ^ px[3]) == 0x9e3779b9u) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) px[k] = (ABL & 2) ? off[k] : __builtin_amdgcn_raw_buffer_load_b32(src, off[k], 0, 0);   // outside the array -> 0
-    };
-    auto emit = [&](int w, const uint32_t px[4], const int best[4]) {
-        const int cq = (w << 8) + lane;
-        if (!(ABL & 4) || (px[0] ^ px[1] ^ px[2] ^ px[3]) == 0x9e3779b9u) {
+                for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[k], dst, (cq + k * 64) * 4, 0, kStoreNT);
+            }
+            if (MAP) {                                      // parity tap (hg_get_tri_map_fused): a separate instantiation
 #pragma unroll
-            for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[k], dst, (cq + k * 64) * 4, 0, kStoreNT);
-        }
-        if (MAP) {                                          // parity tap (hg_get_tri_map_fused): a separate instantiation
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (cq + k * 64 < W) map_out[fd.map_off + row0 + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> 8);
+                for (int k = 0; k < 4; k++)
+                    if (cq + k * 64 < W) map_out[fd.map_off + row_px + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> 8);
+            }
         }
     };
 
-    // One window per iteration.  Measured alternatives: two windows in flight per wave (74 VGPRs, 6
+    // One window per wave iteration.  Measured alternatives: two windows in flight per wave (74 VGPRs, 6
     // waves/SIMD) and a phased variant (4 windows resolved, then 16 gathers, then 16 stores) are both ~4 % slower: with
     // 8 waves/SIMD the other waves already cover a window's memory latency, and reads + writes together run at ~5.2 TB/s.
-    for (int w = wave; w < nwin; w += 4) {
-        int best[4];
-        uint32_t off[4], px[4];
-        resolve(w, best, off);
-        gather(off, px);
-        emit(w, px, best);
+    const int npass = packed ? 1 : nrows;
+    for (int pass = 0; pass < npass; pass++) {
+        const int row = packed ? wave : pass;               // everything below is wave-uniform (scalar registers)
+        const int cnt = __builtin_amdgcn_readfirstlane(cnts[0] * (row == 0) + cnts[1] * (row == 1) + cnts[2] * (row == 2) + cnts[3] * (row == 3));
+        const int base = packed ? wave * 64 : 0, smask = packed ? 63 : CAP - 1;
+        load_row(row, cnt, base, smask, packed ? lane : (int)threadIdx.x, packed ? 64 : 256);
+        __syncthreads();
+        if (row < nrows) do_row(row, cnt, base, smask, packed ? 0 : wave, packed ? 1 : 4);
+        if (!packed) __syncthreads();                       // the next row overwrites the records
     }
 }
 
@@ -604,18 +632,18 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
     const double y = (double)(r + fd.y_off);
     const double bx_hi = (double)W + 0.5;
     const int pitch4 = W * 4;
-    double v[8], h[8], rd[8];
+    double h[8], rd[8];
     if (KIND == 0 || KIND == 2) {
         const double cx = m[2] * y, cy = m[3] * y;                         // :1383-1384
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const double x = (double)(c0 + lane + k * 64 + fd.x_off);
             if (KIND == 0) {                                               // f32-valued matrix: exact product, fma == mul then add
-                v[2 * k] = fma(m[0], x, cx) + m[4];
-                v[2 * k + 1] = fma(m[1], x, cy) + m[5];
+                h[2 * k] = fma(m[0], x, cx) + m[4];
+                h[2 * k + 1] = fma(m[1], x, cy) + m[5];
             } else {                                                       // arbitrary doubles: keep both roundings
-                v[2 * k] = ((m[0] * x) + cx) + m[4];
-                v[2 * k + 1] = ((m[1] * x) + cy) + m[5];
+                h[2 * k] = ((m[0] * x) + cx) + m[4];
+                h[2 * k + 1] = ((m[1] * x) + cy) + m[5];
             }
         }
     } else {
@@ -624,11 +652,11 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
         for (int k = 0; k < 4; k++) {
             const double x = (double)(c0 + lane + k * 64 + fd.x_off);
             const double den = ((m[6] * x) + ad) + 1.0;
-            v[2 * k] = (((m[0] * x) + ax) + m[2]) / den;
-            v[2 * k + 1] = (((m[3] * x) + ay) + m[5]) / den;
+            h[2 * k] = (((m[0] * x) + ax) + m[2]) / den;
+            h[2 * k + 1] = (((m[3] * x) + ay) + m[5]) / den;
         }
     }
-    round_x8(v, h, rd);
+    round_x8(h, rd);
     uint32_t px[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -744,17 +772,18 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, hipStream_t stream)
 {
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
-    const int rpx = (fr.max_obj_h + 7) / 8;
+    const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
+    const int rpx = ((fr.max_obj_h + rg - 1) / rg + 7) / 8;                     // row groups per XCD band
     dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
-    if (map_out) { hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); return; }
+    if (map_out) { hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); return; }
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;      // experiments only
     switch (abl) {
-    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
-    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx); break;
+    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
+    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
+    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
+    case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
+    case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
+    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
     }
 }
 

@@ -181,6 +181,19 @@ static napi_value fn_minmax_xy(napi_env env, napi_callback_info info)
     return r;
 }
 
+static napi_value fn_triangulate(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    size_t n;
+    float *p = (float *)get_typed(env, a[0], napi_float32_array, &n, "points"); if (!p) return NULL;
+    int count = 0;
+    HG_CALL(NULL, "hg_triangulate", hg_triangulate(p, (int)(n / 2), NULL, 0, &count));
+    void *out; napi_value r = make_typed(env, napi_uint32_array, (size_t)count * 3, 4, &out); if (!r) return NULL;
+    if (count) HG_CALL(NULL, "hg_triangulate", hg_triangulate(p, (int)(n / 2), (uint32_t *)out, count, &count));
+    return r;
+}
+
 /* ---------------------------------------------------------------- image + warps */
 static napi_value fn_set_image(napi_env env, napi_callback_info info)
 {
@@ -361,7 +374,7 @@ static napi_value init(napi_env env, napi_value exports)
     static const struct { const char *name; napi_callback fn; } fns[] = {
         { "create", fn_create }, { "destroy", fn_destroy }, { "deviceCount", fn_device_count },
         { "solveAffine", fn_solve_affine }, { "invertAffine", fn_invert_affine }, { "solveProjective", fn_solve_projective },
-        { "transformLimits", fn_transform_limits }, { "minmaxXY", fn_minmax_xy },
+        { "transformLimits", fn_transform_limits }, { "minmaxXY", fn_minmax_xy }, { "triangulate", fn_triangulate },
         { "setImage", fn_set_image }, { "warpInverseGeometric", fn_warp_inverse_geometric },
         { "piecewiseSetMesh", fn_piecewise_set_mesh }, { "piecewisePrepare", fn_piecewise_prepare },
         { "warpInversePiecewise", fn_warp_inverse_piecewise }, { "getTriMap", fn_get_tri_map }, { "getMatrices", fn_get_matrices },

@@ -23,6 +23,7 @@ EXPORTS = [
     "hg_version", "hg_device_count", "hg_create", "hg_create_on_stream", "hg_destroy", "hg_last_error", "hg_sync",
     "hg_device_alloc", "hg_device_free", "hg_copy_to_host",
     "hg_solve_affine", "hg_invert_affine", "hg_solve_projective", "hg_transform_limits", "hg_minmax_xy", "hg_js_round",
+    "hg_triangulate",
     "hg_set_image", "hg_set_image_device",
     "hg_warp_inverse_geometric", "hg_warp_inverse_geometric_device", "hg_geometric_set_frames",
     "hg_warp_inverse_geometric_frames_device", "hg_warp_inverse_geometric_batch_device", "hg_pack_offsets",
@@ -64,6 +65,7 @@ def lib():
         "hg_device_alloc": (i, [vp, sz, C.POINTER(vp)]), "hg_device_free": (i, [vp, vp]), "hg_copy_to_host": (i, [vp, vp, vp, sz]),
         "hg_solve_affine": (i, [f32p, f32p, f32p]), "hg_invert_affine": (i, [f32p, f32p]), "hg_solve_projective": (i, [f32p, f32p, f64p]),
         "hg_transform_limits": (i, [i, f64p, d, d, f64p]), "hg_minmax_xy": (i, [f32p, i, f64p]), "hg_js_round": (d, [d]),
+        "hg_triangulate": (i, [f32p, i, C.POINTER(C.c_uint32), i, C.POINTER(i)]),
         "hg_set_image": (i, [vp, u8p, i, i]), "hg_set_image_device": (i, [vp, vp, i, i]),
         "hg_warp_inverse_geometric": (i, [vp, i, f64p, Geom, u8p]), "hg_warp_inverse_geometric_device": (i, [vp, i, f64p, Geom, vp]),
         "hg_geometric_set_frames": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i]),
@@ -150,6 +152,16 @@ def minmax_xy(pts):
 
 def js_round(x):
     return lib().hg_js_round(float(x))
+
+
+def triangulate(pts):
+    """Delaunay triangles (uint32, 3 per triangle) of interleaved x,y points: where the reference calls Delaunator (:1216)."""
+    a, p = _f32(pts)
+    n = a.size // 2
+    out = np.empty(max(2 * n, 1) * 3, np.uint32)
+    cnt = C.c_int(0)
+    _check(lib().hg_triangulate(p, n, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size // 3, C.byref(cnt)))
+    return out[:3 * cnt.value].copy()
 
 
 def pack_offsets(geoms):

@@ -3,8 +3,8 @@
 //
 // Input: flat or nested x,y coordinates (any array / typed array).  Output: Uint32Array of vertex ids, 3 per triangle,
 // the same container type delaunator@5.0.0 returns.  The reference's dependency is NOT vendored in its tree, so this is
-// an independent implementation: it guarantees a valid Delaunay triangulation (empty circumcircles, cover = convex
-// hull), not the same triangle order or the same diagonal on co-circular quads (SURVEY.md §8c: triangulation parity is
+// an independent implementation (ghost-vertex Bowyer-Watson, so the convex hull is covered exactly): it guarantees a
+// valid Delaunay triangulation (empty circumcircles, cover = convex hull), not the same triangle order or the same diagonal on co-circular quads (SURVEY.md §8c: triangulation parity is
 // unpinned).  O(n^2) worst case: meant for meshes of up to a few thousand landmarks, once per source-point set.
 
 function orient(ax, ay, bx, by, cx, cy) { return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax); }
@@ -16,48 +16,63 @@ function inCircle(ax, ay, bx, by, cx, cy, dx, dy) {
     return adx * (bdy * cd - bd * cdy) - ady * (bdx * cd - bd * cdx) + ad * (bdx * cdy - bdy * cdx);
 }
 
+// "In circumcircle" for a triangle stored counter-clockwise; the vertex id `g` is the ghost vertex at infinity: the ghost
+// triangle (u, v, g) stands for the half-plane to the left of the hull edge u->v (plus the open segment u-v itself).
+function conflicts(X, Y, g, a, b, c, px, py) {
+    if (a !== g && b !== g && c !== g) return inCircle(X[a], Y[a], X[b], Y[b], X[c], Y[c], px, py) > 0;
+    const u = a === g ? b : (b === g ? c : a), v = a === g ? c : (b === g ? a : b);
+    const o = orient(X[u], Y[u], X[v], Y[v], px, py);
+    if (o !== 0) return o > 0;
+    return (px - X[u]) * (px - X[v]) + (py - Y[u]) * (py - Y[v]) < 0;
+}
+
 export function triangulate(points) {
     const flat = ArrayBuffer.isView(points) ? points : points.flat();
     const n = flat.length >> 1;
     if (n < 3) return new Uint32Array(0);
-    let minX = Infinity, minY = Infinity, maxX = -Infinity, maxY = -Infinity;
-    for (let i = 0; i < n; i++) {
-        const x = flat[2 * i], y = flat[2 * i + 1];
-        if (x < minX) minX = x; if (x > maxX) maxX = x; if (y < minY) minY = y; if (y > maxY) maxY = y;
-    }
-    const span = Math.max(maxX - minX, maxY - minY, 1e-9), cx = (minX + maxX) / 2, cy = (minY + maxY) / 2;
-    // vertex coordinates incl. a super-triangle (ids n, n+1, n+2) far outside the data
-    const X = new Float64Array(n + 3), Y = new Float64Array(n + 3);
+    const X = new Float64Array(n), Y = new Float64Array(n);
     for (let i = 0; i < n; i++) { X[i] = flat[2 * i]; Y[i] = flat[2 * i + 1]; }
-    const R = 64 * span;
-    X[n] = cx - R; Y[n] = cy - R; X[n + 1] = cx + R; Y[n + 1] = cy - R; X[n + 2] = cx; Y[n + 2] = cy + R;
-    let tris = [[n, n + 1, n + 2]];                      // counter-clockwise
-    // insert in x order (keeps the cavity search cheap enough and deterministic)
+    // insertion in x order (deterministic, keeps cavities small); exact duplicates are skipped
     const order = Array.from({ length: n }, (_, i) => i).sort((a, b) => (X[a] - X[b]) || (Y[a] - Y[b]) || (a - b));
+    // seed: the first two distinct points and the first point not collinear with them
+    const i0 = order[0];
+    let k1 = 1;
+    while (k1 < n && X[order[k1]] === X[i0] && Y[order[k1]] === Y[i0]) k1++;
+    if (k1 >= n) return new Uint32Array(0);
+    let i1 = order[k1], k2 = k1 + 1;
+    while (k2 < n && orient(X[i0], Y[i0], X[i1], Y[i1], X[order[k2]], Y[order[k2]]) === 0) k2++;
+    if (k2 >= n) return new Uint32Array(0);                                  // all points collinear
+    let i2 = order[k2];
+    if (orient(X[i0], Y[i0], X[i1], Y[i1], X[i2], Y[i2]) < 0) { const t = i1; i1 = i2; i2 = t; }
+    const g = n;                                                             // ghost vertex
+    let tris = [[i0, i1, i2], [i1, i0, g], [i2, i1, g], [i0, i2, g]];
     let prev = -1;
     for (const p of order) {
-        if (prev >= 0 && X[p] === X[prev] && Y[p] === Y[prev]) continue;    // exact duplicates are skipped
+        const dup = prev >= 0 && X[p] === X[prev] && Y[p] === Y[prev];
         prev = p;
+        if (dup || p === i0 || p === i1 || p === i2) continue;
         const px = X[p], py = Y[p];
         const keep = [], edges = new Map();
         for (const t of tris) {
             const [a, b, c] = t;
-            if (inCircle(X[a], Y[a], X[b], Y[b], X[c], Y[c], px, py) > 0) {
-                for (const [u, v] of [[a, b], [b, c], [c, a]]) {
+            if (conflicts(X, Y, g, a, b, c, px, py)) {
+                for (const [u, v] of [[a, b], [b, c], [c, a]]) {               // interior cavity edges cancel pairwise
                     const rev = v + ',' + u;
                     if (edges.has(rev)) edges.delete(rev); else edges.set(u + ',' + v, [u, v]);
                 }
             } else keep.push(t);
         }
         for (const [u, v] of edges.values()) {
-            if (orient(X[u], Y[u], X[v], Y[v], px, py) > 0) keep.push([u, v, p]);
-            else if (orient(X[u], Y[u], X[v], Y[v], px, py) < 0) keep.push([v, u, p]);
+            if (u === g || v === g) { keep.push([u, v, p]); continue; }      // new ghost triangle on the grown hull
+            const o = orient(X[u], Y[u], X[v], Y[v], px, py);
+            if (o > 0) keep.push([u, v, p]);
+            else if (o < 0) keep.push([v, u, p]);
             // collinear with the cavity edge: degenerate sliver, dropped
         }
         tris = keep;
     }
     const out = [];
-    for (const [a, b, c] of tris) if (a < n && b < n && c < n) out.push(a, b, c);
+    for (const [a, b, c] of tris) if (a !== g && b !== g && c !== g) out.push(a, b, c);
     return Uint32Array.from(out);
 }
 

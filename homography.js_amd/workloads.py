@@ -88,6 +88,8 @@ CONFIGS = {
     "C1": dict(kind="affine", W=400, H=400),
     "C2": dict(kind="projective", W=1920, H=1080),
     "C3": dict(kind="piecewise", W=3840, H=2160, nx=10, ny=10, A=40.0),
+    # 68-landmark face mesh, 512 frames in total; triangles from the host Delaunay (hg_triangulate)
+    "C4": dict(kind="face", W=3840, H=2160, landmarks=68, total_frames=512),
     "C5": dict(kind="piecewise", W=7680, H=4320, nx=50, ny=50, A=80.0),
     # experiment only: C5's mesh density without its steep shear
     "C5flat": dict(kind="piecewise", W=7680, H=4320, nx=50, ny=50, A=8.0),

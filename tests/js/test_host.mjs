@@ -1,6 +1,7 @@
 // Host-side (no GPU) checks of the drop-in class's JavaScript: own Delaunay triangulator, error behaviour, CSS export.
 import { triangulate, gridTriangles } from '../../homography.js_amd/js/delaunay.mjs';
 import { Homography } from '../../homography.js_amd/js/Homography.mjs';
+import { createRequire } from 'module';
 
 const fails = [];
 const ok = (c, m) => { if (!c) fails.push(m); };
@@ -48,6 +49,18 @@ for (let k = 0; k < 12; k++) {
     ok(gridTriangles(7, 5).length === 7 * 5 * 6, 'gridTriangles length');
     ok(triangulate(Float32Array.from([0, 0, 10, 0, 0, 10])).length === 3, 'typed-array input');
     ok(triangulate([[0, 0], [1, 1]]).length === 0, 'fewer than 3 points');
+}
+{   // the C-ABI triangulator (hg_triangulate, used by non-JS hosts) returns the same list, order included
+    const hg = createRequire(import.meta.url)('../../homography.js_amd/lib/hgwarp.node');
+    const r = rng(4242);
+    let same = true;
+    for (let k = 0; k < 60 && same; k++) {
+        const n = 3 + Math.floor(r() * 150), p = new Float32Array(2 * n);
+        for (let i = 0; i < 2 * n; i++) p[i] = k % 3 ? r() * 900 : Math.floor(r() * 9) * 25;      // every third set: lattice with duplicates
+        const a = triangulate(p), b = hg.triangulate(p);
+        same = a.length === b.length && a.every((v, i) => v === b[i]);
+    }
+    ok(same, 'hg_triangulate differs from js/delaunay.mjs');
 }
 {   // state-machine errors are bare strings, like the reference's throw("...")
     const expectThrow = (fn, part, tag) => { try { fn(); fails.push(`${tag}: did not throw`); } catch (e) { ok(typeof e === 'string' && e.includes(part), `${tag}: threw ${typeof e} ${e}`); } };

@@ -73,3 +73,51 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     with pytest.raises(HG.HgError) as e:
         HG.Context(0)
     assert "no CPU fallback" in str(e.value) or "device" in str(e.value)
+
+
+def _circumcircle_violations(P, tris):
+    P = P.astype(np.float64)
+    bad = 0
+    for a, b, c in tris.reshape(-1, 3):
+        A, B, Cc = P[a], P[b], P[c]
+        d = 2 * (A[0] * (B[1] - Cc[1]) + B[0] * (Cc[1] - A[1]) + Cc[0] * (A[1] - B[1]))
+        assert abs(d) > 1e-12, "degenerate triangle"
+        ux = ((A @ A) * (B[1] - Cc[1]) + (B @ B) * (Cc[1] - A[1]) + (Cc @ Cc) * (A[1] - B[1])) / d
+        uy = ((A @ A) * (Cc[0] - B[0]) + (B @ B) * (A[0] - Cc[0]) + (Cc @ Cc) * (B[0] - A[0])) / d
+        r2 = (A[0] - ux) ** 2 + (A[1] - uy) ** 2
+        d2 = (P[:, 0] - ux) ** 2 + (P[:, 1] - uy) ** 2
+        d2[[a, b, c]] = np.inf
+        bad += int((d2 < r2 * (1 - 1e-9)).sum())
+    return bad
+
+
+def test_triangulate_is_delaunay_and_matches_scipy_on_generic_points():
+    """hg_triangulate stands where the reference calls Delaunator (:1216).  No reference test pins the triangle order
+    (SURVEY.md §8c), so the bar is: valid Delaunay, and the same triangle SET as an independent implementation."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(5)
+    for n in (3, 4, 7, 68, 300):
+        P = (rng.random((n, 2)) * [1000, 700]).astype(np.float32)
+        t = HG.triangulate(P.ravel())
+        assert t.dtype == np.uint32 and t.size % 3 == 0 and t.size > 0
+        assert _circumcircle_violations(P, t) == 0
+        mine = {tuple(sorted(x)) for x in t.reshape(-1, 3).tolist()}
+        ref = {tuple(sorted(x)) for x in Delaunay(P.astype(np.float64)).simplices.tolist()}
+        assert mine == ref
+    assert HG.triangulate(np.array([0, 0, 1, 1], np.float32)).size == 0                 # fewer than 3 points
+    assert HG.triangulate(np.array([0, 0, 1, 1, 2, 2], np.float32)).size == 0           # collinear
+    with pytest.raises(HG.HgError):
+        HG.triangulate(np.array([0, 0, 1, np.nan, 2, 2], np.float32))
+
+
+def test_c4_face_mesh_workload():
+    """C4: 68 deterministic landmarks, own Delaunay (~120 triangles), rotating offsets per frame."""
+    from hgtest import workloads as WL
+    W, H = 3840, 2160
+    sp = WL.face_mesh(W, H)
+    tris = HG.triangulate(sp)
+    assert sp.size == 136 and 100 <= tris.size // 3 <= 130
+    assert _circumcircle_violations(sp.reshape(-1, 2), tris) == 0
+    frames = WL.face_frames(sp, W, 8)
+    assert len(frames) == 8 and all(f.dtype == np.float32 and f.size == 136 for f in frames)
+    assert np.abs(frames[0].reshape(-1, 2) - sp.reshape(-1, 2)).max() <= 0.02 * W + 1e-3

@@ -294,3 +294,33 @@ def test_full_size_configs_sha_and_properties(ctx, name):
         out2 = ctx.warp_inverse_geometric(1, HG.solve_projective(dp, sp), (w["xOff"], w["yOff"], w["objW"], w["objH"]))
     hit = solid[..., 3] == 255
     assert np.array_equal(out2[hit], out[hit] ^ 0x5A) and not out2[~hit].any()
+
+
+@pytest.mark.parametrize("W,H,F", [(480, 270, 16), (3840, 2160, 3)])
+def test_c4_face_mesh_batch_matches_oracle(ctx, W, H, F):
+    """C4: 68 landmarks triangulated by the host Delaunay (hg_triangulate), landmarks orbiting their rest
+    position; a small analogue over a quarter of the orbit and three frames at the full 4K size, against the oracle."""
+    img = G.lcg_image(W, H, 68)
+    sp = WL.face_mesh(W, H)
+    tris = HG.triangulate(sp)
+    assert 100 <= tris.size // 3 <= 130
+    seq = WL.face_frames(sp, W, 64 if W < 1000 else 512)
+    frames = [seq[(f * 5) % len(seq)] for f in range(F)]
+    geoms = [WL.piecewise_geom(d) for d in frames]
+    msx, msy = WL.src_min(sp)
+    ctx.set_image(img)
+    ctx.piecewise_set_mesh(sp, tris, msx, msy)
+    offs, total = HG.pack_offsets(geoms)
+    d_out = ctx.alloc(total)
+    try:
+        ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+        ctx.warp_inverse_piecewise_frames_device(d_out)
+        ctx.sync()
+        for f in range(F):
+            g = geoms[f]
+            got = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+            want = O.warp_inverse_piecewise(sp, frames[f], tris, img, msx, msy, *g)
+            assert np.array_equal(got, want), f
+            assert (got[..., 3] > 0).mean() > 0.5          # the mesh really covers most of its bounding box
+    finally:
+        ctx.free(d_out)
