@@ -57,8 +57,8 @@ def _pmc_traffic(config, frames, piecewise):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=32, help="frames (destination point sets) per GPU per step")
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "C5", "C2", "C5flat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,6 +158,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The GPU sat idle while the host counted N_hit: ~50 ms of the same work first, so that the W warmup steps and the
+    # timed region run at the sustained clocks (a 0.3 ms step is far shorter than the power-state ramp).  Untimed.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.05:
+        for _ in range(16):
+            run(d_out)
+        ctx.sync()
     for _ in range(args.warmup):
         run(d_out)
     ctx.sync()
@@ -193,7 +200,8 @@ def main():
                 "traffic": _pmc_traffic(args.config, F, piecewise), "kernel_ms": round(k_ms, 5), "launches_timed": k_launches,
                 "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
                 "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel; "
-                        "the shared 4K source stays in the 256 MiB Infinity Cache across frames, so HBM-side traffic is mostly the writes"}
+                        "source reads shared by neighbouring rows and frames hit in L2 / the 256 MiB Infinity Cache, so the measured "
+                        "fabric traffic is below the algorithmic bytes and the fraction can touch 1.0 without exceeding the memory system"}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample
     cpu = None
@@ -217,25 +225,27 @@ def main():
                "sample": f"{n_done} frames of the same workload through oracle/hg_oracle.c (C restatement of the reference's JS loops, "
                          f"gcc -O2, single thread) in {dt:.1f} s; the reference itself is single-threaded JavaScript "
                          f"(24.3 Mpix/s on C3 under Node 12, BASELINE.md \u00a72)"}
-        # the same C restatement on every host core: one frame per thread (ctypes releases the GIL), ~6 s sample
+        # the same C restatement on every host core: one frame per thread at a time (ctypes releases the GIL), ~6 s sample
         if piecewise:
             from concurrent.futures import ThreadPoolExecutor
             cores = os.cpu_count() or 1
-            per_thread = max(1, int(6.0 / max(dt / n_done, 1e-3)))
+            deadline = time.perf_counter() + 6.0
 
             def _work(k):
-                done = 0
-                for j in range(per_thread):
+                done, j = 0, 0
+                while j == 0 or time.perf_counter() < deadline:
                     f = (k + j) % F
                     O.warp_inverse_piecewise(sp, frames[f], tris, img, msx, msy, *geoms[f])
                     done += n_out[f]
-                return done
+                    j += 1
+                return done, j
             t1 = time.perf_counter()
             with ThreadPoolExecutor(cores) as ex:
-                px_mt = sum(ex.map(_work, range(cores)))
+                res = list(ex.map(_work, range(cores)))
             dt_mt = time.perf_counter() - t1
-            cpu["all_cores"] = {"value": round(px_mt / dt_mt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-                                "sample": f"{cores} threads x {per_thread} frames (one frame per thread at a time) in {dt_mt:.1f} s"}
+            cpu["all_cores"] = {"value": round(sum(r[0] for r in res) / dt_mt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                                "sample": f"{sum(r[1] for r in res)} frames on {cores} threads (one frame per thread at a time, "
+                                          f"fresh output buffers per frame) in {dt_mt:.1f} s"}
         # the same algorithm as plain JavaScript under this box's Node (what the reference's own loops achieve here)
         if piecewise and args.config in ("C3", "C5"):
             import shutil

@@ -11,6 +11,8 @@
 
 using namespace hg;
 
+constexpr size_t kStatusRing = 64;      // fused piecewise runs that may be queued before their status words are checked
+
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 
@@ -49,9 +51,14 @@ struct hg_ctx {
     RowEnt *d_rowent = nullptr; size_t rowent_cap = 0;
     int row_cap = 64;                                          // entries per row; grows (sticky) after an overflow
     bool pw_fast = false;                                      // uploaded frames are eligible for k_tri_spans/k_pw_rows
+    bool rows_clean = false;                                   // span counters + the next status set were zeroed by the last k_pw_rows
+    int status_slot = 0;                                       // which of the kStatusRing status-word sets the current step uses
+    int32_t *status_base = nullptr, *status_next = nullptr;
     int pw_row_group = kRowGroup;                              // output rows per k_pw_rows workgroup (4, or 1 for dense meshes)
-    bool pw_status_pending = false;                            // a fused run's status has not been checked yet
-    uint8_t *pw_last_out = nullptr;
+    // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
+    // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
+    struct Pending { uint8_t *out; int slot; };
+    std::vector<Pending> pw_pending_out;
 
     // geometric frames
     int geo_kind = 0;
@@ -357,6 +364,7 @@ extern "C" int hg_set_image(hg_ctx *c, const uint8_t *rgba, int w, int h)
 {
     HG_TRY(bind(c));
     if (!rgba || w <= 0 || h <= 0) return fail(c, HG_ERR_INVALID, "hg_set_image: bad image");
+    HG_TRY(hg_sync(c));                                 // settle queued runs before their source is replaced
     const size_t bytes = (size_t)w * h * 4;
     if (c->img_aliased) { c->d_img = nullptr; c->img_cap = 0; c->img_aliased = false; }
     HG_TRY(ensure(c, c->d_img, c->img_cap, bytes));
@@ -370,6 +378,7 @@ extern "C" int hg_set_image_device(hg_ctx *c, const void *d_rgba, int w, int h)
 {
     HG_TRY(bind(c));
     if (!d_rgba || w <= 0 || h <= 0) return fail(c, HG_ERR_INVALID, "hg_set_image_device: bad image");
+    HG_TRY(hg_sync(c));
     if (c->d_img && !c->img_aliased) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_img)); }
     c->d_img = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_rgba));
     c->img_cap = 0; c->img_aliased = true;
@@ -467,6 +476,7 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
 {
     HG_TRY(bind(c));
     if (!src || n_pts <= 0 || n_tris < 0 || (!tris && n_tris > 0)) return fail(c, HG_ERR_INVALID, "hg_piecewise_set_mesh: bad arguments");
+    HG_TRY(hg_sync(c));
     HG_TRY(ensure(c, c->d_src, c->src_cap, (size_t)n_pts * 2));
     HG_TRY(ensure(c, c->d_tris, c->tris_cap, (size_t)std::max(n_tris, 1) * 3));
     HIP_TRY(c, hipMemcpyAsync(c->d_src, src, sizeof(float) * 2 * n_pts, hipMemcpyHostToDevice, c->stream));
@@ -528,16 +538,17 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     HG_TRY(ensure(c, c->d_fwd, c->fwd_cap, F * T * 6));
     HG_TRY(ensure(c, c->d_inv, c->inv_cap, F * T * kInvStride));
     HG_TRY(ensure(c, c->d_status, c->status_cap, F));
-    if (F > c->h_status_cap) {
+    if (F * kStatusRing > c->h_status_cap) {
         if (c->h_status) HIP_TRY(c, hipHostFree(c->h_status));
         c->h_status = nullptr; c->h_status_cap = 0;
         void *q = nullptr;
-        HIP_TRY(c, hipHostMalloc(&q, sizeof(int32_t) * F, hipHostMallocDefault));
-        c->h_status = static_cast<int32_t *>(q); c->h_status_cap = F;
+        HIP_TRY(c, hipHostMalloc(&q, sizeof(int32_t) * F * kStatusRing, hipHostMallocDefault));
+        c->h_status = static_cast<int32_t *>(q); c->h_status_cap = F * kStatusRing;
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, c->pw_frames.data(), sizeof(FrameDesc) * F, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_dst, dst, sizeof(float) * 2 * c->n_pts * F, hipMemcpyHostToDevice, c->stream));
     c->pw_row_group = max_row_cover(c, dst) <= 56 ? kRowGroup : 1;
+    c->rows_clean = false;                                   // new geometry: the counter layout changes
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pw_setup_done = false;
     return HG_OK;
@@ -589,12 +600,24 @@ static int run_setup(hg_ctx *c)
     c->pw_fast = pw_fast_ok(mesh_of(c), mw);
     if (c->pw_fast) {
         RowLists rl = rows_of(c);
-        // row counters and the per-frame status words share one allocation: one memset per step
-        HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, F * rl.row_stride + F));
+        // Row counters + kStatusRing sets of per-frame status words share one allocation.  It is zeroed by a memset only
+        // for the first step after new frames (or after a setup whose warp never ran): k_pw_rows leaves the counters and
+        // the next status set zeroed for the step that follows it.
+        const int32_t *before = c->d_rowcnt;
+        HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, F * rl.row_stride + kStatusRing * F));
         HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, F * (size_t)rl.row_stride * rl.cap));
         rl = rows_of(c);
-        c->status_ptr = c->d_rowcnt + F * rl.row_stride;
-        HIP_TRY(c, hipMemsetAsync(c->d_rowcnt, 0, sizeof(int32_t) * (F * rl.row_stride + F), c->stream));
+        if (before != c->d_rowcnt) c->rows_clean = false;
+        if (c->rows_clean) c->status_slot = (c->status_slot + 1) % (int)kStatusRing;
+        else {
+            HG_TRY(hg_sync(c));                              // (queued runs still own status sets)
+            c->status_slot = 0;
+            HIP_TRY(c, hipMemsetAsync(c->d_rowcnt, 0, sizeof(int32_t) * (F * rl.row_stride + kStatusRing * F), c->stream));
+        }
+        c->status_base = c->d_rowcnt + F * rl.row_stride;
+        c->status_ptr = c->status_base + (size_t)c->status_slot * F;
+        c->status_next = c->status_base + (size_t)((c->status_slot + 1) % (int)kStatusRing) * F;
+        c->rows_clean = false;                               // dirty until the warp kernel has consumed them
         launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
     } else {
         c->status_ptr = c->d_status;
@@ -608,7 +631,7 @@ static int run_setup(hg_ctx *c)
 
 static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
 {
-    if (c->pw_fast) launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->stream);
+    if (c->pw_fast) { launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true; }
     else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
 }
 
@@ -638,7 +661,7 @@ extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
     HG_TRY(bind(c));
     if (!d_out) return fail(c, HG_ERR_INVALID, "d_out is NULL");
     HG_TRY(check_pw_state(c));
-    if (c->pw_status_pending) HG_TRY(hg_sync(c));
+    if (c->pw_pending_out.size() >= kStatusRing - 1) HG_TRY(hg_sync(c));
     // The reference recomputes the per-triangle matrices on every setDestinyPoints and the map + inverses on every
     // warp(): both are part of the per-frame step, so both run here every time.
     HG_TRY(run_setup(c));
@@ -646,9 +669,13 @@ extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
     run_warp(c, static_cast<uint8_t *>(d_out), nullptr);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
-    c->pw_status_pending = true;
-    c->pw_last_out = static_cast<uint8_t *>(d_out);
+    if (c->pw_fast) c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), c->status_slot});
+    else {                                                   // general path: one status set, checked right away
+        HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
+        c->status_base = nullptr;
+        c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), 0});
+        HG_TRY(hg_sync(c));
+    }
     return HG_OK;
 }
 
@@ -656,12 +683,17 @@ extern "C" int hg_sync(hg_ctx *c)
 {
     HG_TRY(bind(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->pw_status_pending) {
-        c->pw_status_pending = false;
+    if (!c->pw_pending_out.empty()) {
+        // frames a fused run flagged (irregular, or a row list overflowed) are redone through the materialised map, into the
+        // output of the call that flagged them, in call order
+        std::vector<hg_ctx::Pending> pending;
+        pending.swap(c->pw_pending_out);
         bool redo = false;
-        for (size_t f = 0; f < c->pw_frames.size(); f++) {
-            if (c->h_status[f] != FRAME_OK) { redo = true; HG_TRY(run_frame_via_map(c, (int)f, c->pw_last_out)); }
-        }
+        const size_t F = c->pw_frames.size();
+        if (c->status_base) HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
+        for (const hg_ctx::Pending &p : pending)
+            for (size_t f = 0; f < F; f++)
+                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) { redo = true; HG_TRY(run_frame_via_map(c, (int)f, p.out)); }
         if (redo) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->pw_fast && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // denser mesh than assumed: larger lists next time

@@ -75,7 +75,7 @@ void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16
 // Fast path (see hg_kernels.hip): eligibility, span-list build (includes the per-triangle solves), row warp.
 bool pw_fast_ok(const PwMesh &mesh, int max_obj_w);
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream);
-void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, hipStream_t stream);
+void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
 // the pixel loop :1042-1056 reading the map.

@@ -263,6 +263,9 @@ __device__ __forceinline__ double sgpr_f64(double v)
 // 34 MB-per-frame output stream from displacing the shared source image in L2 / Infinity Cache (measured -13 % kernel
 // time on C3 versus default-policy stores).
 constexpr int kStoreNT = 2;
+// k_pw_rows span key: triangle id << 14 | LDS byte offset of the span's matrix record (256 records x 48 B < 2^14), so that
+// one signed max picks the last writer AND carries the address of its matrix; ids are < 2^15 (pw_fast_ok)
+constexpr int kKeyShift = 14, kKeyOffMask = (1 << kKeyShift) - 1;
 
 __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, RowLists rl)
 {
@@ -370,7 +373,8 @@ __device__ __forceinline__ void span_max4(int best[4], int d, int len, int key)
 
 template <int CAP, int ABL, bool MAP>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
-                                                 int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group)
+                                                 int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
+                                                 int32_t *__restrict__ status_next)
 {
     // A workgroup owns rows_per_group consecutive output rows: kRowGroup = 4 when the host expects short span lists, 1
     // for dense meshes (there, rows that share source lines should run side by side in different workgroups).  1-D grid decoded so that XCD x (= block id % 8, the observed
@@ -380,10 +384,13 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     const int f = bi / groups_per_xcd;
     const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * rows_per_group;
     const FrameDesc fd = fr.frames[f];
+    // housekeeping for the NEXT step (saves its memset): the other parity's status words are cleared here, and below every
+    // workgroup zeroes the span counters of its rows once all its waves have read them
+    if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_m[CAP * 6];
-    __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, id << 8 | slot
+    __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (kKeyShift)
     static_assert(CAP == 64 * kRowGroup, "packed mode gives each of the 4 rows a 64-slot block");
 
     const int W = fd.obj_w;
@@ -396,11 +403,13 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     // lists are loaded at once, one barrier, then wave j walks row r0 + j alone -- the list-load latency is paid once per
     // four rows and a row's span scan is a single ballot.  Otherwise the rows are taken one after the other with the
     // whole LDS (up to CAP - 1 spans) and the windows of a row are dealt to the four waves.
-    const int *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
     int cnts[kRowGroup], cmax = 0;
 #pragma unroll
     for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
     if (cmax > rl.cap || cmax > CAP - 1) {
+        __syncthreads();                                    // every wave has read the counters before they are cleared
+        if ((int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;
         if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
         return;
     }
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
             const uint4 a = reinterpret_cast<const uint4 *>(ent + i)[0];
             const uint4 b = reinterpret_cast<const uint4 *>(ent + i)[1];
             const int elo = (int)(a.x & 0xffffu), ehi = (int)(a.x >> 16);
-            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)a.y << 8) | i;
+            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)a.y << kKeyShift) | ((base + i) * 48);
             const double m0 = (double)__uint_as_float(a.z), m1 = (double)__uint_as_float(a.w), m2 = (double)__uint_as_float(b.x),
                          m3 = (double)__uint_as_float(b.y), m4 = (double)__uint_as_float(b.z), m5 = (double)__uint_as_float(b.w);
             double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
@@ -437,7 +446,11 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     };
 
     // All 256-pixel windows w0, w0 + wstep, ... of one row whose spans sit in LDS slots [base, base + cnt).
-    auto do_row = [&](int row, int cnt, int base, int smask, int w0, int wstep) {
+    auto do_row = [&](int row, int cnt, int base, int nan_slot, int w0, int wstep) {
+        // "no triangle": smaller than every real key, its low bits address the NaN record
+        const int nan_key = (int)0x80000000u | ((base + nan_slot) * 48);
+        double xd0 = (double)(w0 * 256 + lane + fd.x_off);  // x of this lane's first pixel of the window, kept as a double
+        const double xstep = (double)(wstep * 256);
         const int r = r0 + row;
         const int64_t row_px = (int64_t)r * W;
         // Output row: raw buffer of 4*W bytes, so the ragged last window needs no per-pixel guard (stores past the row
@@ -448,9 +461,9 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
             int best[4];                                    // 64 consecutive pixels and every store instruction 256 contiguous bytes
             uint32_t px[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) best[k] = -1;
+            for (int k = 0; k < 4; k++) best[k] = nan_key;
             unsigned long long any = (ABL & 8) ? 1ull : 0ull;
-            if (ABL & 8) { best[0] = best[1] = best[2] = best[3] = (w % (cnt > 0 ? cnt : 1)); }     // (experiments only) no triangle search
+            if (ABL & 8) { best[0] = best[1] = best[2] = best[3] = (base + w % (cnt > 0 ? cnt : 1)) * 48; }     // (experiments only) no triangle search
             else for (int j = 0; j < cnt; j += 64) {
                 const int idx = j + lane;
                 int lo = 0x7fffffff, hi = 0;
@@ -470,10 +483,9 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
                 double h[8], rd[8];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t slot = (uint32_t)(best[k] & smask) | (uint32_t)base;      // -1 -> the NaN record (base is a multiple of 64)
-                    const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + __umul24(slot, 48u));
+                    const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & kKeyOffMask));
                     const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                    const double xd = (double)(cq + k * 64 + fd.x_off);
+                    const double xd = xd0 + (double)(k * 64);     // exact: integers far below 2^53
                     // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
                     // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
                     h[2 * k]     = fma(m0.x, xd, m0.y) + m1.x;
@@ -495,8 +507,9 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
             if (MAP) {                                      // parity tap (hg_get_tri_map_fused): a separate instantiation
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (cq + k * 64 < W) map_out[fd.map_off + row_px + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> 8);
+                    if (cq + k * 64 < W) map_out[fd.map_off + row_px + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> kKeyShift);
             }
+            xd0 += xstep;
         }
     };
 
@@ -507,10 +520,11 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     for (int pass = 0; pass < npass; pass++) {
         const int row = packed ? wave : pass;               // everything below is wave-uniform (scalar registers)
         const int cnt = __builtin_amdgcn_readfirstlane(cnts[0] * (row == 0) + cnts[1] * (row == 1) + cnts[2] * (row == 2) + cnts[3] * (row == 3));
-        const int base = packed ? wave * 64 : 0, smask = packed ? 63 : CAP - 1;
-        load_row(row, cnt, base, smask, packed ? lane : (int)threadIdx.x, packed ? 64 : 256);
+        const int base = packed ? wave * 64 : 0, nan_slot = packed ? 63 : CAP - 1;
+        load_row(row, cnt, base, nan_slot, packed ? lane : (int)threadIdx.x, packed ? 64 : 256);
         __syncthreads();
-        if (row < nrows) do_row(row, cnt, base, smask, packed ? 0 : wave, packed ? 1 : 4);
+        if (pass == 0 && (int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;
+        if (row < nrows) do_row(row, cnt, base, nan_slot, packed ? 0 : wave, packed ? 1 : 4);
         if (!packed) __syncthreads();                       // the next row overwrites the records
     }
 }
@@ -769,21 +783,21 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
     hipLaunchKernelGGL(k_tri_spans, dim3(mesh.n_tris, fr.n_frames), dim3(128), 0, stream, mesh, fr, rl);
 }
 
-void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, hipStream_t stream)
+void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
 {
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
     const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
     const int rpx = ((fr.max_obj_h + rg - 1) / rg + 7) / 8;                     // row groups per XCD band
     dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
-    if (map_out) { hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); return; }
+    if (map_out) { hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return; }
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;      // experiments only
     switch (abl) {
-    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
-    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
-    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
-    case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
-    case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
-    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg); break;
+    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
     }
 }
 

@@ -324,3 +324,41 @@ def test_c4_face_mesh_batch_matches_oracle(ctx, W, H, F):
             assert (got[..., 3] > 0).mean() > 0.5          # the mesh really covers most of its bounding box
     finally:
         ctx.free(d_out)
+
+
+def test_queued_runs_settle_in_call_order():
+    """Asynchronous `_frames_device` calls are queued back to back (no host round trip); frames a fused run flags (here: row
+    lists overflow on the first calls of a fresh context) are redone at hg_sync into the output of the call that flagged
+    them.  70 calls > the status ring (64) into three rotating output buffers."""
+    c = HG.Context(0)
+    try:
+        n, W2, H2 = 300, 1200, 12
+        img = G.lcg_image(W2, H2, 21)
+        xs = np.linspace(0, W2, n + 1)
+        sp = np.stack([np.repeat(xs, 2), np.tile([0.0, H2], n + 1)], 1).astype(np.float32).ravel()
+        tr = np.array([[2 * i, 2 * i + 2, 2 * i + 1] for i in range(n)] + [[2 * i + 1, 2 * i + 2, 2 * i + 3] for i in range(n)], np.uint32).ravel()
+        frames = [sp.copy(), sp.copy()]
+        frames[0][1::2] *= 1.5
+        frames[1][1::2] *= 2.0
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        ms = WL.src_min(sp)
+        want = [O.warp_inverse_piecewise(sp, frames[f], tr, img, ms[0], ms[1], *geoms[f]) for f in range(2)]
+        c.set_image(img)
+        c.piecewise_set_mesh(sp, tr, ms[0], ms[1])
+        offs, total = HG.pack_offsets(geoms)
+        bufs = [c.alloc(total) for _ in range(3)]
+        try:
+            c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+            for k in range(70):
+                c.warp_inverse_piecewise_frames_device(bufs[k % 3])
+            c.sync()
+            for b in bufs:
+                for f in range(2):
+                    g = geoms[f]
+                    got = c.to_host(b, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                    assert np.array_equal(got, want[f])
+        finally:
+            for b in bufs:
+                c.free(b)
+    finally:
+        c.close()
