@@ -30,13 +30,23 @@ static napi_value throw_hg(napi_env env, hg_ctx *ctx, const char *what, int code
 
 #define HG_CALL(ctx, what, call) do { int rc_ = (call); if (rc_ != HG_OK) return throw_hg(env, (ctx), (what), rc_); } while (0)
 
-typedef struct { hg_ctx *ctx; int obj_w, obj_h; } handle_t;
+/* d_batch: device buffer the frames of warpInversePiecewiseBatch are produced in (kept between calls, grown as needed) */
+typedef struct { hg_ctx *ctx; int obj_w, obj_h; void *d_batch; size_t d_batch_cap; } handle_t;
+
+static void release_ctx(handle_t *h)
+{
+    if (h->ctx) {
+        if (h->d_batch) hg_device_free(h->ctx, h->d_batch);
+        hg_destroy(h->ctx);
+    }
+    h->ctx = NULL; h->d_batch = NULL; h->d_batch_cap = 0;
+}
 
 static void handle_finalize(napi_env env, void *data, void *hint)
 {
     (void)env; (void)hint;
     handle_t *h = (handle_t *)data;
-    if (h) { if (h->ctx) hg_destroy(h->ctx); free(h); }
+    if (h) { release_ctx(h); free(h); }
 }
 
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
@@ -83,6 +93,41 @@ static napi_value make_typed(napi_env env, napi_typedarray_type t, size_t n, siz
     return ta;
 }
 
+/* RGBA outputs.  Default: a fresh, V8-owned Uint8ClampedArray per call like the reference (:991, :1040).  If the caller
+ * passes its own Uint8ClampedArray of at least `bytes` bytes as the optional last argument, the frame is written there
+ * and a view of exactly `bytes` bytes over the same memory is returned: no 34 MB allocation, first-touch page faults and
+ * garbage per 4K frame (that, not PCIe, is most of the host time of a frame on this platform).  Measured and rejected:
+ * pooled external ArrayBuffers -- Node 12 runs their finalizers only from the event loop, so a synchronous warp() loop
+ * would hold every frame it ever produced. */
+static napi_value make_pixels(napi_env env, size_t bytes, napi_value reuse, int have_reuse, void **data)
+{
+    if (have_reuse) {
+        bool is = false;
+        napi_typedarray_type t; size_t n = 0, off = 0; void *p = NULL; napi_value ab, ta;
+        if (napi_is_typedarray(env, reuse, &is) == napi_ok && is &&
+            napi_get_typedarray_info(env, reuse, &t, &n, &p, &ab, &off) == napi_ok &&
+            (t == napi_uint8_clamped_array || t == napi_uint8_array) && n >= bytes && p) {
+            NAPI_OK(napi_create_typedarray(env, napi_uint8_clamped_array, bytes, ab, off, &ta));
+            *data = p;
+            return ta;
+        }
+    }
+    return make_typed(env, napi_uint8_clamped_array, bytes, 1, data);
+}
+
+/* optional trailing argument: argv[want] if present and not undefined/null */
+static int get_args_opt(napi_env env, napi_callback_info info, size_t want, napi_value *argv, int *have_opt)
+{
+    size_t argc = want + 1;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) { throw_str(env, "hgwarp: wrong number of arguments"); return 0; }
+    *have_opt = 0;
+    if (argc > want) {
+        napi_valuetype vt;
+        if (napi_typeof(env, argv[want], &vt) == napi_ok && vt != napi_undefined && vt != napi_null) *have_opt = 1;
+    }
+    return 1;
+}
+
 /* ---------------------------------------------------------------- context */
 static napi_value fn_create(napi_env env, napi_callback_info info)
 {
@@ -103,7 +148,7 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info)
     napi_value a[1];
     if (!get_args(env, info, 1, a)) return NULL;
     void *p = NULL;
-    if (napi_get_value_external(env, a[0], &p) == napi_ok && p) { handle_t *h = (handle_t *)p; if (h->ctx) { hg_destroy(h->ctx); h->ctx = NULL; } }
+    if (napi_get_value_external(env, a[0], &p) == napi_ok && p) release_ctx((handle_t *)p);
     return NULL;
 }
 
@@ -218,8 +263,8 @@ static int get_geom(napi_env env, napi_value *a, hg_geom *g)
 
 static napi_value fn_warp_inverse_geometric(napi_env env, napi_callback_info info)
 {
-    napi_value a[7];
-    if (!get_args(env, info, 7, a)) return NULL;
+    napi_value a[8]; int reuse = 0;
+    if (!get_args_opt(env, info, 7, a, &reuse)) return NULL;
     handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
     int kind; size_t n; hg_geom g;
     if (!get_i32(env, a[1], &kind)) return NULL;
@@ -227,7 +272,7 @@ static napi_value fn_warp_inverse_geometric(napi_env env, napi_callback_info inf
     if (n < (size_t)(kind == HG_AFFINE ? 6 : 8)) return throw_str(env, "hgwarp: matrix too short");
     if (!get_geom(env, a + 3, &g)) return NULL;
     const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
-    void *out; napi_value r = make_typed(env, napi_uint8_clamped_array, px * 4, 1, &out); if (!r) return NULL;
+    void *out; napi_value r = make_pixels(env, px * 4, a[7], reuse, &out); if (!r) return NULL;
     if (px) HG_CALL(h->ctx, "hg_warp_inverse_geometric", hg_warp_inverse_geometric(h->ctx, kind, m, g, (uint8_t *)out));
     return r;
 }
@@ -260,11 +305,11 @@ static napi_value fn_piecewise_prepare(napi_env env, napi_callback_info info)
 
 static napi_value fn_warp_inverse_piecewise(napi_env env, napi_callback_info info)
 {
-    napi_value a[1];
-    if (!get_args(env, info, 1, a)) return NULL;
+    napi_value a[2]; int reuse = 0;
+    if (!get_args_opt(env, info, 1, a, &reuse)) return NULL;
     handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
     const size_t px = (h->obj_w > 0 && h->obj_h > 0) ? (size_t)h->obj_w * h->obj_h : 0;
-    void *out; napi_value r = make_typed(env, napi_uint8_clamped_array, px * 4, 1, &out); if (!r) return NULL;
+    void *out; napi_value r = make_pixels(env, px * 4, a[1], reuse, &out); if (!r) return NULL;
     if (px) HG_CALL(h->ctx, "hg_warp_inverse_piecewise", hg_warp_inverse_piecewise(h->ctx, (uint8_t *)out));
     return r;
 }
@@ -347,8 +392,14 @@ static napi_value fn_warp_inverse_piecewise_batch(napi_env env, napi_callback_in
     size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
     size_t total = 0;
     hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
-    void *d_out = NULL;
-    int rc = hg_device_alloc(h->ctx, total ? total : 1, &d_out);
+    int rc = HG_OK;
+    if (total > h->d_batch_cap) {
+        if (h->d_batch) hg_device_free(h->ctx, h->d_batch);
+        h->d_batch = NULL; h->d_batch_cap = 0;
+        rc = hg_device_alloc(h->ctx, total, &h->d_batch);
+        if (rc == HG_OK) h->d_batch_cap = total;
+    }
+    void *d_out = h->d_batch;
     if (rc == HG_OK) rc = hg_warp_inverse_piecewise_batch_device(h->ctx, dst, (const hg_geom *)gv, offs, F, d_out);
     if (rc == HG_OK) rc = hg_sync(h->ctx);
     napi_value arr = NULL;
@@ -362,7 +413,6 @@ static napi_value fn_warp_inverse_piecewise_batch(napi_env env, napi_callback_in
             napi_set_element(env, arr, f, ta);
         }
     }
-    if (d_out) hg_device_free(h->ctx, d_out);
     free(offs);
     if (rc != HG_OK) return throw_hg(env, h->ctx, "warpInversePiecewiseBatch", rc);
     return arr;

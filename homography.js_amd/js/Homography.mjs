@@ -75,6 +75,11 @@ class Homography {
         this._lastPath = null;
         this._native = addon();                                 // throws if the addon is missing: there is no JS fallback
         this._device = options.device === undefined ? 0 : options.device;
+        // Opt-in (not in the reference): warp() writes every frame of the inverse paths into one internal buffer and returns
+        // a view of it, instead of allocating a fresh 4*w*h-byte array per call -- for frame loops that consume a frame
+        // before asking for the next one.  Default false: a fresh array per call, like the reference (:991, :1040).
+        this.reuseOutput = options.reuseOutput === true;
+        this._outBuffer = null;
         this._ctxHandle = null;                                 // GPU context, created at the first warp
     }
 
@@ -340,6 +345,13 @@ class Homography {
 
     _window() { return [this._xOutputOffset, this._yOutputOffset, this._objectiveWidth, this._objectiveHeight]; }
 
+    /** The caller-owned output buffer handed to the addon when `reuseOutput` is on (grown as needed), else undefined. */
+    _reusable(bytes) {
+        if (!this.reuseOutput) return undefined;
+        if (this._outBuffer === null || this._outBuffer.length < bytes) this._outBuffer = new Uint8ClampedArray(bytes);
+        return this._outBuffer;
+    }
+
     _inverseGeometric() {                                                                                // :987-1013
         this._lastPath = '_inverseGeometricWarp';
         this._alignRanges();
@@ -347,7 +359,8 @@ class Homography {
         this._uploadImage();
         const [xo, yo, ow, oh] = this._window();
         if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
-        return this._native.warpInverseGeometric(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, Float64Array.from(inv), xo, yo, ow, oh);
+        return this._native.warpInverseGeometric(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, Float64Array.from(inv), xo, yo, ow, oh,
+                                                 this._reusable(ow * oh * 4));
     }
 
     _inversePiecewise() {                                                                                // :1029-1058
@@ -358,7 +371,7 @@ class Homography {
         this._uploadImage();
         this._uploadMesh();
         this._native.piecewisePrepare(this._ctx, asF32(this._dstPoints), xo, yo, ow, oh);
-        return this._native.warpInversePiecewise(this._ctx);
+        return this._native.warpInversePiecewise(this._ctx, this._reusable(ow * oh * 4));
     }
 
     _forwardGeometric() {                                                                                // :911-932

@@ -42,6 +42,22 @@ g.setReferencePoints([[0, 0], [0, 1], [1, 0], [1, 1]], [[1 / 10, 1 / 2], [0, 1],
 const img2 = lcgImage(400, 400, 1);
 const o1 = g.warp(img2), o2 = g.warp();
 ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'projective repeat');
+{   // opt-in reuseOutput: same bytes, one buffer behind every returned frame, sized views
+    const r = new Homography('piecewiseaffine', null, null, { reuseOutput: true });
+    r.setSourcePoints(src, lcgImage(W, H, 21), W, H, false);
+    const seen = new Set();
+    for (let pass = 0; pass < 2; pass++) sets.forEach((d, f) => {       // (the frames grow with f: pass 0 sizes the buffer)
+        r.setDestinyPoints(d, false);
+        const o = r.warp(null, false, true);
+        ok(o.data.length === 4 * o.width * o.height && sha(o.data) === sha(single[f].data), `reuseOutput frame ${f} differs`);
+        if (pass === 1) seen.add(o.data.buffer);
+    });
+    ok(seen.size === 1, `reuseOutput used ${seen.size} buffers for ${sets.length} frames once sized`);
+    const p = new Homography('projective', null, null, { reuseOutput: true });
+    p.setReferencePoints([[0, 0], [0, 1], [1, 0], [1, 1]], [[1 / 10, 1 / 2], [0, 1], [9 / 10, 1 / 2], [1, 1]]);
+    ok(sha(p.warp(img2).data) === sha(o1.data), 'reuseOutput projective differs');
+    r.close(); p.close();
+}
 h.close(); g.close();
 ok((() => { try { h.warp(); return true; } catch (e) { return false; } })(), 'warp after close() re-creates the context');
 console.log(JSON.stringify({ failures: fails }));

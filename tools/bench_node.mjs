@@ -1,0 +1,42 @@
+// End-to-end timing of the drop-in JS class (host buffers in, host buffers out: PCIe + allocation included), C3 workload.
+//   node tools/bench_node.mjs [seconds]
+import { Homography } from '../homography.js_amd/js/Homography.mjs';
+import { gridTriangles } from '../homography.js_amd/js/delaunay.mjs';
+
+const W = 3840, H = 2160, nx = 10, ny = 10, A = 40, budget = Number(process.argv[2] || 3);
+const data = new Uint8ClampedArray(W * H * 4);
+{ let s = 1; for (let i = 0; i < data.length; i++) { s = (Math.imul(s, 1664525) + 1013904223) >>> 0; data[i] = s >>> 24; } }
+const src = [], dsts = [];
+for (let j = 0; j <= ny; j++) for (let i = 0; i <= nx; i++) src.push([i * (W / nx), j * (H / ny)]);
+for (let n = 8; n < 12; n++) dsts.push(src.map(([x, y]) => [x, A + y + Math.sin((n * x) / Math.PI) * A]));
+const now = () => Number(process.hrtime.bigint()) / 1e6;
+
+const h = new Homography('piecewiseaffine');
+h.setSourcePoints(src, { data, width: W, height: H }, W, H, false);
+h.setTriangles(gridTriangles(nx, ny));
+h.setDestinyPoints(dsts[0], false);
+let out = h.warp();                                             // first call: context creation, buffers
+const res = { workload: `C3 ${W}x${H}, 200 triangles`, node: process.version };
+{   // the reference's per-frame loop: setDestinyPoints(dst_f); warp()
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) { h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(); frames++; px += out.width * out.height; }
+    const ms = now() - t0;
+    res.warp_loop = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) };
+}
+{   // the same loop with the opt-in single output buffer (reuseOutput)
+    h.reuseOutput = true;
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) { h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(); frames++; px += out.width * out.height; }
+    const ms = now() - t0;
+    res.warp_loop_reuse = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) };
+    h.reuseOutput = false;
+}
+{   // the same frames as one GPU pass
+    const F = 8, sets = Array.from({ length: F }, (_, f) => dsts[f % 4]);
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) { const outs = h.warpBatch(sets); frames += F; for (const o of outs) px += o.width * o.height; }
+    const ms = now() - t0;
+    res.warp_batch8 = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) };
+}
+h.close();
+console.log(JSON.stringify(res));
