@@ -10,7 +10,7 @@ def shard_frames(n_frames, rank, world):
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-def broadcast_source(img_t, rank, world, dist, src=0):
+def broadcast_source(img_t, rank, world, dist, src=0, verify=True):
     """Shared source texture, rank `src` -> all ranks: scatter 1/N to every peer, then all-gather.
 
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring/tree broadcast is bound by one link, while this way each
@@ -33,4 +33,15 @@ def broadcast_source(img_t, rank, world, dist, src=0):
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         padded = torch.cat(parts)
-    return padded[:n].view(img_t.shape).contiguous()
+    out = padded[:n].view(img_t.shape).contiguous()
+    if verify:
+        # every rank must now hold the same bytes: compare a checksum across ranks (all ranks see the same min/max, so
+        # they take the same branch) and fall back to the library's plain broadcast if the scatter path disagreed
+        s = out.sum(dtype=torch.int64).reshape(1)
+        lo, hi = s.clone(), s.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if int(lo.item()) != int(hi.item()):
+            out = img_t.contiguous()
+            dist.broadcast(out, src=src)
+    return out
