@@ -55,6 +55,7 @@ struct hg_ctx {
     int status_slot = 0;                                       // which of the kStatusRing status-word sets the current step uses
     int32_t *status_base = nullptr, *status_next = nullptr;
     int pw_row_group = kRowGroup;                              // output rows per k_pw_rows workgroup (4, or 1 for dense meshes)
+    int pw_tri_threads = 128;                                  // k_tri_spans workgroup size
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
     struct Pending { uint8_t *out; int slot; };
@@ -492,9 +493,10 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
 // Largest number of triangles whose fillTriangle row range (:1113-1120) covers one output row, over the uploaded frames:
 // an estimate of the longest per-row span list, used ONLY to pick k_pw_rows' layout (4 rows per workgroup with 64 LDS
 // slots each, or 1 row with all 256); the kernel checks the real counts and is exact either way.
-static int max_row_cover(const hg_ctx *c, const float *dst)
+static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_rows)
 {
     int worst = 0;
+    double rows_total = 0.0, tris_total = 0.0;
     std::vector<int> diff;
     for (size_t f = 0; f < c->pw_frames.size(); f++) {
         const FrameDesc &fd = c->pw_frames[f];
@@ -516,10 +518,12 @@ static int max_row_cover(const hg_ctx *c, const float *dst)
             const double a = std::max(std::trunc(lo) - fd.y_off, 0.0), b = std::min(std::ceil(hi) - fd.y_off + 1.0, (double)fd.obj_h);
             if (!(a < b)) continue;
             diff[(size_t)a] += 1; diff[(size_t)b] -= 1;
+            rows_total += b - a; tris_total += 1.0;
         }
         int run = 0;
         for (int r = 0; r < fd.obj_h; r++) { run += diff[r]; worst = std::max(worst, run); }
     }
+    *mean_tri_rows = tris_total > 0 ? rows_total / tris_total : 0.0;
     return worst;
 }
 
@@ -547,7 +551,11 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, c->pw_frames.data(), sizeof(FrameDesc) * F, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_dst, dst, sizeof(float) * 2 * c->n_pts * F, hipMemcpyHostToDevice, c->stream));
-    c->pw_row_group = max_row_cover(c, dst) <= 56 ? kRowGroup : 1;
+    double tri_rows = 0.0;
+    const int cover = max_row_cover(c, dst, &tri_rows);
+    c->pw_row_group = cover <= 56 ? kRowGroup : 1;
+    c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
+    if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
     c->rows_clean = false;                                   // new geometry: the counter layout changes
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pw_setup_done = false;
@@ -577,6 +585,7 @@ static PwFrames frames_of(const hg_ctx *c)
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     f.max_obj_h = mh;
     f.row_group = c->pw_row_group;
+    f.tri_threads = c->pw_tri_threads;
     return f;
 }
 

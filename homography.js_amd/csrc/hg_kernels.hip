@@ -307,7 +307,7 @@ __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
     const int64_t len = (int64_t)W * fd.obj_h;
     int32_t *__restrict__ rowcnt = rl.cnt + (size_t)f * rl.row_stride;
     RowEnt *__restrict__ rowent = rl.ent + (size_t)f * rl.row_stride * rl.cap;
-    for (int64_t y = (int64_t)y_min + threadIdx.x; y < y_end; y += 128) {
+    for (int64_t y = (int64_t)y_min + threadIdx.x; y < y_end; y += blockDim.x) {
         int64_t k, fin;
         span_cells(seg, (double)y, (double)fd.y_off, (double)W, len, k, fin);
         if (k >= fin) continue;
@@ -780,7 +780,7 @@ bool pw_fast_ok(const PwMesh &mesh, int max_obj_w)
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream)
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
-    hipLaunchKernelGGL(k_tri_spans, dim3(mesh.n_tris, fr.n_frames), dim3(128), 0, stream, mesh, fr, rl);
+    hipLaunchKernelGGL(k_tri_spans, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl);
 }
 
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
