@@ -242,13 +242,14 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
 //                wrap) and appends the covered cells, cut at output-row boundaries, to that OUTPUT row's span list
 //                {lo, hi, triangle id, inverse matrix as 6 f32} (32 bytes, global memory, atomic slot counter per row).
 //                Exact for any input; the only limit is the per-row list capacity (overflow -> frame redone via the map).
-//   k_pw_rows    one workgroup per output row: loads the row's list into LDS (matrix widened to f64 and specialised to
-//                this row: {m0, m2*y, m4, m1, m3*y, m5}; m2*y and m3*y are the separately rounded products of :1383-1384),
-//                then each wave walks 256-pixel windows: spans overlapping the window are found with one ballot per 64
-//                spans and every lane keeps the LARGEST covering id per pixel (== the sequential overwrite order of
-//                :852-858), then the pixel body: 1 mul + 2 add per coordinate in fp64, Math.round and the bounds test
-//                :1047 through two round-toward-minus-infinity adds per coordinate (see round_x8), one buffer load whose
-//                hardware range check returns 0 outside the RGBA array (the JS `undefined` -> 0 case), coalesced stores.
+//   k_pw_rows    one workgroup per group of 4 output rows (or per row for dense meshes): loads the rows' lists into LDS
+//                (matrix widened to f64 and specialised to the row: {m0, m2*y, m4, m1, m3*y, m5}; m2*y and m3*y are the
+//                separately rounded products of :1383-1384), then each wave walks the 256-pixel windows of its row: spans
+//                overlapping the window are found with one ballot per 64 spans and every lane keeps the LARGEST covering
+//                id per pixel (== the sequential overwrite order of :852-858), then the pixel body: 1 fma + 1 add per
+//                coordinate in fp64, Math.round and the bounds test :1047 through two round-toward-minus-infinity adds
+//                per coordinate (see round_x8), one buffer load whose hardware range check returns 0 outside the RGBA
+//                array (the JS `undefined` -> 0 case), coalesced non-temporal stores.
 // Requirements checked by pw_fast_ok(): n_tris <= 32767 (ids == their Int16 value), obj_w <= 65535, source < 2^31 bytes,
 // min_src_x/y >= 0 (so that the upper y bound can be left to the buffer range check).
 

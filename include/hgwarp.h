@@ -61,7 +61,11 @@ int hg_create_on_stream(int device_id, void *hip_stream, hg_ctx **ctx);
 void hg_destroy(hg_ctx *ctx);
 /* Text of the last error on this ctx (or, with ctx == NULL, of the last failed hg_create / host call of this thread). */
 const char *hg_last_error(const hg_ctx *ctx);
-/* Waits for the ctx stream; returns the first deferred error of the asynchronous `_device` calls since the last sync. */
+/* Waits for the ctx stream; returns the first deferred error of the asynchronous `_device` calls since the last sync.
+ * Also settles queued piecewise runs: hg_warp_inverse_piecewise_frames_device calls are queued back to back (up to 63
+ * before the library syncs by itself); a frame whose mesh is denser than the fast path's row lists (or whose spans are
+ * irregular) is only flagged by the kernel and is redone here, through the materialised map, into the output buffer of
+ * the call that flagged it.  A frame is final once hg_sync (or any synchronous call) has returned. */
 int hg_sync(hg_ctx *ctx);
 /* Device scratch/output helpers so that bindings without a device allocator (Node) can keep frames resident. */
 int hg_device_alloc(hg_ctx *ctx, size_t bytes, void **dptr);
