@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc.sh <tag> : SQ-level PMC passes of a short bench run (each pass its own rocprofv3 run), results as sqlite under gpurun_out/pmc_<tag>
+# NB (measured the hard way on this pool): passes with TCC_* (other than the derived FETCH_SIZE / WRITE_SIZE), TA_* or TCP_*
+# counters never return -- each ran into its timeout.  Only SQ_*/GRBM_* and FETCH_SIZE / WRITE_SIZE passes are usable here.
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_$1; mkdir -p $out
 B="python bench.py --no-cpu-baseline --steps 3 --warmup 1"
