@@ -486,11 +486,13 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
                 for (int k = 0; k < 4; k++) {
                     const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & kKeyOffMask));
                     const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                    const double xd = xd0 + (double)(k * 64);     // exact: integers far below 2^53
+                    // (ABL & 16, timing experiment only: the access pattern of a 16 px x 4 row lane patch instead of 64 px x 1 row)
+                    const double xd = (ABL & 16) ? (double)(c0 + (lane & 15) + 16 * k + fd.x_off) : xd0 + (double)(k * 64);     // exact: integers far below 2^53
                     // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
                     // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
                     h[2 * k]     = fma(m0.x, xd, m0.y) + m1.x;
                     h[2 * k + 1] = fma(m1.y, xd, m2.x) + m2.y;
+                    if (ABL & 16) h[2 * k + 1] += (double)(lane >> 4);
                 }
                 round_x8(h, rd);
 #pragma unroll
@@ -797,6 +799,7 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
     case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
     case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    case 16: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 16, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
     case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
     default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
     }
