@@ -18,10 +18,12 @@ overflow = 0
 for t in range(trials):
     W, H = int(rng.integers(8, 700)), int(rng.integers(8, 400))
     img = G.lcg_image(W, H, 9000 + t)
+    mode = t % 8
     nx, ny = int(rng.integers(1, 24)), int(rng.integers(1, 16))
+    if mode == 6:
+        nx, ny = int(rng.integers(30, 140)), int(rng.integers(1, 6))                      # dense rows: 1 row per workgroup, > 63 spans per row
     sp = WL.grid_points(W, H, nx, ny).reshape(-1, 2).astype(np.float64)
     tris = WL.grid_triangles(nx, ny)
-    mode = t % 6
     if mode == 1:
         sp = sp * rng.uniform(0.3, 0.9) + rng.uniform(0, 0.3) * np.array([W, H])        # minSrc > 0
     elif mode == 2:
@@ -51,6 +53,24 @@ for t in range(trials):
         ok = ok and np.array_equal(ctx.get_tri_map(fused=True), wmap)
     except HG.HgError:
         overflow += 1          # more spans in a row than the fused kernel's LDS list: the warp itself went through the map path
+    if mode == 7:                                                                           # the same mesh as a 3-frame batch with different windows
+        frames = [dp32, (dp * rng.uniform(0.6, 1.4, 2) + rng.uniform(-30, 30, 2)).astype(np.float32).ravel(),
+                  (dp + rng.uniform(-3, 3, dp.shape)).astype(np.float32).ravel()]
+        geoms = []
+        for d in frames:
+            m = O.minmax_xy(d)
+            geoms.append((int(m[0]), int(m[1]), int(m[2] - m[0]), int(m[3] - m[1])))
+        if all(g[2] > 0 and g[3] > 0 and g[2] * g[3] < 6_000_000 for g in geoms):
+            offs, total = HG.pack_offsets(geoms)
+            d_out = ctx.alloc(total)
+            ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+            ctx.warp_inverse_piecewise_frames_device(d_out)
+            ctx.warp_inverse_piecewise_frames_device(d_out)                                 # queued twice: self-cleaning counters
+            ctx.sync()
+            for f, g in enumerate(geoms):
+                gotf = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                ok = ok and np.array_equal(gotf, O.warp_inverse_piecewise(sp32, frames[f], tris, img, int(ms[0]), int(ms[1]), *g))
+            ctx.free(d_out)
     # geometric kernels on the same image
     d4 = (WL.corners(W, H).reshape(4, 2) * rng.uniform(0.4, 2.0, 2) + rng.uniform(-0.2, 0.2, (4, 2)) * [W, H] + rng.uniform(-50, 50, 2)).astype(np.float32).ravel()
     s4 = WL.corners(W, H)
