@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,7 +31,8 @@ struct hg_ctx {
     // mesh (source side)
     float *d_src = nullptr; size_t src_cap = 0;
     uint32_t *d_tris = nullptr; size_t tris_cap = 0;
-    std::vector<uint32_t> h_tris;                              // host copy (row-density estimate in hg_piecewise_set_frames)
+    std::vector<uint32_t> h_tris;                              // host copies (row-density / shear estimates in hg_piecewise_set_frames)
+    std::vector<float> h_src;
     int n_pts = 0, n_tris = 0, min_src_x = 0, min_src_y = 0;
     bool have_mesh = false;
 
@@ -56,6 +58,10 @@ struct hg_ctx {
     int32_t *status_base = nullptr, *status_next = nullptr;
     int pw_row_group = kRowGroup;                              // output rows per k_pw_rows workgroup (4, or 1 for dense meshes)
     int pw_tri_threads = 128;                                  // k_tri_spans workgroup size
+    bool pw_patch = false;                                     // dense mesh that fits k_pw_patch (4-row groups, 2-D gather patches)
+    bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
+    bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
+    int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
     struct Pending { uint8_t *out; int slot; };
@@ -206,6 +212,8 @@ extern "C" int hg_copy_to_host(hg_ctx *c, void *dst, const void *src, size_t byt
     HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return HG_OK;
 }
+
+extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kernel : 0; }
 
 extern "C" int hg_set_timing(hg_ctx *c, int enabled)
 {
@@ -485,6 +493,7 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n_pts = n_pts; c->n_tris = n_tris; c->min_src_x = msx; c->min_src_y = msy;
     c->h_tris.assign(tris, tris + (size_t)3 * n_tris);
+    c->h_src.assign(src, src + (size_t)2 * n_pts);
     c->have_mesh = true;
     c->pw_frames.clear(); c->pw_setup_done = false;
     return HG_OK;
@@ -493,37 +502,58 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
 // Largest number of triangles whose fillTriangle row range (:1113-1120) covers one output row, over the uploaded frames:
 // an estimate of the longest per-row span list, used ONLY to pick k_pw_rows' layout (4 rows per workgroup with 64 LDS
 // slots each, or 1 row with all 256); the kernel checks the real counts and is exact either way.
-static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_rows)
+static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_rows, int *max_group_tris, double *mean_shear)
 {
-    int worst = 0;
-    double rows_total = 0.0, tris_total = 0.0;
-    std::vector<int> diff;
+    int worst = 0, worst_group = 0;
+    double rows_total = 0.0, tris_total = 0.0, shear_total = 0.0, shear_n = 0.0;
+    std::vector<int> diff, starts;
     for (size_t f = 0; f < c->pw_frames.size(); f++) {
         const FrameDesc &fd = c->pw_frames[f];
         if (fd.obj_w <= 0 || fd.obj_h <= 0) continue;
         const float *dp = dst + f * (size_t)c->n_pts * 2;
         diff.assign((size_t)fd.obj_h + 2, 0);
+        starts.assign((size_t)fd.obj_h + 2, 0);
         for (int t = 0; t < c->n_tris; t++) {
             double lo = INFINITY, hi = -INFINITY;
             bool ok = true;
+            double sx[3], sy[3], dx[3], dy[3];
             for (int k = 0; k < 3; k++) {
                 const uint32_t v = c->h_tris[3 * (size_t)t + k];
                 if (v >= (uint32_t)c->n_pts) { ok = false; break; }
                 const double y = dp[2 * (size_t)v + 1];
                 if (!(y == y)) { ok = false; break; }
                 lo = std::min(lo, y); hi = std::max(hi, y);
+                sx[k] = c->h_src[2 * (size_t)v]; sy[k] = c->h_src[2 * (size_t)v + 1]; dx[k] = dp[2 * (size_t)v]; dy[k] = y;
             }
             if (!ok) continue;
+            {   // |d(source row) / d(output x)| of the triangle's inverse map: how many source lines 64 consecutive output
+                // pixels spread over (plain doubles: an estimate, never used for pixels)
+                const double e1x = sx[1] - sx[0], e1y = sy[1] - sy[0], e2x = sx[2] - sx[0], e2y = sy[2] - sy[0];
+                const double f1x = dx[1] - dx[0], f1y = dy[1] - dy[0], f2x = dx[2] - dx[0], f2y = dy[2] - dy[0];
+                const double D = e1x * e2y - e2x * e1y;
+                const double a = (f1x * e2y - f2x * e1y) / D, cc = (e1x * f2x - e2x * f1x) / D;
+                const double b = (f1y * e2y - f2y * e1y) / D, d = (e1x * f2y - e2x * f1y) / D;
+                const double sh = std::fabs(b / (a * d - b * cc));
+                if (sh == sh && sh < 1e6) { shear_total += sh; shear_n += 1.0; }
+            }
             // rows [trunc(minY), ceil(maxY)) - yOff, one more below for spans that spill over the row end (x-offset quirk)
             const double a = std::max(std::trunc(lo) - fd.y_off, 0.0), b = std::min(std::ceil(hi) - fd.y_off + 1.0, (double)fd.obj_h);
             if (!(a < b)) continue;
-            diff[(size_t)a] += 1; diff[(size_t)b] -= 1;
+            diff[(size_t)a] += 1; diff[(size_t)b] -= 1; starts[(size_t)a] += 1;
             rows_total += b - a; tris_total += 1.0;
         }
         int run = 0;
-        for (int r = 0; r < fd.obj_h; r++) { run += diff[r]; worst = std::max(worst, run); }
+        int group = 0;                                       // triangles touching the 4-row group the row belongs to
+        for (int r = 0; r < fd.obj_h; r++) {
+            run += diff[r];
+            worst = std::max(worst, run);
+            group = (r % kRowGroup == 0) ? run : group + starts[r];
+            worst_group = std::max(worst_group, group);
+        }
     }
     *mean_tri_rows = tris_total > 0 ? rows_total / tris_total : 0.0;
+    *max_group_tris = worst_group;
+    *mean_shear = shear_n > 0 ? shear_total / shear_n : 0.0;
     return worst;
 }
 
@@ -551,9 +581,16 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, c->pw_frames.data(), sizeof(FrameDesc) * F, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_dst, dst, sizeof(float) * 2 * c->n_pts * F, hipMemcpyHostToDevice, c->stream));
-    double tri_rows = 0.0;
-    const int cover = max_row_cover(c, dst, &tri_rows);
+    double tri_rows = 0.0, shear = 0.0;
+    int group_tris = 0, max_w = 0;
+    const int cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear);
+    for (const FrameDesc &d : c->pw_frames) max_w = std::max(max_w, d.obj_w);
     c->pw_row_group = cover <= 56 ? kRowGroup : 1;
+    // dense rows that still fit the patch kernel's LDS budget, sheared enough for 2-D gather patches to pay (measured: C5,
+    // mean shear 0.39, 0.63 -> 0.50 ms; the same mesh without shear 0.35 -> 0.37 ms).  Layout choice only: the kernels check
+    // the real counts.
+    c->pw_patch = cover > 56 && cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW &&
+                  shear >= 0.2 && !c->pw_patch_disabled;
     c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
     c->rows_clean = false;                                   // new geometry: the counter layout changes
@@ -640,7 +677,14 @@ static int run_setup(hg_ctx *c)
 
 static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
 {
-    if (c->pw_fast) { launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true; }
+    static const int force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;        // experiments only: 0 = never, 1 = whenever allowed by size
+    int mw = 0;
+    for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
+    const bool patch = c->pw_fast && !map_out && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force == 1 : c->pw_patch);
+    c->pw_used_patch = patch;
+    c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
+    if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, c->stream); c->rows_clean = true; }
+    else if (c->pw_fast) { launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true; }
     else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
 }
 
@@ -705,6 +749,7 @@ extern "C" int hg_sync(hg_ctx *c)
                 if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) { redo = true; HG_TRY(run_frame_via_map(c, (int)f, p.out)); }
         if (redo) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->pw_used_patch) c->pw_patch_disabled = true;   // (its limits are tighter than k_pw_rows': do not pay the map path again)
             if (c->pw_fast && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // denser mesh than assumed: larger lists next time
         }
     }

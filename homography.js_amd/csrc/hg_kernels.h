@@ -77,6 +77,10 @@ void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16
 bool pw_fast_ok(const PwMesh &mesh, int max_obj_w);
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream);
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream);
+// Dense meshes (64..199 spans per row, obj_w <= 8192): 4 rows per workgroup, 16 x 4 pixel gather patches, one matrix record
+// per triangle of the group.  Same row lists, same status protocol as launch_pw_rows; no map tap.
+constexpr int kPatchMaxW = 8192, kPatchMaxRowSpans = 196, kPatchMaxGroupTris = 204;
+void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
 // the pixel loop :1042-1056 reading the map.

@@ -357,9 +357,10 @@ __device__ __forceinline__ void round_x8(double h[8], double r[8])
 // i.e. (unsigned)(d + 64k) < len.  Two VALU instructions per pixel: the compare writes EXEC directly (v_cmpx) and the
 // max runs under it; a compare + select + max sequence (what the compiler emits) needs three.  All 64 lanes are active
 // here (uniform control flow, 256-thread blocks), EXEC is restored from the saved copy after every pixel.
+template <int STRIDE = 64>
 __device__ __forceinline__ void span_max4(int best[4], int d, int len, int key)
 {
-    const int d1 = d + 64, d2 = d + 128, d3 = d + 192;
+    const int d1 = d + STRIDE, d2 = d + 2 * STRIDE, d3 = d + 3 * STRIDE;
     unsigned long long sv;
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
@@ -369,6 +370,21 @@ __device__ __forceinline__ void span_max4(int best[4], int d, int len, int key)
         "v_cmpx_lt_u32_e32 vcc, %[d3], %[len]\n\t" "v_max_i32_e32 %[b3], %[b3], %[key]\n\t" "s_mov_b64 exec, %[sv]"
         : [b0] "+v"(best[0]), [b1] "+v"(best[1]), [b2] "+v"(best[2]), [b3] "+v"(best[3]), [sv] "=&s"(sv)
         : [d0] "v"(d), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [len] "v"(len), [key] "v"(key)
+        : "vcc");
+}
+
+// same, the four pixel offsets given explicitly
+__device__ __forceinline__ void span_max4d(int best[4], int d0, int d1, int d2, int d3, int len, int key)
+{
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d0], %[len]\n\t" "v_max_i32_e32 %[b0], %[b0], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d1], %[len]\n\t" "v_max_i32_e32 %[b1], %[b1], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d2], %[len]\n\t" "v_max_i32_e32 %[b2], %[b2], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d3], %[len]\n\t" "v_max_i32_e32 %[b3], %[b3], %[key]\n\t" "s_mov_b64 exec, %[sv]"
+        : [b0] "+v"(best[0]), [b1] "+v"(best[1]), [b2] "+v"(best[2]), [b3] "+v"(best[3]), [sv] "=&s"(sv)
+        : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [len] "v"(len), [key] "v"(key)
         : "vcc");
 }
 
@@ -529,6 +545,189 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
         if (pass == 0 && (int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;
         if (row < nrows) do_row(row, cnt, base, nan_slot, packed ? 0 : wave, packed ? 1 : 4);
         if (!packed) __syncthreads();                       // the next row overwrites the records
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_pw_patch (dense meshes)
+// Same contract and the same row lists as k_pw_rows, for meshes whose rows carry 64..199 spans (C5: 5 000 triangles on 8K,
+// ~145 per row).  There k_pw_rows runs one row per workgroup, and under the steep shear such meshes usually have (source y
+// moves ~1 row per output pixel) the 64 lanes of a row-contiguous gather hit 64 different 128-byte source lines.  Here a
+// workgroup owns 4 output rows and every gather instruction covers a 2-D patch, 16 pixels x 4 rows: vertically adjacent
+// output pixels read horizontally adjacent source pixels, so a patch touches ~19 lines.  What makes four dense rows fit
+// in LDS: the matrix records are stored once per TRIANGLE of the group (a triangle crossing all four rows appears in four
+// lists), found through a small hash table while the lists are loaded; m2*y, m3*y are then formed per pixel (one more
+// fp64 multiply per coordinate, rounded exactly where the reference rounds them).  The span lookup is per lane (lanes of
+// a wave sit on four different rows), through per-(row, 64-pixel column) bins of span indices built in LDS.
+// Limits (host picks the kernel from its estimate; a group that exceeds one flags the frame -> map path, and the context
+// stops using this kernel): <= 199 spans per row, <= 208 triangles per 4-row group, <= 8 spans per bin, obj_w <= 8192.
+constexpr int kPatchRows = 4, kPatchCap = 200, kPatchRecs = 208, kPatchBins = 128, kPatchBinSlots = 8, kPatchHash = 1024, kPatchTilePitch = 68;
+// (sized so that six workgroups fit a CU's 160 KB of LDS: 26.9 KB each)
+static_assert(kPatchHash * 4 <= kPatchRows * kPatchBins * kPatchBinSlots, "the hash table lives in the bin-slot area");
+
+__global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
+                                                  int groups_per_xcd, int32_t *__restrict__ status_next)
+{
+    const int bid = blockIdx.x, xcd = bid & 7, bi = bid >> 3;
+    const int f = bi / groups_per_xcd;
+    const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * kPatchRows;
+    const FrameDesc fd = fr.frames[f];
+    if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;   // (see k_pw_rows)
+    if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
+
+    __shared__ __align__(16) double s_rec[(kPatchRecs + 1) * 6];            // {m0, m2, m4, m1, m3, m5} per triangle; last = NaN record
+    __shared__ uint32_t s_lohi[kPatchRows * kPatchCap];                     // span cells [lo, hi) of the row, 16 bits each
+    __shared__ int s_key[kPatchRows * kPatchCap];                           // id << 14 | byte offset of the triangle's record
+    __shared__ int s_bincnt[kPatchRows * kPatchBins];
+    __shared__ __align__(4) uint8_t s_bin[kPatchRows * kPatchBins * kPatchBinSlots];   // span indices per (row, 64-px column)
+    __shared__ uint32_t s_tile[4 * kPatchRows * kPatchTilePitch];          // per wave: 4 rows x 64 pixels (+ padding against bank conflicts)
+    __shared__ int s_nrec, s_fail;
+    uint32_t *s_hash = reinterpret_cast<uint32_t *>(s_bin);                 // id << 16 | (record + 1), 0 = empty; used before the bins
+
+    const int W = fd.obj_w;
+    const int nbins = (W + 63) >> 6;
+    const int nrows = min(kPatchRows, fd.obj_h - r0);
+    int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    int cnts[kPatchRows], cmax = 0;
+#pragma unroll
+    for (int j = 0; j < kPatchRows; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
+    for (int i = threadIdx.x; i < kPatchRows * kPatchBins; i += 256) s_bincnt[i] = 0;
+    for (int i = threadIdx.x; i < kPatchHash; i += 256) s_hash[i] = 0u;
+    if (threadIdx.x == 0) { s_nrec = 0; s_fail = (cmax > rl.cap || cmax > kPatchCap - 1 || nbins > kPatchBins) ? 1 : 0; }
+    __syncthreads();
+    if ((int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;                    // every wave has read the counters: clean for the next step
+    const bool bad0 = s_fail != 0;
+
+    // ---- phase 1: span lists -> LDS; each triangle of the group gets ONE matrix record (hash on the id: the thread that
+    // claims the bucket writes the record and publishes its index; the others remember the bucket and read it later)
+    int my_bucket[(kPatchRows * kPatchCap + 255) / 256];
+    int n_mine = 0;
+    if (!bad0) for (int e = threadIdx.x; e < kPatchRows * kPatchCap; e += 256) {
+        const int rr = e / kPatchCap, i = e - rr * kPatchCap;
+        const int cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
+        int bucket = -1;
+        if (i < cnt) {
+            const RowEnt *ent = rl.ent + ((size_t)f * rl.row_stride + r0 + rr) * rl.cap + i;
+            const uint4 a = reinterpret_cast<const uint4 *>(ent)[0];
+            s_lohi[e] = a.x;
+            const uint32_t id = a.y;
+            uint32_t hpos = (id * 2654435761u) >> 22;                       // 10 bits
+            for (int probe = 0; probe < kPatchHash; probe++, hpos = (hpos + 1) & (kPatchHash - 1)) {
+                const uint32_t old = atomicCAS(&s_hash[hpos], 0u, (id << 16) | 0xffffu);
+                if (old == 0u) {                                            // claimed: this thread owns the triangle's record
+                    const int rec = atomicAdd(&s_nrec, 1);
+                    if (rec < kPatchRecs) {
+                        const uint4 b = reinterpret_cast<const uint4 *>(ent)[1];
+                        double2 *mrec = reinterpret_cast<double2 *>(s_rec + rec * 6);
+                        mrec[0] = make_double2((double)__uint_as_float(a.z), (double)__uint_as_float(b.x));    // m0, m2
+                        mrec[1] = make_double2((double)__uint_as_float(b.z), (double)__uint_as_float(a.w));    // m4, m1
+                        mrec[2] = make_double2((double)__uint_as_float(b.y), (double)__uint_as_float(b.w));    // m3, m5
+                        s_hash[hpos] = (id << 16) | (uint32_t)(rec + 1);
+                    } else s_fail = 1;
+                    bucket = (int)hpos;
+                    break;
+                }
+                if ((old >> 16) == id) { bucket = (int)hpos; break; }
+            }
+            s_key[e] = (int)id;
+        }
+        my_bucket[n_mine++] = bucket;
+    }
+    if (threadIdx.x < 3) reinterpret_cast<double2 *>(s_rec + kPatchRecs * 6)[threadIdx.x] = make_double2(NAN, NAN);
+    __syncthreads();
+    // ---- phase 2: keys (id << 14 | record offset), once every record index is published
+    const bool bad1 = s_fail != 0;
+    n_mine = 0;
+    if (!bad1) for (int e = threadIdx.x; e < kPatchRows * kPatchCap; e += 256) {
+        const int bucket = my_bucket[n_mine++];
+        if (bucket >= 0) s_key[e] = (s_key[e] << kKeyShift) | (int)(((s_hash[bucket] & 0xffffu) - 1u) * 48u);
+    }
+    __syncthreads();
+    // ---- phase 3: the hash table is dead, its memory becomes the bins: span index -> every 64-pixel column it overlaps
+    if (!bad1) for (int e = threadIdx.x; e < kPatchRows * kPatchCap; e += 256) {
+        const int rr = e / kPatchCap, i = e - rr * kPatchCap;
+        const int cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
+        if (i < cnt) {
+            const uint32_t lh = s_lohi[e];
+            const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
+            for (int b = lo >> 6; b <= (hi - 1) >> 6 && b < nbins; b++) {
+                const int pos = atomicAdd(&s_bincnt[rr * kPatchBins + b], 1);
+                if (pos < kPatchBinSlots) s_bin[(rr * kPatchBins + b) * kPatchBinSlots + pos] = (uint8_t)i;
+                else s_fail = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_fail) {                                           // the host redoes the frame through the materialised map
+        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+        return;
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rr = lane >> 4;                               // lane = (row of the group, columns (lane & 15) + 16k of the block)
+    int ck[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ck[k] = (lane & 15) + 16 * k;
+    const double y = (double)(r0 + rr + fd.y_off);
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mesh.img), 0, mesh.W * mesh.H * 4, 0x00020000);
+    // output: the group's rows as one raw buffer; lanes of rows past the frame end and pixels past the row end get an
+    // offset the hardware range check drops
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r0 * W * 4, 0, nrows * W * 4, 0x00020000);
+    const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
+    const double by_lo = (double)mesh.min_src_y + 0.5;
+    const int pitch4 = mesh.W * 4;
+    const int nan_key = (int)0x80000000u | (kPatchRecs * 48);
+    const int row_base = rr * kPatchCap;
+    uint32_t *tile = s_tile + wave * (kPatchRows * kPatchTilePitch);
+
+    for (int cw = wave; cw < nbins; cw += 4) {              // this wave's 64-pixel-wide column blocks, all 4 rows at once
+        const int c0 = cw << 6;                             // pixel k of the lane: (c0 + ck[k], r0 + rr)
+        int best[4] = { nan_key, nan_key, nan_key, nan_key };
+        const int bidx = rr * kPatchBins + cw;
+        const int nb = min(s_bincnt[bidx], kPatchBinSlots);
+        const uint8_t *bin = s_bin + bidx * kPatchBinSlots;
+        for (int p = 0; __any(p < nb); p++) {
+            int lo = 0, len = 0, key = 0;                   // len 0: no pixel passes the span test
+            if (p < nb) {
+                const int e = row_base + bin[p];
+                const uint32_t lh = s_lohi[e];
+                lo = (int)(lh & 0xffffu); len = (int)(lh >> 16) - lo; key = s_key[e];
+            }
+            const int d = c0 - lo;
+            span_max4d(best, d + ck[0], d + ck[1], d + ck[2], d + ck[3], len, key);     // larger id wins (== last writer of :852-858)
+        }
+        double h[8], rd[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_rec) + (best[k] & kKeyOffMask));
+            const double2 m02 = mrec[0], m41 = mrec[1], m35 = mrec[2];
+            const double xd = (double)(c0 + ck[k] + fd.x_off);
+            // :1383-1384  (m0*x) + (m2*y) + m4: m2*y rounded on its own, m0*x exact in fp64 (see k_pw_rows)
+            h[2 * k]     = fma(m02.x, xd, m02.y * y) + m41.x;
+            h[2 * k + 1] = fma(m41.y, xd, m35.x * y) + m35.y;
+        }
+        round_x8(h, rd);
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo);   // :1047 (NaN fails)
+            const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
+            px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
+        }
+        // 64 x 4 transpose through this wave's LDS tile (wave-synchronous: no barrier), so that each store instruction
+        // writes 256 contiguous bytes of ONE row instead of four 64-byte pieces (measured: 0.62 -> 0.50 ms on C5)
+#pragma unroll
+        for (int k = 0; k < 4; k++) tile[rr * kPatchTilePitch + ck[k]] = px[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int xs = (cw << 6) + lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                       // row k of the group, pixel xs: past the row / frame end -> dropped
+            const uint32_t v = tile[k * kPatchTilePitch + lane];
+            __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && k < nrows) ? (uint32_t)(k * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -784,6 +983,13 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
     hipLaunchKernelGGL(k_tri_spans, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl);
+}
+
+void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, hipStream_t stream)
+{
+    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
+    const int gpx = ((fr.max_obj_h + kPatchRows - 1) / kPatchRows + 7) / 8;
+    hipLaunchKernelGGL(k_pw_patch, dim3((unsigned)gpx * 8u * (unsigned)fr.n_frames), dim3(256), 0, stream, mesh, fr, rl, out, gpx, status_next);
 }
 
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)

@@ -163,6 +163,9 @@ int hg_warp_forward_geometric(hg_ctx *ctx, int kind, const double *m, hg_geom ge
  * max_src_x/y = rounded source-point bbox maximum (:758); the forward triangle map :817-832 is rebuilt on the device. */
 int hg_warp_forward_piecewise(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host);
 
+/* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
+ * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general). */
+int hg_last_piecewise_kernel(hg_ctx *ctx);
 /* ------------------------------------------------------------------------------------------------ measurement aid
  * hipEvent pairs recorded on the ctx stream around each launch of the dominant kernel (the fused piecewise kernel or
  * the geometric kernel; not the tiny per-triangle setup).  hg_set_timing(ctx, 1) enables it and resets the counters;

@@ -362,3 +362,35 @@ def test_queued_runs_settle_in_call_order():
                 c.free(b)
     finally:
         c.close()
+
+
+def test_dense_sheared_mesh_takes_the_patch_kernel():
+    """A mesh with ~150 spans per row and shear ~1 (C5's regime at a size the oracle does in a blink): the host picks
+    k_pw_patch (4-row groups, 2-D gather patches, one matrix record per triangle of the group); a flat dense mesh and a
+    sparse mesh stay on k_pw_rows.  All bit-exact against the oracle, three frames with different windows per batch."""
+    c = HG.Context(0)
+    try:
+        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 3), (1600, 150, 56, 3, 0.5, 2), (640, 150, 8, 3, 18.0, 1)]:
+            img = G.lcg_image(W, H, 31)
+            sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+            frames = [WL.sin_dst(sp, A, 8 + f) for f in range(3)]
+            frames[1] = (frames[1].reshape(-1, 2) * np.float32([1.1, 0.9]) + np.float32([7, 3])).ravel()
+            geoms = [WL.piecewise_geom(d) for d in frames]
+            ms = WL.src_min(sp)
+            c.set_image(img)
+            c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+            offs, total = HG.pack_offsets(geoms)
+            d_out = c.alloc(total)
+            try:
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                for _ in range(3):                           # queued runs: counters are cleaned by the kernel itself
+                    c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                assert c.last_piecewise_kernel() == want_kernel, (nx, A, c.last_piecewise_kernel())
+                for f, g in enumerate(geoms):
+                    got = c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                    assert np.array_equal(got, O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *g)), (nx, A, f)
+            finally:
+                c.free(d_out)
+    finally:
+        c.close()
