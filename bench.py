@@ -46,9 +46,10 @@ def _pmc_traffic(config, frames, piecewise):
     WRITE_SIZE, profiles/hbm_traffic.json), when they were collected for this very workload; else null."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            t = json.load(f)
-        if piecewise and t.get("config") == config and t.get("frames_per_launch") == frames:
-            return int(t["hbm_bytes_per_launch"])
+            entries = json.load(f)
+        for t in entries if isinstance(entries, list) else [entries]:
+            if piecewise and t.get("config") == config and t.get("frames_per_launch") == frames:
+                return int(t["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -195,7 +196,8 @@ def main():
     # ---------------------------------------------------------------- roofline of the dominant kernel (rank 0's launches)
     k_ms = k_total_ms / max(k_launches, 1)
     achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_pw_rows" if piecewise else "k_geo<projective>",
+    kernel_name = {3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo<projective>"
+    roofline = {"bound": "hbm", "kernel": kernel_name,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": _pmc_traffic(args.config, F, piecewise), "kernel_ms": round(k_ms, 5), "launches_timed": k_launches,
                 "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
