@@ -201,9 +201,12 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": _pmc_traffic(args.config, F, piecewise), "kernel_ms": round(k_ms, 5), "launches_timed": k_launches,
                 "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
-                "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel; "
-                        "source reads shared by neighbouring rows and frames hit in L2 / the 256 MiB Infinity Cache, so the measured "
-                        "fabric traffic is below the algorithmic bytes and the fraction can touch 1.0 without exceeding the memory system"}
+                "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel"}
+    if roofline["traffic"] is not None and roofline["traffic"] < algo_bytes_per_launch:
+        roofline["note"] += ("; source reads shared by neighbouring rows and frames hit in L2 / the 256 MiB Infinity Cache, so the measured "
+                             "fabric traffic is below the algorithmic bytes and the fraction can touch 1.0 without exceeding the memory system")
+    elif roofline["traffic"] is not None:
+        roofline["note"] += "; measured fabric traffic exceeds the algorithmic bytes: scattered source lines are fetched more than once"
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample
     cpu = None
