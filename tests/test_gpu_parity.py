@@ -394,3 +394,37 @@ def test_dense_sheared_mesh_takes_the_patch_kernel():
                 c.free(d_out)
     finally:
         c.close()
+
+
+def test_patch_kernel_limits_fall_back_and_stay_off():
+    """56 triangle columns squeezed into 300 pixels: ~150 spans per row (inside k_pw_patch's budget, so the host picks it) but
+    ~30 per 64-pixel bin (beyond its 8): the kernel only flags the frames, hg_sync redoes them through the materialised map,
+    and the context then stays on k_pw_rows."""
+    c = HG.Context(0)
+    try:
+        W, H, nx, ny, A = 300, 120, 56, 3, 6.0
+        img = G.lcg_image(W, H, 41)
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        frames = [WL.sin_dst(sp, A, 8 + f) for f in range(2)]
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        ms = WL.src_min(sp)
+        want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(2)]
+        c.set_image(img)
+        c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+        offs, total = HG.pack_offsets(geoms)
+        d_out = c.alloc(total)
+        try:
+            kernels = []
+            for _ in range(2):
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                kernels.append(c.last_piecewise_kernel())
+                for f, g in enumerate(geoms):
+                    got = c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                    assert np.array_equal(got, want[f]), f
+            assert kernels == [3, 2], kernels
+        finally:
+            c.free(d_out)
+    finally:
+        c.close()
