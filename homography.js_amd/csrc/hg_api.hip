@@ -62,6 +62,7 @@ struct hg_ctx {
     bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
     bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
+    int opt_min_row_groups = 1536, opt_patch = -1;             // hg_set_option()
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
     struct Pending { uint8_t *out; int slot; };
@@ -214,6 +215,16 @@ extern "C" int hg_copy_to_host(hg_ctx *c, void *dst, const void *src, size_t byt
 }
 
 extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kernel : 0; }
+
+extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
+{
+    HG_TRY(bind(c));
+    if (!key) return fail(c, HG_ERR_INVALID, "hg_set_option: key is NULL");
+    if (!std::strcmp(key, "min_row_groups")) c->opt_min_row_groups = value;
+    else if (!std::strcmp(key, "patch")) c->opt_patch = value;
+    else return fail(c, HG_ERR_INVALID, std::string("hg_set_option: unknown key ") + key);
+    return HG_OK;
+}
 
 extern "C" int hg_set_timing(hg_ctx *c, int enabled)
 {
@@ -586,6 +597,11 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     const int cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear);
     for (const FrameDesc &d : c->pw_frames) max_w = std::max(max_w, d.obj_w);
     c->pw_row_group = cover <= 56 ? kRowGroup : 1;
+    {   // few rows in total (a single 4K frame has 560 four-row groups for 256 CUs): one row per workgroup fills the chip better
+        int64_t groups = 0;
+        for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + kRowGroup - 1) / kRowGroup;
+        if (groups < c->opt_min_row_groups) c->pw_row_group = 1;
+    }
     // dense rows that still fit the patch kernel's LDS budget, sheared enough for 2-D gather patches to pay (measured: C5,
     // mean shear 0.39, 0.63 -> 0.50 ms; the same mesh without shear 0.35 -> 0.37 ms).  Layout choice only: the kernels check
     // the real counts.
@@ -677,7 +693,8 @@ static int run_setup(hg_ctx *c)
 
 static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
 {
-    static const int force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;        // experiments only: 0 = never, 1 = whenever allowed by size
+    static const int env_force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;    // experiments only: 0 = never, 1 = whenever allowed by size
+    const int force = c->opt_patch >= 0 ? c->opt_patch : env_force;
     int mw = 0;
     for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
     const bool patch = c->pw_fast && !map_out && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force == 1 : c->pw_patch);

@@ -15,9 +15,17 @@ HG = hip.load()
 GOLD = G.load()
 
 
-@pytest.fixture(scope="module")
-def ctx():
+# The piecewise fast path picks a kernel layout from the frame set (rows per workgroup, k_pw_patch for dense sheared meshes);
+# results must not depend on it, so every test that takes `ctx` runs under each layout policy.
+LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0}, "rows1": {"min_row_groups": 1 << 30, "patch": 0},
+           "patch": {"min_row_groups": 0, "patch": 1}}
+
+
+@pytest.fixture(scope="module", params=list(LAYOUTS))
+def ctx(request):
     c = HG.Context(0)
+    for k, v in LAYOUTS[request.param].items():
+        c.set_option(k, v)
     yield c
     c.close()
 
@@ -369,6 +377,7 @@ def test_dense_sheared_mesh_takes_the_patch_kernel():
     k_pw_patch (4-row groups, 2-D gather patches, one matrix record per triangle of the group); a flat dense mesh and a
     sparse mesh stay on k_pw_rows.  All bit-exact against the oracle, three frames with different windows per batch."""
     c = HG.Context(0)
+    c.set_option("min_row_groups", 0)            # (these frame sets are small: without this they would all run one row per workgroup)
     try:
         for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 3), (1600, 150, 56, 3, 0.5, 2), (640, 150, 8, 3, 18.0, 1)]:
             img = G.lcg_image(W, H, 31)
