@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=32, help="frames (destination point sets) per GPU per step")
+    ap.add_argument("--frames", type=int, default=64, help="frames (destination point sets) per GPU per step")
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "C5", "C2", "C5flat"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
