@@ -426,6 +426,47 @@ static int fill_frames(hg_ctx *c, std::vector<FrameDesc> &v, const hg_geom *geom
 }
 
 // ------------------------------------------------------------------------------------------------ affine / projective
+// Can every division (m0*x + m1*y + m2) / (m6*x + m7*y + 1), (m3*x + m4*y + m5) / (same) of this frame be done by
+// div2_plain (hg_kernels.hip), i.e. without the scaling / special-value steps of the full IEEE expansion?
+//   * matrix entries finite, each 0 or 2^-100 <= |m| <= 2^100; pixel coordinates |x|, |y| < 2^28
+//     => numerators are 0 or in [2^-210, 2^130] (a non-zero sum of two such roundings cannot fall below 2^-206);
+//   * the denominator, evaluated in the kernel's own operation order, is weakly monotone along x and along y (every
+//     rounding is), so over the window it lies between its values at the four corners: same sign at all four and
+//     2^-100 <= |den| <= 2^130 there => the same holds at every pixel.
+static bool geo_plain_division(const double *m, const hg_geom &g)
+{
+    const double lo = 0x1p-100, hi = 0x1p100;
+    for (int k = 0; k < 8; k++) {
+        const double a = std::fabs(m[k]);
+        if (!(a == a) || !(a == 0.0 || (a >= lo && a <= hi))) return false;
+    }
+    if (g.obj_w <= 0 || g.obj_h <= 0) return true;
+    const int64_t x0 = g.x_off, x1 = (int64_t)g.x_off + g.obj_w + 255, y0 = g.y_off, y1 = (int64_t)g.y_off + g.obj_h - 1;   // (+255: the ragged last window is computed too)
+    if (std::max(std::llabs(x0), std::llabs(x1)) >= (1ll << 28) || std::max(std::llabs(y0), std::llabs(y1)) >= (1ll << 28)) return false;
+    double dmin = INFINITY, dmax = -INFINITY;
+    for (int64_t y : {y0, y1}) for (int64_t x : {x0, x1}) {
+        const double ad = m[7] * (double)y;
+        const double den = ((m[6] * (double)x) + ad) + 1.0;                  // :1402-1403, the kernel's order
+        dmin = std::min(dmin, den); dmax = std::max(dmax, den);
+    }
+    if (!(dmin == dmin) || !(dmax == dmax)) return false;
+    if (dmin > 0) return dmin >= lo && dmax <= 0x1p130;
+    if (dmax < 0) return -dmax >= lo && -dmin <= 0x1p130;
+    return false;
+}
+
+extern "C" int hg_selftest_division(hg_ctx *c, uint64_t samples, uint64_t seed, uint64_t *mismatches)
+{
+    HG_TRY(bind(c));
+    if (!mismatches) return fail(c, HG_ERR_INVALID, "mismatches is NULL");
+    unsigned long long *d = nullptr;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&d), sizeof(unsigned long long)));
+    *mismatches = run_selftest_division(seed, samples, d, c->stream);
+    HIP_TRY(c, hipFree(d));
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
 extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, const hg_geom *geoms, const size_t *offs, int n)
 {
     HG_TRY(bind(c));
@@ -442,7 +483,11 @@ extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, con
         for (int k = 0; k < 6; k++) exact = exact && (double)(float)m[8 * f + k] == m[8 * f + k];
         exact = exact && std::abs((int64_t)geoms[f].x_off) + std::max(geoms[f].obj_w, 0) < (1 << 28);
     }
-    c->geo_f32_exact = exact;
+    if (kind == HG_PROJECTIVE) {
+        exact = true;
+        for (int f = 0; f < n && exact; f++) exact = geo_plain_division(m + 8 * f, geoms[f]);
+    }
+    c->geo_f32_exact = exact;                               // projective: "every division of the frame set is in the plain range"
     return HG_OK;
 }
 

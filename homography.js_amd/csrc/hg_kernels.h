@@ -93,6 +93,9 @@ void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream
 // f32_exact: every affine matrix entry is a float value and |x| < 2^28 (lets the kernel use an exact-product fma).
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
                 const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
+// (f32_exact doubles as "plain division range proved" for kind 1: see geo_plain_division() in hg_api.hip)
+// div2_plain vs IEEE division on `samples` pseudo-random operand triples; returns the number of mismatching quotients
+unsigned long long run_selftest_division(uint64_t seed, uint64_t samples, unsigned long long *d_counter, hipStream_t stream);
 
 // Forward (scatter) paths, SURVEY.md §8f-1: winner buffer `win` = obj_w*obj_h int32 scratch.
 void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, int H, const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);

@@ -822,11 +822,59 @@ __global__ __launch_bounds__(256) void k_geo(const FrameDesc *__restrict__ frame
     store_quad(orow, cq, OW, vec_ok, px);
 }
 
+// nx / d and ny / d, IEEE-754 double, for operands in the PLAIN range: finite, d != 0, magnitudes such that the hardware
+// division expansion would neither pre-scale its operands (v_div_scale) nor patch the result (v_div_fixup) -- the host
+// proves that per frame (geo_plain_division()).  There the expansion is: r = rcp(d); two Newton steps on r; q = n * r;
+// one correction q + (n - d*q) * r.  This is that very sequence with the reciprocal computed once for both quotients, so
+// the results are the same bits as `nx / d`, `ny / d` (k_selftest_division compares them over the whole plain range).
+__device__ __forceinline__ void div2_plain(double nx, double ny, double d, double &qx, double &qy)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    const double q0 = nx * r, q1 = ny * r;
+    qx = fma(fma(-d, q0, nx), r, q0);
+    qy = fma(fma(-d, q1, ny), r, q1);
+}
+
+// Self-test of div2_plain against the compiler's IEEE division on pseudo-random operands of the plain range (exponents of d
+// in [-100, 130], of n in [-210, 130] or n == 0, random signs and mantissas, plus mantissa edge patterns).
+__global__ void k_selftest_division(uint64_t seed, uint64_t n_per_thread, unsigned long long *mismatches)
+{
+    uint64_t s = seed ^ ((uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull);
+    auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s * 0x2545F4914F6CDD1Dull; };
+    auto make = [&](int emin, int emax, bool allow_zero) {
+        const uint64_t a = next(), b = next();
+        if (allow_zero && (a & 63) == 0) return (a & 64) ? -0.0 : 0.0;
+        uint64_t mant = b & 0xFFFFFFFFFFFFFull;
+        switch ((a >> 8) & 7) {                              // edge mantissas: all zeros, all ones, single bits
+        case 0: mant = 0; break;
+        case 1: mant = 0xFFFFFFFFFFFFFull; break;
+        case 2: mant = 1ull << ((a >> 12) % 52); break;
+        case 3: mant = 0xFFFFFFFFFFFFFull ^ (1ull << ((a >> 12) % 52)); break;
+        default: break;
+        }
+        const int e = emin + (int)((a >> 20) % (uint64_t)(emax - emin + 1));
+        const uint64_t bits = ((a >> 63) << 63) | ((uint64_t)(e + 1023) << 52) | mant;
+        return __longlong_as_double((long long)bits);
+    };
+    unsigned long long bad = 0;
+    for (uint64_t i = 0; i < n_per_thread; i++) {
+        const double d = make(-100, 130, false), nx = make(-210, 130, true), ny = make(-210, 130, true);
+        double qx, qy;
+        div2_plain(nx, ny, d, qx, qy);
+        const double rx = nx / d, ry = ny / d;
+        if (!(qx == rx) || !(qy == ry)) bad++;               // (== : +0 equals -0, the sign of a zero never reaches a pixel)
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // k_geo_fast: same loop with the k_pw_rows pixel body (requirements checked by geo_fast_ok(): source < 2^31 bytes).
 //   * lane l owns pixels c0 + l + 64k of its row: a gather instruction covers 64 consecutive output pixels;
 //   * row-constant terms are computed once per lane: fl(m1*y), fl(m4*y), fl(m7*y) (projective) / fl(m2*y), fl(m3*y) (affine);
 //   * affine: the matrix holds f32 values, m0*x is exact in fp64, so fma(m0, x, fl(m2*y)) rounds exactly where JS does;
-//     projective: the matrix is full double, every product rounds: plain mul/add and two IEEE divides per pixel;
+//     projective: the matrix is full double, every product rounds: plain mul/add and two IEEE divides per pixel (KIND 1),
+//     or div2_plain when the host has shown that no pixel of the frame set leaves the plain range (KIND 3);
 //   * Math.round + bounds :1001 via two round-toward-minus-infinity adds per coordinate (round_x8), source through a
 //     range-checked buffer load (0 outside the array), stores through a per-row buffer descriptor (no tail guards).
 template <int KIND>
@@ -868,8 +916,9 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
         for (int k = 0; k < 4; k++) {
             const double x = (double)(c0 + lane + k * 64 + fd.x_off);
             const double den = ((m[6] * x) + ad) + 1.0;
-            h[2 * k] = (((m[0] * x) + ax) + m[2]) / den;
-            h[2 * k + 1] = (((m[3] * x) + ay) + m[5]) / den;
+            const double nx = ((m[0] * x) + ax) + m[2], ny = ((m[3] * x) + ay) + m[5];
+            if (KIND == 3) div2_plain(nx, ny, den, h[2 * k], h[2 * k + 1]);     // same bits, one reciprocal (host-proved range)
+            else { h[2 * k] = nx / den; h[2 * k + 1] = ny / den; }
         }
     }
     round_x8(h, rd);
@@ -1044,13 +1093,25 @@ void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double 
     dim3 grid((max_w + 255) / 256, (max_h + 3) / 4, n_frames);
     const bool fast = ((int64_t)H + 2) * W * 4 < ((int64_t)1 << 31) && W < (1 << 21) && H < (1 << 22) && max_w < (1 << 28);
     if (fast) {
-        if (kind == 1)      hipLaunchKernelGGL(k_geo_fast<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+        if (kind == 1 && f32_exact) hipLaunchKernelGGL(k_geo_fast<3>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+        else if (kind == 1) hipLaunchKernelGGL(k_geo_fast<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
         else if (f32_exact) hipLaunchKernelGGL(k_geo_fast<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
         else                hipLaunchKernelGGL(k_geo_fast<2>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
         return;
     }
     if (kind == 0) hipLaunchKernelGGL(k_geo<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
     else           hipLaunchKernelGGL(k_geo<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+}
+
+unsigned long long run_selftest_division(uint64_t seed, uint64_t samples, unsigned long long *d_counter, hipStream_t stream)
+{
+    const uint64_t threads = 256ull * 1024ull, per = (samples + threads - 1) / threads;
+    unsigned long long h = ~0ull;                            // (stays "all wrong" if any step fails)
+    if (hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), stream) != hipSuccess) return h;
+    hipLaunchKernelGGL(k_selftest_division, dim3(1024), dim3(256), 0, stream, seed, per, d_counter);
+    if (hipMemcpyAsync(&h, d_counter, sizeof h, hipMemcpyDeviceToHost, stream) != hipSuccess) return ~0ull;
+    if (hipStreamSynchronize(stream) != hipSuccess) return ~0ull;
+    return h;
 }
 
 void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, int H, const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream)

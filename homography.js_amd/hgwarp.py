@@ -31,7 +31,7 @@ EXPORTS = [
     "hg_piecewise_set_frames", "hg_warp_inverse_piecewise_frames_device", "hg_warp_inverse_piecewise_batch_device",
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
     "hg_warp_forward_geometric", "hg_warp_forward_piecewise",
-    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_set_option",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_set_option", "hg_selftest_division",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
         "hg_get_tri_map": (i, [vp, C.POINTER(C.c_int16), sz]), "hg_get_tri_map_fused": (i, [vp, C.POINTER(C.c_int16), sz]),
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
         "hg_last_piecewise_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]),
+        "hg_selftest_division": (i, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
         "hg_kernel_ms_stats": (i, [vp, f64p, C.POINTER(i)]),
         "hg_warp_forward_geometric": (i, [vp, i, f64p, Geom, u8p]),
@@ -247,6 +248,12 @@ class Context:
     def set_option(self, key, value):
         """Layout knobs of the piecewise fast path ("min_row_groups", "patch"); results never depend on them."""
         self._c(lib().hg_set_option(self._h, key.encode(), int(value)))
+
+    def selftest_division(self, samples, seed=1):
+        """Mismatches between the shared-reciprocal division of the projective kernel and IEEE division (must be 0)."""
+        bad = C.c_uint64(0)
+        self._c(lib().hg_selftest_division(self._h, int(samples), int(seed), C.byref(bad)))
+        return bad.value
 
     def kernel_ms_stats(self):
         """(total ms, launches) of the dominant kernel since set_timing(True)."""

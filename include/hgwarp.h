@@ -171,6 +171,9 @@ int hg_last_piecewise_kernel(hg_ctx *ctx);
  *   "min_row_groups" (default 1536): frame sets with fewer 4-row groups run one row per workgroup;
  *   "patch" (default -1 = by estimate): 0 never use k_pw_patch, 1 use it whenever the frame width allows. */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);
+/* Self-test of the projective kernels' shared-reciprocal division against IEEE division on `samples` pseudo-random
+ * operand triples drawn from the range the host admits it for; *mismatches must come back 0. */
+int hg_selftest_division(hg_ctx *ctx, uint64_t samples, uint64_t seed, uint64_t *mismatches);
 /* ------------------------------------------------------------------------------------------------ measurement aid
  * hipEvent pairs recorded on the ctx stream around each launch of the dominant kernel (the fused piecewise kernel or
  * the geometric kernel; not the tiny per-triangle setup).  hg_set_timing(ctx, 1) enables it and resets the counters;

@@ -437,3 +437,14 @@ def test_patch_kernel_limits_fall_back_and_stay_off():
             c.free(d_out)
     finally:
         c.close()
+
+
+def test_shared_reciprocal_division_is_ieee_division():
+    """The projective kernel divides both numerators by one refined reciprocal when the host has shown the frame's operands
+    stay in the plain range; that sequence must give the bits of IEEE division there: 2^29 random / edge-mantissa triples."""
+    c = HG.Context(0)
+    try:
+        assert c.selftest_division(1 << 29, seed=20260928) == 0
+        assert c.selftest_division(1 << 26, seed=7) == 0
+    finally:
+        c.close()
