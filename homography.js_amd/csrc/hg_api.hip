@@ -62,6 +62,7 @@ struct hg_ctx {
     bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
     bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
+    long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
     int opt_min_row_groups = 1536, opt_patch = -1;             // hg_set_option()
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
@@ -215,6 +216,8 @@ extern "C" int hg_copy_to_host(hg_ctx *c, void *dst, const void *src, size_t byt
 }
 
 extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kernel : 0; }
+
+extern "C" long hg_redone_frames(hg_ctx *c) { return c ? c->pw_redone : 0; }
 
 extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
 {
@@ -651,6 +654,7 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     // mean shear 0.39, 0.63 -> 0.50 ms; the same mesh without shear 0.35 -> 0.37 ms).  Layout choice only: the kernels check
     // the real counts.
     c->pw_patch = cover > 56 && cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW &&
+                  (int64_t)cover * 64 <= (int64_t)8 * max_w &&          // spans per 64-pixel bin ~ cover * 64 / width: overfull bins are slow
                   shear >= 0.2 && !c->pw_patch_disabled;
     c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
@@ -808,7 +812,7 @@ extern "C" int hg_sync(hg_ctx *c)
         if (c->status_base) HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
         for (const hg_ctx::Pending &p : pending)
             for (size_t f = 0; f < F; f++)
-                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) { redo = true; HG_TRY(run_frame_via_map(c, (int)f, p.out)); }
+                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; HG_TRY(run_frame_via_map(c, (int)f, p.out)); }
         if (redo) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->pw_used_patch) c->pw_patch_disabled = true;   // (its limits are tighter than k_pw_rows': do not pay the map path again)

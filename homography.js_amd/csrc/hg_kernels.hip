@@ -559,7 +559,8 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
 // fp64 multiply per coordinate, rounded exactly where the reference rounds them).  The span lookup is per lane (lanes of
 // a wave sit on four different rows), through per-(row, 64-pixel column) bins of span indices built in LDS.
 // Limits (host picks the kernel from its estimate; a group that exceeds one flags the frame -> map path, and the context
-// stops using this kernel): <= 199 spans per row, <= 208 triangles per 4-row group, <= 8 spans per bin, obj_w <= 8192.
+// stops using this kernel): <= 199 spans per row, <= 208 triangles per 4-row group, obj_w <= 8192.  A bin with more than
+// 8 spans is handled inside the kernel (the block tests the row's whole list).
 constexpr int kPatchRows = 4, kPatchCap = 200, kPatchRecs = 208, kPatchBins = 128, kPatchBinSlots = 8, kPatchHash = 1024, kPatchTilePitch = 68;
 // (sized so that six workgroups fit a CU's 160 KB of LDS: 26.9 KB each)
 static_assert(kPatchHash * 4 <= kPatchRows * kPatchBins * kPatchBinSlots, "the hash table lives in the bin-slot area");
@@ -650,9 +651,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             const uint32_t lh = s_lohi[e];
             const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
             for (int b = lo >> 6; b <= (hi - 1) >> 6 && b < nbins; b++) {
-                const int pos = atomicAdd(&s_bincnt[rr * kPatchBins + b], 1);
+                const int pos = atomicAdd(&s_bincnt[rr * kPatchBins + b], 1);          // (a count beyond the slots marks the bin as overfull)
                 if (pos < kPatchBinSlots) s_bin[(rr * kPatchBins + b) * kPatchBinSlots + pos] = (uint8_t)i;
-                else s_fail = 1;
             }
         }
     }
@@ -678,23 +678,36 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     const int pitch4 = mesh.W * 4;
     const int nan_key = (int)0x80000000u | (kPatchRecs * 48);
     const int row_base = rr * kPatchCap;
+    const int my_cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
     uint32_t *tile = s_tile + wave * (kPatchRows * kPatchTilePitch);
 
     for (int cw = wave; cw < nbins; cw += 4) {              // this wave's 64-pixel-wide column blocks, all 4 rows at once
         const int c0 = cw << 6;                             // pixel k of the lane: (c0 + ck[k], r0 + rr)
         int best[4] = { nan_key, nan_key, nan_key, nan_key };
         const int bidx = rr * kPatchBins + cw;
-        const int nb = min(s_bincnt[bidx], kPatchBinSlots);
+        const int nb = s_bincnt[bidx];
         const uint8_t *bin = s_bin + bidx * kPatchBinSlots;
-        for (int p = 0; __any(p < nb); p++) {
-            int lo = 0, len = 0, key = 0;                   // len 0: no pixel passes the span test
-            if (p < nb) {
-                const int e = row_base + bin[p];
-                const uint32_t lh = s_lohi[e];
-                lo = (int)(lh & 0xffffu); len = (int)(lh >> 16) - lo; key = s_key[e];
+        if (!__any(nb > kPatchBinSlots)) {
+            for (int p = 0; __any(p < nb); p++) {
+                int lo = 0, len = 0, key = 0;               // len 0: no pixel passes the span test
+                if (p < nb) {
+                    const int e = row_base + bin[p];
+                    const uint32_t lh = s_lohi[e];
+                    lo = (int)(lh & 0xffffu); len = (int)(lh >> 16) - lo; key = s_key[e];
+                }
+                const int d = c0 - lo;
+                span_max4d(best, d + ck[0], d + ck[1], d + ck[2], d + ck[3], len, key);     // larger id wins (== last writer of :852-858)
             }
-            const int d = c0 - lo;
-            span_max4d(best, d + ck[0], d + ck[1], d + ck[2], d + ck[3], len, key);     // larger id wins (== last writer of :852-858)
+        } else {                                            // more spans in one 64-pixel bin than it has slots (slivers): test the
+            for (int i = 0; __any(i < my_cnt); i++) {       // row's whole list for this block -- slow, exact, rare
+                int lo = 0, len = 0, key = 0;
+                if (i < my_cnt) {
+                    const uint32_t lh = s_lohi[row_base + i];
+                    lo = (int)(lh & 0xffffu); len = (int)(lh >> 16) - lo; key = s_key[row_base + i];
+                }
+                const int d = c0 - lo;
+                span_max4d(best, d + ck[0], d + ck[1], d + ck[2], d + ck[3], len, key);
+            }
         }
         double h[8], rd[8];
 #pragma unroll

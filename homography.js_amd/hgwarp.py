@@ -31,7 +31,7 @@ EXPORTS = [
     "hg_piecewise_set_frames", "hg_warp_inverse_piecewise_frames_device", "hg_warp_inverse_piecewise_batch_device",
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
     "hg_warp_forward_geometric", "hg_warp_forward_piecewise",
-    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_set_option", "hg_selftest_division",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_redone_frames", "hg_set_option", "hg_selftest_division",
 ]
 
 
@@ -80,7 +80,7 @@ def lib():
         "hg_warp_inverse_piecewise_batch_device": (i, [vp, f32p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
         "hg_get_tri_map": (i, [vp, C.POINTER(C.c_int16), sz]), "hg_get_tri_map_fused": (i, [vp, C.POINTER(C.c_int16), sz]),
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
-        "hg_last_piecewise_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]),
+        "hg_last_piecewise_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]),
         "hg_selftest_division": (i, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
         "hg_kernel_ms_stats": (i, [vp, f64p, C.POINTER(i)]),
@@ -244,6 +244,10 @@ class Context:
     def last_piecewise_kernel(self):
         """0 none, 1 k_pw_rows (4-row groups), 2 k_pw_rows (1 row), 3 k_pw_patch, 4 k_pw_fused."""
         return lib().hg_last_piecewise_kernel(self._h)
+
+    def redone_frames(self):
+        """Frames redone through the materialised map since the context was created."""
+        return lib().hg_redone_frames(self._h)
 
     def set_option(self, key, value):
         """Layout knobs of the piecewise fast path ("min_row_groups", "patch"); results never depend on them."""

@@ -166,6 +166,9 @@ int hg_warp_forward_piecewise(hg_ctx *ctx, const float *dst_points, int max_src_
 /* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
  * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general). */
 int hg_last_piecewise_kernel(hg_ctx *ctx);
+/* Frames the fused kernels only flagged (row lists / kernel limits exceeded, irregular spans) and hg_sync redid through the
+ * materialised map, since the ctx was created (tests / profiling: a steady-state workload should show 0). */
+long hg_redone_frames(hg_ctx *ctx);
 /* Layout knobs of the piecewise fast path; they never change results (tests run the parity suite under each setting), only
  * which kernel layout the next hg_piecewise_set_frames picks:
  *   "min_row_groups" (default 1536): frame sets with fewer 4-row groups run one row per workgroup;

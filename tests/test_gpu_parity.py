@@ -396,6 +396,7 @@ def test_dense_sheared_mesh_takes_the_patch_kernel():
                     c.warp_inverse_piecewise_frames_device(d_out)
                 c.sync()
                 assert c.last_piecewise_kernel() == want_kernel, (nx, A, c.last_piecewise_kernel())
+                assert c.redone_frames() == 0                 # nothing went through the map-path fallback
                 for f, g in enumerate(geoms):
                     got = c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
                     assert np.array_equal(got, O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *g)), (nx, A, f)
@@ -406,37 +407,45 @@ def test_dense_sheared_mesh_takes_the_patch_kernel():
 
 
 def test_patch_kernel_limits_fall_back_and_stay_off():
-    """56 triangle columns squeezed into 300 pixels: ~150 spans per row (inside k_pw_patch's budget, so the host picks it) but
-    ~30 per 64-pixel bin (beyond its 8): the kernel only flags the frames, hg_sync redoes them through the materialised map,
-    and the context then stays on k_pw_rows."""
-    c = HG.Context(0)
-    try:
-        W, H, nx, ny, A = 300, 120, 56, 3, 6.0
-        img = G.lcg_image(W, H, 41)
-        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
-        frames = [WL.sin_dst(sp, A, 8 + f) for f in range(2)]
-        geoms = [WL.piecewise_geom(d) for d in frames]
-        ms = WL.src_min(sp)
-        want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(2)]
-        c.set_image(img)
-        c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
-        offs, total = HG.pack_offsets(geoms)
-        d_out = c.alloc(total)
+    """(a) 56 triangle columns squeezed into 300 pixels: ~150 spans per row but ~30 per 64-pixel bin, beyond the 8 slots of
+    k_pw_patch's bins: handled inside the kernel (those blocks test the row's whole list), no fallback.  (b) 110 columns:
+    ~220 spans per row, beyond its LDS budget: the kernel only flags the frames, hg_sync redoes them through the
+    materialised map, and the context then stays on k_pw_rows.  The host's estimates would keep both meshes on k_pw_rows,
+    so the patch kernel is forced."""
+    for nx, expect_redone in ((56, False), (110, True)):
+        c = HG.Context(0)
+        c.set_option("patch", 1)
+        c.set_option("min_row_groups", 0)
         try:
-            kernels = []
-            for _ in range(2):
-                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
-                c.warp_inverse_piecewise_frames_device(d_out)
-                c.sync()
-                kernels.append(c.last_piecewise_kernel())
-                for f, g in enumerate(geoms):
-                    got = c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
-                    assert np.array_equal(got, want[f]), f
-            assert kernels == [3, 2], kernels
+            W, H, ny, A = 300, 120, 3, 6.0
+            img = G.lcg_image(W, H, 41)
+            sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+            frames = [WL.sin_dst(sp, A, 8 + f) for f in range(2)]
+            geoms = [WL.piecewise_geom(d) for d in frames]
+            ms = WL.src_min(sp)
+            want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(2)]
+            c.set_image(img)
+            c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+            offs, total = HG.pack_offsets(geoms)
+            d_out = c.alloc(total)
+            try:
+                kernels = []
+                for _ in range(2):
+                    c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                    c.warp_inverse_piecewise_frames_device(d_out)
+                    c.sync()
+                    kernels.append(c.last_piecewise_kernel())
+                    for f, g in enumerate(geoms):
+                        got = c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                        assert np.array_equal(got, want[f]), (nx, f)
+                if expect_redone:
+                    assert kernels[0] == 3 and kernels[1] in (1, 2) and c.redone_frames() == 2, (kernels, c.redone_frames())
+                else:
+                    assert kernels == [3, 3] and c.redone_frames() == 0, (kernels, c.redone_frames())
+            finally:
+                c.free(d_out)
         finally:
-            c.free(d_out)
-    finally:
-        c.close()
+            c.close()
 
 
 def test_shared_reciprocal_division_is_ieee_division():
