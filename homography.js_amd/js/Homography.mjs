@@ -80,6 +80,11 @@ class Homography {
         // before asking for the next one.  Default false: a fresh array per call, like the reference (:991, :1040).
         this.reuseOutput = options.reuseOutput === true;
         this._outBuffer = null;
+        // Opt-in (not in the reference): the caller promises not to mutate `image.data` between warps, so the source is
+        // uploaded once per setImage() / context instead of on every warp().  Default false: the reference aliases the
+        // caller's buffer and re-reads it on every warp (:298), so a mutated buffer must show up.
+        this.staticImage = options.staticImage === true;
+        this._uploadedImage = null;
         this._ctxHandle = null;                                 // GPU context, created at the first warp
     }
 
@@ -131,6 +136,7 @@ class Homography {
             throw ("hgwarp: setImage() needs an ImageData-shaped {data: Uint8ClampedArray, width, height}; HTMLImageElement inputs need a browser DOM");
         }
         this._image = image.data;                               // aliased, not copied (:298): re-read (re-uploaded) on every warp()
+        this._uploadedImage = null;                             // (staticImage: an explicit setImage always uploads)
         this._setSourceSize(image.width, image.height);
         if (this._srcPoints !== null && this.transform === 'piecewiseaffine') this._refreshPiecewise();
         if (this._dstPoints !== null && (this._objectiveWidth <= 0 || this._objectiveHeight <= 0)) this._deriveOutputWindow();
@@ -334,8 +340,12 @@ class Homography {
     }
 
     _uploadImage() {
-        // The reference re-reads the caller's buffer on every warp (:298), so a mutated buffer must show up: upload every time.
-        this._native.setImage(this._ctx, this._image, this._width, this._height);
+        // The reference re-reads the caller's buffer on every warp (:298), so a mutated buffer must show up: upload every time
+        // (unless the caller opted into `staticImage`).
+        const ctx = this._ctx;
+        if (this.staticImage && this._uploadedImage === this._image && this._uploadedCtx === ctx) return;
+        this._native.setImage(ctx, this._image, this._width, this._height);
+        this._uploadedImage = this._image; this._uploadedCtx = ctx;
     }
 
     _uploadMesh() {

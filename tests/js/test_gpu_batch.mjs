@@ -57,6 +57,17 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     p.setReferencePoints([[0, 0], [0, 1], [1, 0], [1, 1]], [[1 / 10, 1 / 2], [0, 1], [9 / 10, 1 / 2], [1, 1]]);
     ok(sha(p.warp(img2).data) === sha(o1.data), 'reuseOutput projective differs');
     r.close(); p.close();
+    // opt-in staticImage: same bytes without re-uploading; a mutation of the buffer is then (by contract) not seen until setImage
+    const simg = lcgImage(W, H, 21);
+    const q = new Homography('piecewiseaffine', null, null, { staticImage: true });
+    q.setSourcePoints(src, simg, W, H, false);
+    q.setDestinyPoints(sets[1], false);
+    ok(sha(q.warp(null, false, true).data) === sha(single[1].data), 'staticImage frame differs');
+    simg.data.fill(9);
+    ok(sha(q.warp(null, false, true).data) === sha(single[1].data), 'staticImage: the cached source should still be in use');
+    q.setImage(simg);
+    ok(q.warp(null, false, true).data.every((v) => v === 9 || v === 0), 'staticImage: setImage() must upload the new content');
+    q.close();
 }
 h.close(); g.close();
 ok((() => { try { h.warp(); return true; } catch (e) { return false; } })(), 'warp after close() re-creates the context');
