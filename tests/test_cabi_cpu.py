@@ -104,6 +104,19 @@ def test_triangulate_is_delaunay_and_matches_scipy_on_generic_points():
         mine = {tuple(sorted(x)) for x in t.reshape(-1, 3).tolist()}
         ref = {tuple(sorted(x)) for x in Delaunay(P.astype(np.float64)).simplices.tolist()}
         assert mine == ref
+    # scale: the same triangle set as Qhull on 20 000 points, in well under a second (adjacency-based insertion)
+    P = (rng.random((20000, 2)) * [4000, 3000]).astype(np.float32)
+    t = HG.triangulate(P.ravel())
+    assert {tuple(sorted(x)) for x in t.reshape(-1, 3).tolist()} == {tuple(sorted(x)) for x in Delaunay(P.astype(np.float64)).simplices.tolist()}
+    # co-circular inputs: a lattice is covered exactly, a circle + centre (+ duplicates) gives the fan
+    g = np.stack(np.meshgrid(np.arange(60) * 7.0, np.arange(40) * 5.0), -1).reshape(-1, 2).astype(np.float32)
+    tri = g[HG.triangulate(g.ravel()).reshape(-1, 3)].astype(np.float64)
+    area = 0.5 * np.abs((tri[:, 1, 0] - tri[:, 0, 0]) * (tri[:, 2, 1] - tri[:, 0, 1]) - (tri[:, 2, 0] - tri[:, 0, 0]) * (tri[:, 1, 1] - tri[:, 0, 1]))
+    assert tri.shape[0] == 2 * 59 * 39 and area.min() > 0 and abs(area.sum() - 59 * 7 * 39 * 5) < 1e-6
+    th = np.linspace(0, 2 * np.pi, 500, endpoint=False)
+    circ = np.stack([np.cos(th), np.sin(th)], 1) * 1000 + 1500
+    circ = np.vstack([circ, [[1500, 1500]], circ[:50]]).astype(np.float32)
+    assert HG.triangulate(circ.ravel()).size // 3 == 500
     assert HG.triangulate(np.array([0, 0, 1, 1], np.float32)).size == 0                 # fewer than 3 points
     assert HG.triangulate(np.array([0, 0, 1, 1, 2, 2], np.float32)).size == 0           # collinear
     with pytest.raises(HG.HgError):
