@@ -658,6 +658,7 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
                   shear >= 0.2 && !c->pw_patch_disabled;
     c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
+    if (cover > 200 && c->row_cap < kRowSpanCapDense) c->row_cap = kRowSpanCapDense;
     c->rows_clean = false;                                   // new geometry: the counter layout changes
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pw_setup_done = false;
@@ -816,7 +817,8 @@ extern "C" int hg_sync(hg_ctx *c)
         if (redo) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->pw_used_patch) c->pw_patch_disabled = true;   // (its limits are tighter than k_pw_rows': do not pay the map path again)
-            if (c->pw_fast && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // denser mesh than assumed: larger lists next time
+            if (c->pw_fast && c->row_cap < kRowSpanCapDense)      // denser mesh than assumed: larger lists next time
+                c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
         }
     }
     const int d = c->deferred;

@@ -28,6 +28,7 @@ enum : int32_t {
 
 constexpr int kRowSpanCap = 1024;   // spans per output row held in LDS by the general fused kernel (k_pw_fused)
 constexpr int kRowSpanCapFast = 256; // ... by the fast kernel (k_pw_rows), which also keeps a 48-byte matrix per span
+constexpr int kRowSpanCapDense = 512; // ... by its dense instantiation (README-scale meshes: ~23 000 triangles, 200-500 spans per row)
 constexpr int kRowGroup = 4;            // output rows per k_pw_rows workgroup (64 LDS slots each in packed mode)
 constexpr int kInvStride = 8;       // floats per inverse matrix on the device (6 used; 32-byte rows)
 

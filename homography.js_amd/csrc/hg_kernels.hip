@@ -407,8 +407,10 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_m[CAP * 6];
-    __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (kKeyShift)
-    static_assert(CAP == 64 * kRowGroup, "packed mode gives each of the 4 rows a 64-slot block");
+    __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (KS)
+    static_assert(CAP >= 64 * kRowGroup, "packed mode gives each of the 4 rows a 64-slot block");
+    constexpr int KS = CAP * 48 <= (1 << kKeyShift) ? kKeyShift : kKeyShift + 1, KMASK = (1 << KS) - 1;   // id << KS | record offset
+    static_assert(CAP * 48 <= (1 << KS) && KS <= 15, "record offsets must fit below the 15-bit id");
 
     const int W = fd.obj_w;
     const int lane = threadIdx.x & 63;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
             const uint4 a = reinterpret_cast<const uint4 *>(ent + i)[0];
             const uint4 b = reinterpret_cast<const uint4 *>(ent + i)[1];
             const int elo = (int)(a.x & 0xffffu), ehi = (int)(a.x >> 16);
-            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)a.y << kKeyShift) | ((base + i) * 48);
+            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)a.y << KS) | ((base + i) * 48);
             const double m0 = (double)__uint_as_float(a.z), m1 = (double)__uint_as_float(a.w), m2 = (double)__uint_as_float(b.x),
                          m3 = (double)__uint_as_float(b.y), m4 = (double)__uint_as_float(b.z), m5 = (double)__uint_as_float(b.w);
             double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
                 double h[8], rd[8];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & kKeyOffMask));
+                    const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KMASK));
                     const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
                     // (ABL & 16, timing experiment only: the access pattern of a 16 px x 4 row lane patch instead of 64 px x 1 row)
                     const double xd = (ABL & 16) ? (double)(c0 + (lane & 15) + 16 * k + fd.x_off) : xd0 + (double)(k * 64);     // exact: integers far below 2^53
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
             if (MAP) {                                      // parity tap (hg_get_tri_map_fused): a separate instantiation
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (cq + k * 64 < W) map_out[fd.map_off + row_px + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> kKeyShift);
+                    if (cq + k * 64 < W) map_out[fd.map_off + row_px + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> KS);
             }
             xd0 += xstep;
         }
@@ -1060,6 +1062,11 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
     const int rpx = ((fr.max_obj_h + rg - 1) / rg + 7) / 8;                     // row groups per XCD band
     dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
+    if (rl.cap > kRowSpanCapFast) {                          // very dense meshes: 512 LDS slots per row (32 KB), one row per workgroup
+        if (map_out) hipLaunchKernelGGL((k_pw_rows<kRowSpanCapDense, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next);
+        else         hipLaunchKernelGGL((k_pw_rows<kRowSpanCapDense, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next);
+        return;
+    }
     if (map_out) { hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return; }
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;      // experiments only
     switch (abl) {
