@@ -458,6 +458,11 @@ static bool geo_plain_division(const double *m, const hg_geom &g)
     return false;
 }
 
+extern "C" int hg_projective_plain_range(const double *m, hg_geom geom)
+{
+    return (m && geo_plain_division(m, geom)) ? 1 : 0;
+}
+
 extern "C" int hg_selftest_division(hg_ctx *c, uint64_t samples, uint64_t seed, uint64_t *mismatches)
 {
     HG_TRY(bind(c));

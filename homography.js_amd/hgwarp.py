@@ -31,7 +31,7 @@ EXPORTS = [
     "hg_piecewise_set_frames", "hg_warp_inverse_piecewise_frames_device", "hg_warp_inverse_piecewise_batch_device",
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
     "hg_warp_forward_geometric", "hg_warp_forward_piecewise",
-    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_redone_frames", "hg_set_option", "hg_selftest_division",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_redone_frames", "hg_set_option", "hg_selftest_division", "hg_projective_plain_range",
 ]
 
 
@@ -82,6 +82,7 @@ def lib():
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
         "hg_last_piecewise_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]),
         "hg_selftest_division": (i, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "hg_projective_plain_range": (i, [f64p, Geom]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
         "hg_kernel_ms_stats": (i, [vp, f64p, C.POINTER(i)]),
         "hg_warp_forward_geometric": (i, [vp, i, f64p, Geom, u8p]),
@@ -150,6 +151,12 @@ def minmax_xy(pts):
     out = np.empty(4, np.float64)
     _check(lib().hg_minmax_xy(p, a.size, out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
+
+
+def projective_plain_range(m, geom):
+    """True if the projective kernel may use its shared-reciprocal division for this frame (host-side range proof)."""
+    a = np.ascontiguousarray(m, np.float64)
+    return bool(lib().hg_projective_plain_range(a.ctypes.data_as(C.POINTER(C.c_double)), Geom(*[int(v) for v in geom])))
 
 
 def js_round(x):

@@ -174,6 +174,10 @@ long hg_redone_frames(hg_ctx *ctx);
  *   "min_row_groups" (default 1536): frame sets with fewer 4-row groups run one row per workgroup;
  *   "patch" (default -1 = by estimate): 0 never use k_pw_patch, 1 use it whenever the frame width allows. */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);
+/* Host-side proof obligation of that division (no GPU needed): 1 if every pixel of the window `geom` under the inverse
+ * projective matrix m[8] keeps numerators and denominator in the plain range (entries 0 or in [2^-100, 2^100], coordinates
+ * below 2^28, denominator of one sign and in [2^-100, 2^130] at the four corners), else 0 (-> IEEE divides in the kernel). */
+int hg_projective_plain_range(const double *m, hg_geom geom);
 /* Self-test of the projective kernels' shared-reciprocal division against IEEE division on `samples` pseudo-random
  * operand triples drawn from the range the host admits it for; *mismatches must come back 0. */
 int hg_selftest_division(hg_ctx *ctx, uint64_t samples, uint64_t seed, uint64_t *mismatches);

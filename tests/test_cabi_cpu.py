@@ -134,3 +134,20 @@ def test_c4_face_mesh_workload():
     frames = WL.face_frames(sp, W, 8)
     assert len(frames) == 8 and all(f.dtype == np.float32 and f.size == 136 for f in frames)
     assert np.abs(frames[0].reshape(-1, 2) - sp.reshape(-1, 2)).max() <= 0.02 * W + 1e-3
+
+
+def test_projective_plain_range_classification():
+    """Which projective frames may use the shared-reciprocal division (host-side proof, no GPU): ordinary homographies yes;
+    a horizon (denominator changing sign) inside the window, non-finite or denormal-scale entries, absurd windows no."""
+    g = (0, 0, 1920, 1080)
+    ident = [1, 0, 0, 0, 1, 0, 0, 0]
+    assert HG.projective_plain_range(ident, g)
+    assert HG.projective_plain_range([0.9, 0.1, -30, -0.05, 1.1, 12, 1e-4, -2e-4], g)             # den in [0.78, 1.19]
+    assert not HG.projective_plain_range([1, 0, 0, 0, 1, 0, -1e-3, 0], g)                          # den = 1 - x/1000: zero at x = 1000
+    assert HG.projective_plain_range([1, 0, 0, 0, 1, 0, -1e-3, 0], (0, 0, 700, 1080))              # same matrix, window ends before the horizon
+    assert not HG.projective_plain_range([1, 0, 0, 0, 1, 0, -1e-3, 0], (0, 0, 800, 1080))          # (the ragged last 256-pixel window is computed too)
+    assert not HG.projective_plain_range([1, 0, 0, 0, 1, 0, float("nan"), 0], g)
+    assert not HG.projective_plain_range([1, 0, 0, 0, 1e-200, 0, 0, 0], g)
+    assert not HG.projective_plain_range([1e150, 0, 0, 0, 1, 0, 0, 0], g)
+    assert not HG.projective_plain_range(ident, (1 << 28, 0, 100, 100))
+    assert HG.projective_plain_range(ident, (0, 0, 0, 0))                                          # empty window: nothing to divide
