@@ -78,6 +78,8 @@ struct hg_ctx {
 
     // scratch
     int32_t *d_map32 = nullptr; size_t map32_cap = 0;
+    int32_t *d_fmap = nullptr; size_t fmap_cap = 0;            // forward (source-side) triangle map of the current mesh, kept across warps
+    bool fmap_valid = false; int fmap_w = 0, fmap_h = 0;
     int32_t *d_win32 = nullptr; size_t win32_cap = 0;
     int16_t *d_map16 = nullptr; size_t map16_cap = 0;
     uint8_t *d_out_tmp = nullptr; size_t out_tmp_cap = 0;
@@ -178,7 +180,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
     void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent,
-                     c->d_geo_frames, c->d_mats, c->d_map32, c->d_win32, c->d_map16, c->d_out_tmp };
+                     c->d_geo_frames, c->d_mats, c->d_map32, c->d_fmap, c->d_win32, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -549,6 +551,12 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
 {
     HG_TRY(bind(c));
     if (!src || n_pts <= 0 || n_tris < 0 || (!tris && n_tris > 0)) return fail(c, HG_ERR_INVALID, "hg_piecewise_set_mesh: bad arguments");
+    // bindings re-send the mesh on every warp (the reference keeps it cached, :742, :758): an identical mesh keeps the
+    // device copies and what was derived from them (the forward triangle map)
+    if (c->have_mesh && n_pts == c->n_pts && n_tris == c->n_tris && msx == c->min_src_x && msy == c->min_src_y &&
+        std::memcmp(src, c->h_src.data(), sizeof(float) * 2 * (size_t)n_pts) == 0 &&
+        (n_tris == 0 || std::memcmp(tris, c->h_tris.data(), sizeof(uint32_t) * 3 * (size_t)n_tris) == 0))
+        return HG_OK;
     HG_TRY(hg_sync(c));
     HG_TRY(ensure(c, c->d_src, c->src_cap, (size_t)n_pts * 2));
     HG_TRY(ensure(c, c->d_tris, c->tris_cap, (size_t)std::max(n_tris, 1) * 3));
@@ -558,6 +566,7 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
     c->n_pts = n_pts; c->n_tris = n_tris; c->min_src_x = msx; c->min_src_y = msy;
     c->h_tris.assign(tris, tris + (size_t)3 * n_tris);
     c->h_src.assign(src, src + (size_t)2 * n_pts);
+    c->fmap_valid = false;
     c->have_mesh = true;
     c->pw_frames.clear(); c->pw_setup_done = false;
     return HG_OK;
@@ -976,19 +985,19 @@ extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int
     const size_t n = (size_t)geom.obj_w * geom.obj_h;
     const size_t n_map = (map_w > 0 && map_h > 0) ? (size_t)map_w * map_h : 0;
     // (A) forward triangle map over the source bbox: _buildTrianglesCorrespondencesMatrix :817-832 == the same
-    //     rasteriser on the SOURCE triangles with width maxSrcX-minSrcX and y offset minSrcY
-    std::vector<float> src_host((size_t)c->n_pts * 2);
-    HIP_TRY(c, hipMemcpy(src_host.data(), c->d_src, sizeof(float) * src_host.size(), hipMemcpyDeviceToHost));
+    //     rasteriser on the SOURCE triangles with width maxSrcX-minSrcX and y offset minSrcY.  It depends on the mesh only,
+    //     so it is kept until the mesh (or the bbox) changes -- like the reference's cached _trianglesCorrespondencesMatrix.
     hg_geom gmap = { 0, c->min_src_y, map_w, map_h };
     const size_t zero = 0;
-    if (n_map) {
-        HG_TRY(hg_piecewise_set_frames(c, src_host.data(), &gmap, &zero, 1));
+    if (n_map && !(c->fmap_valid && c->fmap_w == map_w && c->fmap_h == map_h)) {
+        HG_TRY(hg_piecewise_set_frames(c, c->h_src.data(), &gmap, &zero, 1));
         c->status_ptr = c->d_status;
         HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t), c->stream));
         launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
-        HG_TRY(ensure(c, c->d_map32, c->map32_cap, n_map));
-        launch_map_build(mesh_of(c), frames_of(c), 0, c->pw_frames[0], c->d_map32, c->stream);
+        HG_TRY(ensure(c, c->d_fmap, c->fmap_cap, n_map));
+        launch_map_build(mesh_of(c), frames_of(c), 0, c->pw_frames[0], c->d_fmap, c->stream);
         HIP_TRY(c, hipGetLastError());
+        c->fmap_valid = true; c->fmap_w = map_w; c->fmap_h = map_h;
     }
     // (B) forward matrices of the real frame (:785-804), then scatter + gather
     HG_TRY(hg_piecewise_set_frames(c, dst_points, &geom, &zero, 1));
@@ -998,7 +1007,7 @@ extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int
     c->pw_setup_done = false;
     HG_TRY(ensure(c, c->d_win32, c->win32_cap, n));
     HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, n * 4));
-    launch_fwd_pw(c->d_map32, c->d_fwd, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, map_w, map_h, c->pw_frames[0], c->d_win32, c->d_out_tmp, c->stream);
+    launch_fwd_pw(c->d_fmap, c->d_fwd, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, map_w, map_h, c->pw_frames[0], c->d_win32, c->d_out_tmp, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
