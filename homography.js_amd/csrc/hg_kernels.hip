@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
 //                per coordinate (see round_x8), one buffer load whose hardware range check returns 0 outside the RGBA
 //                array (the JS `undefined` -> 0 case), coalesced non-temporal stores.
 // Requirements checked by pw_fast_ok(): n_tris <= 32767 (ids == their Int16 value), obj_w <= 65535, source < 2^31 bytes,
-// min_src_x/y >= 0 (so that the upper y bound can be left to the buffer range check).
+// |min_src_x/y| < 2^22.
 
 __device__ __forceinline__ uint32_t dlo(double v) { return (uint32_t)__double2loint(v); }
 // a wave-uniform double moved to scalar registers (v_cmp_f64 takes it as its scalar operand): frees two VGPRs each
@@ -437,11 +437,12 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
     // from the hardware range check == the JS `undefined` -> 0 of :1051.
     const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mesh.img), 0, mesh.W * mesh.H * 4, 0x00020000);
-    // :1047 on h = RTN(s + 0.5):  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= hx < W + minSrcX + 0.5, and
-    // minSrcY <= sy <=> minSrcY + 0.5 <= hy.  The upper y bound needs no test: round(sy) >= H puts the byte offset at or
-    // beyond 4*W*H, which reads 0 exactly like the reference (it either fails :1047 or reads past the array).
+    // :1047 on h = RTN(s + 0.5):  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= hx < W + minSrcX + 0.5, same for y.
+    // All four are tested on the doubles: the rounded coordinates are only 32-bit (a source row of 300 * 2^24 must be
+    // rejected, not wrapped back into the image); what the range check of the buffer load still provides is the `undefined`
+    // -> 0 of flat indices that pass :1047 and yet fall outside the array (sx in [W - 0.5, W) on the last row).
     const double bx_lo = sgpr_f64((double)mesh.min_src_x + 0.5), bx_hi = sgpr_f64((double)mesh.W + (double)mesh.min_src_x + 0.5);
-    const double by_lo = sgpr_f64((double)mesh.min_src_y + 0.5);
+    const double by_lo = sgpr_f64((double)mesh.min_src_y + 0.5), by_hi = sgpr_f64((double)mesh.H + (double)mesh.min_src_y + 0.5);
     const int pitch4 = mesh.W * 4;
 
     // row `row` of the group -> LDS slots [base, base + cnt) (+ a NaN record in slot base + nan_slot that pixels without a
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
                 round_x8(h, rd);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo);   // NaN fails
+                    const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi);   // NaN fails
                     const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
                     const uint32_t off = inb ? o : 0xffffffffu;
                     px[k] = (ABL & 2) ? off : __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0);       // outside the array -> 0
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     // offset the hardware range check drops
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r0 * W * 4, 0, nrows * W * 4, 0x00020000);
     const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
-    const double by_lo = (double)mesh.min_src_y + 0.5;
+    const double by_lo = (double)mesh.min_src_y + 0.5, by_hi = (double)mesh.H + (double)mesh.min_src_y + 0.5;
     const int pitch4 = mesh.W * 4;
     const int nan_key = (int)0x80000000u | (kPatchRecs * 48);
     const int row_base = rr * kPatchCap;
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
         uint32_t px[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo);   // :1047 (NaN fails)
+            const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi);   // :1047 (NaN fails)
             const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
             px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
         }
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
     const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), 0, W * H * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r * OW * 4, 0, OW * 4, 0x00020000);
     const double y = (double)(r + fd.y_off);
-    const double bx_hi = (double)W + 0.5;
+    const double bx_hi = (double)W + 0.5, by_hi = (double)H + 0.5;
     const int pitch4 = W * 4;
     double h[8], rd[8];
     if (KIND == 0 || KIND == 2) {
@@ -940,7 +941,7 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
     uint32_t px[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const bool inb = (int)(h[2 * k] >= 0.5) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= 0.5);     // :1001 (NaN fails; sy < H via the range check)
+        const bool inb = (int)(h[2 * k] >= 0.5) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= 0.5) & (int)(h[2 * k + 1] < by_hi);     // :1001 (NaN fails)
         const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2)); // :1005
         px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
     }
@@ -1038,9 +1039,10 @@ void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16
 bool pw_fast_ok(const PwMesh &mesh, int max_obj_w)
 {
     return mesh.n_tris > 0 && mesh.n_tris <= 32767 && max_obj_w <= 65535 && (int64_t)mesh.W * mesh.H * 4 < ((int64_t)1 << 31) &&
-           mesh.W < (1 << 21) && mesh.H < (1 << 22) && mesh.min_src_x >= 0 && mesh.min_src_y >= 0 &&
-           mesh.min_src_x < (1 << 22) && mesh.min_src_y < (1 << 22) &&
-           ((int64_t)mesh.H + mesh.min_src_y + 2) * mesh.W + mesh.min_src_x < ((int64_t)1 << 31);   // record index stays in 32 bits
+           mesh.W < (1 << 21) && mesh.H < (1 << 22) && std::abs(mesh.min_src_x) < (1 << 22) && std::abs(mesh.min_src_y) < (1 << 22) &&
+           // the flat byte offset (round(sy) * W + round(sx)) * 4 of every pixel that passes :1047 stays inside 32 bits, so that
+           // negative ones (negative source minimum) wrap to >= 2^31 and are dropped by the range check like the rest
+           (((int64_t)mesh.H + std::abs(mesh.min_src_y) + 2) * mesh.W + std::abs(mesh.min_src_x) + 2) * 4 < ((int64_t)1 << 31);
 }
 
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream)

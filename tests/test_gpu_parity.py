@@ -457,3 +457,33 @@ def test_shared_reciprocal_division_is_ieee_division():
         assert c.selftest_division(1 << 26, seed=7) == 0
     finally:
         c.close()
+
+
+def test_huge_source_row_is_rejected_not_wrapped(ctx):
+    """A sliver triangle (0.0002 px wide in the output, 2e6 px tall in the source) whose left-overshoot pixels map to source
+    rows around 300 * 2^24: the reference rejects them (srcY >= height, :1047); an implementation that leaves the upper y
+    bound to a 32-bit byte offset would wrap them back into the image.  Also a projective frame with the same property."""
+    W = H = 64
+    img = G.lcg_image(W, H, 5)
+    sp = np.array([20, 5, 20, 60, 20.003, 2015599.75, 0, 0, 63, 0, 0, 63], np.float32)
+    dp = np.array([10.5001, 0, 10.5001, 63, 10.4999, 0, 0, 0, 63, 0, 0, 63], np.float32)
+    tris = np.array([3, 4, 5, 0, 1, 2], np.uint32)
+    ms, md = O.minmax_xy(sp), O.minmax_xy(dp)
+    geom = (int(md[0]), int(md[1]), int(md[2] - md[0]), int(md[3] - md[1]))
+    want, wmap, _, winv = O.warp_inverse_piecewise(sp, dp, tris, img, int(ms[0]), int(ms[1]), *geom, taps=True)
+    sliver = wmap.reshape(geom[3], geom[2]) == 1
+    iv = winv[1].astype(np.float64)
+    ys, xs = np.nonzero(sliver)
+    sy = iv[1] * (xs + geom[0]) + iv[3] * (ys + geom[1]) + iv[5]
+    assert sliver.sum() > 20 and sy.min() > 2.0 ** 32 and np.all(want[sliver] == 0)      # the case is what it claims to be
+    ctx.set_image(img)
+    ctx.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
+    ctx.piecewise_prepare(dp, geom)
+    assert np.array_equal(ctx.warp_inverse_piecewise(), want)
+    assert np.array_equal(ctx.warp_inverse_piecewise_via_map(), want)
+    # geometric kernels: sy = x * 2^24 * 300 / 10 ... an affine / projective matrix that sends column 10 to row 300 * 2^24
+    for kind, m in ((0, [1, 503316480.0, 0, 1, 0, 0]), (1, [1, 0, 0, 503316480.0, 1, 0, 0, 0])):
+        m = np.array(m, np.float64)
+        g = (0, 0, 32, 8)
+        wantg = O.warp_inverse_geometric(kind, m, img, *g)
+        assert np.array_equal(ctx.warp_inverse_geometric(kind, m, g), wantg), kind
