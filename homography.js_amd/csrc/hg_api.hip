@@ -547,10 +547,20 @@ extern "C" int hg_warp_inverse_geometric(hg_ctx *c, int kind, const double *m, h
 }
 
 // ------------------------------------------------------------------------------------------------ piecewise affine
+// NaN is a legal (if useless) coordinate -- the reference then simply draws nothing for that triangle -- but magnitudes beyond
+// kMaxCoord (Infinity included) are refused: the row loops of the rasterisers are bounded under that assumption (hg_math.h).
+static bool coords_ok(const float *p, size_t n)
+{
+    for (size_t i = 0; i < n; i++) if (std::fabs((double)p[i]) > kMaxCoord) return false;      // (NaN compares false)
+    return true;
+}
+
 extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, const uint32_t *tris, int n_tris, int msx, int msy)
 {
     HG_TRY(bind(c));
     if (!src || n_pts <= 0 || n_tris < 0 || (!tris && n_tris > 0)) return fail(c, HG_ERR_INVALID, "hg_piecewise_set_mesh: bad arguments");
+    if (!coords_ok(src, (size_t)n_pts * 2))
+        return fail(c, HG_ERR_INVALID, "hg_piecewise_set_mesh: a source coordinate is infinite or beyond 2^24 in magnitude");
     // bindings re-send the mesh on every warp (the reference keeps it cached, :742, :758): an identical mesh keeps the
     // device copies and what was derived from them (the forward triangle map)
     if (c->have_mesh && n_pts == c->n_pts && n_tris == c->n_tris && msx == c->min_src_x && msy == c->min_src_y &&
@@ -635,6 +645,9 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     HG_TRY(bind(c));
     if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
     if (!dst || !geoms || n <= 0) return fail(c, HG_ERR_INVALID, "hg_piecewise_set_frames: bad arguments");
+    if (!coords_ok(dst, (size_t)n * c->n_pts * 2))
+        return fail(c, HG_ERR_INVALID, "hg_piecewise_set_frames: a destiny coordinate is infinite or beyond 2^24 in magnitude "
+                                       "(the reference's fillTriangle row loop would run for that many rows, forever for Infinity)");
     HG_TRY(hg_sync(c));                                 // settle a pending run before its inputs are replaced
     HG_TRY(fill_frames(c, c->pw_frames, geoms, offs, n));
     const size_t T = (size_t)std::max(c->n_tris, 1), F = (size_t)n;

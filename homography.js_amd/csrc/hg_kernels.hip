@@ -308,7 +308,9 @@ __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
     const int64_t len = (int64_t)W * fd.obj_h;
     int32_t *__restrict__ rowcnt = rl.cnt + (size_t)f * rl.row_stride;
     RowEnt *__restrict__ rowent = rl.ent + (size_t)f * rl.row_stride * rl.cap;
-    for (int64_t y = (int64_t)y_min + threadIdx.x; y < y_end; y += blockDim.x) {
+    int64_t y_first = y_min, y_stop = y_end;
+    clamp_rows(y_first, y_stop, fd.y_off, W, len);           // rows that cannot write a cell are skipped (hg_math.h)
+    for (int64_t y = y_first + threadIdx.x; y < y_stop; y += blockDim.x) {
         int64_t k, fin;
         span_cells(seg, (double)y, (double)fd.y_off, (double)W, len, k, fin);
         if (k >= fin) continue;
@@ -757,7 +759,9 @@ __global__ __launch_bounds__(256) void k_map_fill(PwFrames fr, int f, int T, Fra
     const Seg *segs = fr.segs + ((size_t)f * T + t) * 3;
     const int64_t len = (int64_t)fd.obj_w * fd.obj_h;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t y = (int64_t)tr.y_min + wave; y < tr.y_end; y += 4) {
+    int64_t y_first = tr.y_min, y_stop = tr.y_end;
+    clamp_rows(y_first, y_stop, fd.y_off, fd.obj_w, len);
+    for (int64_t y = y_first + wave; y < y_stop; y += 4) {
         int64_t k, fin;
         span_cells(segs, (double)y, (double)fd.y_off, (double)fd.obj_w, len, k, fin);
         for (int64_t c = k + lane; c < fin; c += 64) atomicMax(&map32[c], t);

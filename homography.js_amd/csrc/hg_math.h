@@ -133,6 +133,22 @@ HG_HD void tri_rows(double y0, double y1, double y2, int32_t &y_min, int32_t &y_
     y_end = top > 1073741824.0 ? 1073741824 : (top < -1073741824.0 ? -1073741824 : (int32_t)top);
 }
 
+// Rows of fillTriangle's loop that can overwrite a cell at all.  A row y writes cells (y - yOff) * W + round(x) (after
+// TypedArray.fill's index rules: indices <= -len and >= len write nothing) with x between the triangle's vertex x's, and
+// the library only accepts coordinates up to kMaxCoord in magnitude (hg_piecewise_set_frames / _set_mesh; NaN vertices
+// produce no cells).  So every row outside (yOff - (len + kMaxCoord + 2) / W, yOff + (len + kMaxCoord + 2) / W) is a no-op
+// and the kernels skip it: the loop length is bounded by the window, not by how far away a vertex lies.
+constexpr double kMaxCoord = 16777216.0;        // 2^24
+
+HG_HD void clamp_rows(int64_t &y_first, int64_t &y_end, int32_t y_off, int32_t map_w, int64_t len)
+{
+    if (map_w <= 0) { y_end = y_first; return; }
+    const double reach = ((double)len + kMaxCoord + 2.0) / (double)map_w + 2.0;
+    const int64_t lo = (int64_t)floor((double)y_off - reach), hi = (int64_t)ceil((double)y_off + reach);
+    if (y_first < lo) y_first = lo;
+    if (y_end > hi) y_end = hi;
+}
+
 // ---------------------------------------------------------------------------------------------- point transforms
 
 // applyAffineTransformToPoint :1382-1385 (m = 6 doubles holding f32 values)

@@ -122,7 +122,9 @@ int hg_pack_offsets(const hg_geom *geoms, int n_frames, size_t *offsets, size_t 
 
 /* ------------------------------------------------------------------------------------------------ piecewise affine
  * Source side of the mesh, kept across frames like the reference's cached _srcPoints/_triangles/_minSrcX/_minSrcY
- * (:742, :758).  min_src_x/min_src_y are the rounded source-point bbox minimum used by the bounds test :1047. */
+ * (:742, :758).  min_src_x/min_src_y are the rounded source-point bbox minimum used by the bounds test :1047.
+ * Coordinates (source and destiny) may be NaN but not infinite or beyond 2^24 in magnitude: HG_ERR_INVALID (the
+ * reference's fillTriangle row loop would run for as many rows as the triangle is tall -- forever for Infinity). */
 int hg_piecewise_set_mesh(hg_ctx *ctx, const float *src_points, int n_points, const uint32_t *triangles, int n_triangles,
                           int min_src_x, int min_src_y);
 /* Per-frame destination side = what setDestinyPoints + the head of _inversePiecewiseAffineWarp recompute every frame:

@@ -487,3 +487,39 @@ def test_huge_source_row_is_rejected_not_wrapped(ctx):
         g = (0, 0, 32, 8)
         wantg = O.warp_inverse_geometric(kind, m, img, *g)
         assert np.array_equal(ctx.warp_inverse_geometric(kind, m, g), wantg), kind
+
+
+def test_far_away_and_absurd_vertices(ctx):
+    """A destiny vertex a million pixels away makes a triangle two million rows tall: the rasterisers only walk the rows that
+    can reach the window, the result is still the oracle's.  Infinite or > 2^24 coordinates are refused (the reference's
+    row loop would not terminate); NaN stays legal (draws nothing)."""
+    import time
+    W, H = 96, 64
+    img = G.lcg_image(W, H, 12)
+    sp, tris = WL.grid_points(W, H, 3, 2), WL.grid_triangles(3, 2)
+    dp = WL.sin_dst(sp, 3.0, 8).reshape(-1, 2).copy()
+    dp[5] = [40.0, 1.0e6]
+    dp[7] = [-3.0e5, -2.0e6]
+    dp = dp.astype(np.float32).ravel()
+    geom = (0, 0, 96, 70)                                    # (the window is the caller's: here the sane part of the mesh)
+    ms = WL.src_min(sp)
+    want, wmap, _, _ = O.warp_inverse_piecewise(sp, dp, tris, img, ms[0], ms[1], *geom, taps=True)
+    ctx.set_image(img)
+    ctx.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+    ctx.piecewise_prepare(dp, geom)
+    t0 = time.perf_counter()
+    assert np.array_equal(ctx.warp_inverse_piecewise(), want)
+    assert np.array_equal(ctx.get_tri_map(), wmap)
+    assert np.array_equal(ctx.warp_inverse_piecewise_via_map(), want)
+    assert time.perf_counter() - t0 < 5.0
+    for bad in (np.inf, -np.inf, 3.0e7, -1.0e30):
+        d2 = dp.copy(); d2[3] = bad
+        with pytest.raises(HG.HgError):
+            ctx.piecewise_prepare(d2, geom)
+        s2 = sp.copy(); s2[2] = bad
+        with pytest.raises(HG.HgError):
+            ctx.piecewise_set_mesh(s2, tris, ms[0], ms[1])
+    d3 = dp.copy(); d3[3] = np.nan
+    ctx.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+    ctx.piecewise_prepare(d3, geom)
+    assert np.array_equal(ctx.warp_inverse_piecewise(), O.warp_inverse_piecewise(sp, d3, tris, img, ms[0], ms[1], *geom))
