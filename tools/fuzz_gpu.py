@@ -86,6 +86,28 @@ for t in range(trials):
         lim = [int(v) for v in lim]
         ia = O.affine_from_triangles(d4[:6], s4[:6]).astype(np.float64)
         ok = ok and np.array_equal(ctx.warp_inverse_geometric(0, ia, lim), O.warp_inverse_geometric(0, ia, img, *lim))
+    # forward (scatter) paths: what warp() takes for same-size outputs; wider than the unit test (windows that cut the image,
+    # magnifications with holes, strong shear, negative offsets)
+    if t % 4 == 0:
+        s3 = np.array([0, 0, 0, H, W, 0], np.float32)
+        d3 = (s3.reshape(3, 2) * rng.uniform(0.3, 1.8, 2) + rng.uniform(-40, 40, 2) + rng.uniform(-25, 25, (3, 2))).astype(np.float32).ravel()
+        fa = O.affine_from_triangles(s3, d3).astype(np.float64)
+        lim = O.transform_limits(0, fa, W, H)
+        if np.all(np.isfinite(lim)) and 0 < lim[2] * lim[3] < 3_000_000:
+            lim = [int(v) for v in lim]
+            ok = ok and np.array_equal(ctx.warp_forward_geometric(0, fa, lim), O.warp_forward_geometric(0, fa, img, *lim))
+        fp = O.projective_from_squares(s4, d4)
+        lim = O.transform_limits(1, fp, W, H)
+        if np.all(np.isfinite(lim)) and 0 < lim[2] * lim[3] < 3_000_000:
+            lim = [int(v) for v in lim]
+            ok = ok and np.array_equal(ctx.warp_forward_geometric(1, fp, lim), O.warp_forward_geometric(1, fp, img, *lim))
+        mw, mh = int(ms[2] - ms[0]), int(ms[3] - ms[1])
+        if 0 < mw * mh < 3_000_000 and geom[2] * geom[3] < 3_000_000:
+            fwdm = O.piecewise_matrices(sp32, dp32, tris)
+            fmap = O.build_tri_map(sp32, tris, mw, int(ms[1]), mw * mh)
+            wantf = O.warp_forward_piecewise(fmap, fwdm, img, int(ms[0]), int(ms[1]), int(ms[2]), int(ms[3]), *geom)
+            ctx.piecewise_set_mesh(sp32, tris, int(ms[0]), int(ms[1]))
+            ok = ok and np.array_equal(ctx.warp_forward_piecewise(dp32, int(ms[2]), int(ms[3]), geom), wantf)
     if not ok:
         bad += 1
         print("MISMATCH trial", t, "mode", mode, W, H, nx, ny, geom, flush=True)
