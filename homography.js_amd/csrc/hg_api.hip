@@ -421,6 +421,9 @@ static int fill_frames(hg_ctx *c, std::vector<FrameDesc> &v, const hg_geom *geom
         d.x_off = geoms[i].x_off; d.y_off = geoms[i].y_off; d.obj_w = geoms[i].obj_w; d.obj_h = geoms[i].obj_h;
         const size_t px = (d.obj_w > 0 && d.obj_h > 0) ? (size_t)d.obj_w * (size_t)d.obj_h : 0;
         if (px > ((size_t)1 << 31)) return fail(c, HG_ERR_INVALID, "frame larger than 2^31 pixels");
+        // pixel coordinates x = xOff + column stay exact integers in every kernel (int32 sums, f32-matrix * x products in fp64)
+        if (std::abs((int64_t)d.x_off) > (1 << 26) || std::abs((int64_t)d.y_off) > (1 << 26))
+            return fail(c, HG_ERR_INVALID, "output window offset beyond 2^26 pixels");
         d.out_off = offs ? offs[i] : off;
         if (d.out_off & 3) return fail(c, HG_ERR_INVALID, "output offsets must be multiples of 4 bytes");
         d.map_off = moff;
