@@ -31,7 +31,8 @@ static napi_value throw_hg(napi_env env, hg_ctx *ctx, const char *what, int code
 #define HG_CALL(ctx, what, call) do { int rc_ = (call); if (rc_ != HG_OK) return throw_hg(env, (ctx), (what), rc_); } while (0)
 
 /* d_batch: device buffer the frames of warpInversePiecewiseBatch are produced in (kept between calls, grown as needed) */
-typedef struct { hg_ctx *ctx; int obj_w, obj_h; void *d_batch; size_t d_batch_cap; } handle_t;
+/* n_pts / n_tris: the mesh last set, so that point-set and matrix buffers can be checked before the C ABI reads / fills them */
+typedef struct { hg_ctx *ctx; int obj_w, obj_h; void *d_batch; size_t d_batch_cap; size_t n_pts, n_tris; } handle_t;
 
 static void release_ctx(handle_t *h)
 {
@@ -287,6 +288,7 @@ static napi_value fn_piecewise_set_mesh(napi_env env, napi_callback_info info)
     uint32_t *tris = (uint32_t *)get_typed(env, a[2], napi_uint32_array, &nt, "triangles"); if (!tris) return NULL;
     if (!get_i32(env, a[3], &msx) || !get_i32(env, a[4], &msy)) return NULL;
     HG_CALL(h->ctx, "hg_piecewise_set_mesh", hg_piecewise_set_mesh(h->ctx, src, (int)(np / 2), tris, (int)(nt / 3), msx, msy));
+    h->n_pts = np / 2; h->n_tris = nt / 3;
     return NULL;
 }
 
@@ -298,6 +300,7 @@ static napi_value fn_piecewise_prepare(napi_env env, napi_callback_info info)
     size_t n; hg_geom g;
     float *dst = (float *)get_typed(env, a[1], napi_float32_array, &n, "dstPoints"); if (!dst) return NULL;
     if (!get_geom(env, a + 2, &g)) return NULL;
+    if (h->n_pts == 0 || n < 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold one x,y pair per mesh point (piecewiseSetMesh first)");
     HG_CALL(h->ctx, "hg_piecewise_prepare", hg_piecewise_prepare(h->ctx, dst, g));
     h->obj_w = g.obj_w; h->obj_h = g.obj_h;
     return NULL;
@@ -339,6 +342,7 @@ static napi_value fn_warp_forward_piecewise(napi_env env, napi_callback_info inf
     float *dst = (float *)get_typed(env, a[1], napi_float32_array, &n, "dstPoints"); if (!dst) return NULL;
     if (!get_i32(env, a[2], &mx) || !get_i32(env, a[3], &my)) return NULL;
     if (!get_geom(env, a + 4, &g)) return NULL;
+    if (h->n_pts == 0 || n < 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold one x,y pair per mesh point (piecewiseSetMesh first)");
     const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
     void *out; napi_value r = make_typed(env, napi_uint8_clamped_array, px * 4, 1, &out); if (!r) return NULL;
     if (px) HG_CALL(h->ctx, "hg_warp_forward_piecewise", hg_warp_forward_piecewise(h->ctx, dst, mx, my, g, (uint8_t *)out));
@@ -365,7 +369,7 @@ static napi_value fn_get_matrices(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 2, a)) return NULL;
     handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
     int T; if (!get_i32(env, a[1], &T)) return NULL;
-    if (T < 0) T = 0;
+    T = (int)h->n_tris;                                      /* the C ABI fills n_triangles x 6 floats: size by the mesh, not by the caller */
     void *fwd, *inv;
     napi_value rf = make_typed(env, napi_float32_array, (size_t)T * 6, 4, &fwd); if (!rf) return NULL;
     napi_value ri = make_typed(env, napi_float32_array, (size_t)T * 6, 4, &inv); if (!ri) return NULL;
@@ -389,6 +393,7 @@ static napi_value fn_warp_inverse_piecewise_batch(napi_env env, napi_callback_in
     int32_t *gv = (int32_t *)get_typed(env, a[2], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
     const int F = (int)(ng / 4);
     if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
+    if (h->n_pts == 0 || nd < (size_t)F * 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold frames x mesh points x,y pairs (piecewiseSetMesh first)");
     size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
     size_t total = 0;
     hg_pack_offsets((const hg_geom *)gv, F, offs, &total);

@@ -194,6 +194,7 @@ class Context:
 
     def __init__(self, device=0, stream=None):
         self._h = C.c_void_p()
+        self._n_pts = self._n_tris = 0
         L = lib()
         if stream is None:
             code = L.hg_create(int(device), C.byref(self._h))
@@ -297,7 +298,8 @@ class Context:
         return out
 
     def warp_forward_piecewise(self, dst_pts, max_src_x, max_src_y, geom):
-        _, dp = _f32(dst_pts)
+        d, dp = _f32(dst_pts)
+        assert d.size == 2 * self._n_pts, "one x,y pair per mesh point"
         g = Geom(*[int(v) for v in geom])
         out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
         self._c(lib().hg_warp_forward_piecewise(self._h, dp, int(max_src_x), int(max_src_y), g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
@@ -318,9 +320,11 @@ class Context:
         t = np.ascontiguousarray(tris, dtype=np.uint32)
         self._c(lib().hg_piecewise_set_mesh(self._h, sp, s.size // 2, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size // 3,
                                             int(min_src_x), int(min_src_y)))
+        self._n_pts, self._n_tris = s.size // 2, t.size // 3      # the C ABI takes plain pointers: sizes are checked on this side
 
     def piecewise_prepare(self, dst_pts, geom):
-        _, dp = _f32(dst_pts)
+        d, dp = _f32(dst_pts)
+        assert d.size == 2 * self._n_pts, "one x,y pair per mesh point"
         self._geom = Geom(*[int(v) for v in geom])
         self._c(lib().hg_piecewise_prepare(self._h, dp, self._geom))
 
@@ -346,6 +350,7 @@ class Context:
         return m
 
     def get_matrices(self, n_tris):
+        assert n_tris == self._n_tris, "the library fills n_triangles x 6 floats"
         fwd = np.empty((n_tris, 6), np.float32)
         inv = np.empty((n_tris, 6), np.float32)
         self._c(lib().hg_get_matrices(self._h, fwd.ctypes.data_as(C.POINTER(C.c_float)), inv.ctypes.data_as(C.POINTER(C.c_float))))
@@ -353,6 +358,7 @@ class Context:
 
     def piecewise_set_frames(self, dst_pts, geoms, offsets=None):
         d, dp = _f32(dst_pts)
+        assert d.size == 2 * self._n_pts * len(geoms), "frames x mesh points x,y pairs"
         offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
         self._c(lib().hg_piecewise_set_frames(self._h, dp, _geoms(geoms), offs, len(geoms)))
 
