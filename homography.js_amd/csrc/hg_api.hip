@@ -680,12 +680,13 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
         for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + kRowGroup - 1) / kRowGroup;
         if (groups < c->opt_min_row_groups) c->pw_row_group = 1;
     }
-    // dense rows that still fit the patch kernel's LDS budget, sheared enough for 2-D gather patches to pay (measured: C5,
-    // mean shear 0.39, 0.63 -> 0.50 ms; the same mesh without shear 0.35 -> 0.37 ms).  Layout choice only: the kernels check
-    // the real counts.
+    // dense rows that still fit the patch kernel's LDS budget, sheared enough for 2-D gather patches to pay.  Measured
+    // (k_pw_rows one row per workgroup -> k_pw_patch): C5, shear 0.39, cover 190: 0.63 -> 0.50 ms; 4K 60x60 grid, 0.15, 148:
+    // 0.58 -> 0.50; 40x40, 0.16, 98: 0.47 -> 0.45; 32x32, 0.18, 92: 0.43 -> 0.42; but 24x24, 0.08, 60: 0.37 -> 0.38 and C5
+    // without its shear, 0.04, 150: 0.35 -> 0.37.  Layout choice only: the kernels check the real counts.
     c->pw_patch = cover > 56 && cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW &&
                   (int64_t)cover * 64 <= (int64_t)8 * max_w &&          // spans per 64-pixel bin ~ cover * 64 / width: overfull bins are slow
-                  shear >= 0.2 && !c->pw_patch_disabled;
+                  shear >= 0.1 && !c->pw_patch_disabled;
     c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
     if (cover > 200 && c->row_cap < kRowSpanCapDense) c->row_cap = kRowSpanCapDense;
