@@ -592,13 +592,14 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
 {
     int worst = 0, worst_group = 0;
     double rows_total = 0.0, tris_total = 0.0, shear_total = 0.0, shear_n = 0.0;
-    std::vector<int> diff, starts;
+    std::vector<int> diff, tdiff, starts;
     for (size_t f = 0; f < c->pw_frames.size(); f++) {
         const FrameDesc &fd = c->pw_frames[f];
         if (fd.obj_w <= 0 || fd.obj_h <= 0) continue;
         const float *dp = dst + f * (size_t)c->n_pts * 2;
         diff.assign((size_t)fd.obj_h + 2, 0);
         starts.assign((size_t)fd.obj_h + 2, 0);
+        tdiff.assign((size_t)fd.obj_h + 2, 0);
         for (int t = 0; t < c->n_tris; t++) {
             double lo = INFINITY, hi = -INFINITY;
             bool ok = true;
@@ -625,15 +626,21 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
             // rows [trunc(minY), ceil(maxY)) - yOff, one more below for spans that spill over the row end (x-offset quirk)
             const double a = std::max(std::trunc(lo) - fd.y_off, 0.0), b = std::min(std::ceil(hi) - fd.y_off + 1.0, (double)fd.obj_h);
             if (!(a < b)) continue;
-            diff[(size_t)a] += 1; diff[(size_t)b] -= 1; starts[(size_t)a] += 1;
+            diff[(size_t)a] += 1; diff[(size_t)b] -= 1;
             rows_total += b - a; tris_total += 1.0;
+            // tighter, for the triangles-per-group estimate: a triangle has spans on the integer rows inside [minY, maxY]
+            // (:1179; triangles that only touch a row at a vertex between two integers do not count), plus the spill row when
+            // the window is offset in x
+            const double ta = std::max(std::ceil(lo) - fd.y_off, 0.0), tb = std::min(std::floor(hi) - fd.y_off + (fd.x_off != 0 ? 2.0 : 1.0), (double)fd.obj_h);
+            if (ta < tb) { tdiff[(size_t)ta] += 1; tdiff[(size_t)tb] -= 1; starts[(size_t)ta] += 1; }
         }
-        int run = 0;
-        int group = 0;                                       // triangles touching the 4-row group the row belongs to
+        int run = 0, trun = 0;
+        int group = 0;                                       // triangles with spans in the 4-row group the row belongs to
         for (int r = 0; r < fd.obj_h; r++) {
             run += diff[r];
+            trun += tdiff[r];
             worst = std::max(worst, run);
-            group = (r % kRowGroup == 0) ? run : group + starts[r];
+            group = (r % kRowGroup == 0) ? trun : group + starts[r];
             worst_group = std::max(worst_group, group);
         }
     }
@@ -683,10 +690,13 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     // dense rows that still fit the patch kernel's LDS budget, sheared enough for 2-D gather patches to pay.  Measured
     // (k_pw_rows one row per workgroup -> k_pw_patch): C5, shear 0.39, cover 190: 0.63 -> 0.50 ms; 4K 60x60 grid, 0.15, 148:
     // 0.58 -> 0.50; 40x40, 0.16, 98: 0.47 -> 0.45; 32x32, 0.18, 92: 0.43 -> 0.42; but 24x24, 0.08, 60: 0.37 -> 0.38 and C5
-    // without its shear, 0.04, 150: 0.35 -> 0.37.  Layout choice only: the kernels check the real counts.
+    // without its shear, 0.04, 150 (5 spans per 256-pixel window): 0.35 -> 0.37.  Regardless of shear it also wins when many
+    // narrow spans share a window (k_pw_rows tests every span of a window on all four pixels of every lane, k_pw_patch only
+    // the spans of the lane's 64-pixel bin): lens-distortion style 64x36 grid on 4K, shear 0.02, 8.5 spans per window:
+    // 0.73 -> 0.49 ms.  Layout choice only: the kernels check the real counts.
     c->pw_patch = cover > 56 && cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW &&
                   (int64_t)cover * 64 <= (int64_t)8 * max_w &&          // spans per 64-pixel bin ~ cover * 64 / width: overfull bins are slow
-                  shear >= 0.1 && !c->pw_patch_disabled;
+                  (shear >= 0.1 || (int64_t)cover * 256 >= (int64_t)6 * max_w) && !c->pw_patch_disabled;
     c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
     if (cover > 200 && c->row_cap < kRowSpanCapDense) c->row_cap = kRowSpanCapDense;

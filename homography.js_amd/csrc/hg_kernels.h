@@ -80,7 +80,9 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream);
 // Dense meshes (64..199 spans per row, obj_w <= 8192): 4 rows per workgroup, 16 x 4 pixel gather patches, one matrix record
 // per triangle of the group.  Same row lists, same status protocol as launch_pw_rows; no map tap.
-constexpr int kPatchMaxW = 8192, kPatchMaxRowSpans = 196, kPatchMaxGroupTris = 204;
+// (limits on the HOST ESTIMATES, which run ~10 % above the real counts the kernel enforces: 199 spans per row, 208 triangles
+// per group; a frame set that does exceed those is redone once through the map path and the context drops back to k_pw_rows)
+constexpr int kPatchMaxW = 8192, kPatchMaxRowSpans = 215, kPatchMaxGroupTris = 225;
 void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
