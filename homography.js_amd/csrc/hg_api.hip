@@ -593,6 +593,7 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
     int worst = 0, worst_group = 0;
     double rows_total = 0.0, tris_total = 0.0, shear_total = 0.0, shear_n = 0.0;
     std::vector<int> diff, tdiff, starts;
+    const int shear_stride = std::max(1, c->n_tris / 1024);
     for (size_t f = 0; f < c->pw_frames.size(); f++) {
         const FrameDesc &fd = c->pw_frames[f];
         if (fd.obj_w <= 0 || fd.obj_h <= 0) continue;
@@ -613,7 +614,7 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
                 sx[k] = c->h_src[2 * (size_t)v]; sy[k] = c->h_src[2 * (size_t)v + 1]; dx[k] = dp[2 * (size_t)v]; dy[k] = y;
             }
             if (!ok) continue;
-            {   // |d(source row) / d(output x)| of the triangle's inverse map: how many source lines 64 consecutive output
+            if (t % shear_stride == 0) {   // |d(source row) / d(output x)| of the triangle's inverse map (a sample is enough): how many source lines 64 consecutive output
                 // pixels spread over (plain doubles: an estimate, never used for pixels)
                 const double e1x = sx[1] - sx[0], e1y = sy[1] - sy[0], e2x = sx[2] - sx[0], e2y = sy[2] - sy[0];
                 const double f1x = dx[1] - dx[0], f1y = dy[1] - dy[0], f2x = dx[2] - dx[0], f2y = dy[2] - dy[0];

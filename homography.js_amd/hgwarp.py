@@ -290,6 +290,12 @@ class Context:
         self._c(lib().hg_warp_inverse_geometric(self._h, int(kind), p, g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
+    def warp_inverse_geometric_device(self, kind, m, geom, d_out):
+        """One affine / projective frame into device memory (asynchronous; sync() settles it)."""
+        a, p = _f64(m)
+        assert a.size >= (6 if int(kind) == 0 else 8)
+        self._c(lib().hg_warp_inverse_geometric_device(self._h, int(kind), p, Geom(*[int(v) for v in geom]), C.c_void_p(int(d_out))))
+
     def warp_forward_geometric(self, kind, m, geom):
         _, p = _f64(m)
         g = Geom(*[int(v) for v in geom])
