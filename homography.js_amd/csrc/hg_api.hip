@@ -679,9 +679,18 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, c->pw_frames.data(), sizeof(FrameDesc) * F, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_dst, dst, sizeof(float) * 2 * c->n_pts * F, hipMemcpyHostToDevice, c->stream));
     double tri_rows = 0.0, shear = 0.0;
-    int group_tris = 0, max_w = 0;
-    const int cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear);
-    for (const FrameDesc &d : c->pw_frames) max_w = std::max(max_w, d.obj_w);
+    int group_tris = 0, max_w = 0, cover = 0;
+    int64_t total_px = 0;
+    for (const FrameDesc &d : c->pw_frames) { max_w = std::max(max_w, d.obj_w); if (d.obj_w > 0 && d.obj_h > 0) total_px += (int64_t)d.obj_w * d.obj_h; }
+    if (total_px < ((int64_t)4 << 20) && (int64_t)F * c->n_tris > 4096) {
+        // small frames of a dense mesh (the README's 400x400 / 23 000-triangle benchmark): walking every triangle on the host
+        // would cost more than the frame; guess the row density from the triangle count (the span lists grow if it was low)
+        cover = (int)(2.5 * std::sqrt((double)c->n_tris));
+        group_tris = 1 << 30;                               // (no k_pw_patch without the real estimate)
+        tri_rows = 64.0;
+    } else {
+        cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear);
+    }
     c->pw_row_group = cover <= 56 ? kRowGroup : 1;
     {   // few rows in total (a single 4K frame has 560 four-row groups for 256 CUs): one row per workgroup fills the chip better
         int64_t groups = 0;
