@@ -59,6 +59,7 @@ struct hg_ctx {
     int pw_row_group = kRowGroup;                              // output rows per k_pw_rows workgroup (4, or 1 for dense meshes)
     int pw_tri_threads = 128;                                  // k_tri_spans workgroup size
     bool pw_patch = false;                                     // dense mesh that fits k_pw_patch (4-row groups, 2-D gather patches)
+    bool pw_patch_dense = false;                               // ... only in its global-record variant (up to 511 spans per row)
     bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
     bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
@@ -707,6 +708,10 @@ extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geo
     c->pw_patch = cover > 56 && cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW &&
                   (int64_t)cover * 64 <= (int64_t)8 * max_w &&          // spans per 64-pixel bin ~ cover * 64 / width: overfull bins are slow
                   (shear >= 0.1 || (int64_t)cover * 256 >= (int64_t)6 * max_w) && !c->pw_patch_disabled;
+    // beyond that budget, up to ~480 spans per row: the same kernel without matrix records in LDS (pixels read them from global)
+    c->pw_patch_dense = !c->pw_patch && cover > kPatchMaxRowSpans && cover <= kPatchMaxRowSpansDense && max_w <= kPatchMaxW &&
+                        (int64_t)cover * 64 <= (int64_t)8 * max_w && !c->pw_patch_disabled;
+    if (c->pw_patch_dense) c->pw_patch = true;
     c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
     if (cover > 200 && c->row_cap < kRowSpanCapDense) c->row_cap = kRowSpanCapDense;
@@ -801,7 +806,7 @@ static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
     const bool patch = c->pw_fast && !map_out && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force == 1 : c->pw_patch);
     c->pw_used_patch = patch;
     c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
-    if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, c->stream); c->rows_clean = true; }
+    if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, c->pw_patch_dense, c->stream); c->rows_clean = true; }
     else if (c->pw_fast) { launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true; }
     else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
 }

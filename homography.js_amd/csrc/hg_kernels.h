@@ -83,7 +83,9 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
 // (limits on the HOST ESTIMATES, which run ~10 % above the real counts the kernel enforces: 199 spans per row, 208 triangles
 // per group; a frame set that does exceed those is redone once through the map path and the context drops back to k_pw_rows)
 constexpr int kPatchMaxW = 8192, kPatchMaxRowSpans = 215, kPatchMaxGroupTris = 225;
-void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, hipStream_t stream);
+// global_records: the variant for up to 511 spans per row whose pixels read their matrix from the tap array instead of LDS
+constexpr int kPatchMaxRowSpansDense = 480;
+void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
 // the pixel loop :1042-1056 reading the map.

@@ -4,6 +4,7 @@
 // Citations are file:line into the reference's Homography.js (v1.8.0).  Design notes: DESIGN.md §4.
 #include "hg_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace hg {
 
@@ -569,10 +570,17 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
 constexpr int kPatchRows = 4, kPatchCap = 200, kPatchRecs = 208, kPatchBins = 128, kPatchBinSlots = 8, kPatchHash = 1024, kPatchTilePitch = 68;
 // (sized so that six workgroups fit a CU's 160 KB of LDS: 26.9 KB each)
 static_assert(kPatchHash * 4 <= kPatchRows * kPatchBins * kPatchBinSlots, "the hash table lives in the bin-slot area");
+// GLOBALREC variant for very dense meshes (up to 511 spans per row: README-scale, ~23 000 triangles on 4K): no matrix
+// records in LDS at all -- a pixel reads its triangle's inverse matrix (6 floats, the tap array k_tri_spans fills, L2
+// resident) from global memory and widens it itself; the LDS then holds 4 x 512 spans (30.4 KB, five workgroups per CU).
+constexpr int kPatchCapDense = 512;
 
+template <bool GLOBALREC>
 __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                   int groups_per_xcd, int32_t *__restrict__ status_next)
 {
+    constexpr int CAPR = GLOBALREC ? kPatchCapDense : kPatchCap;            // spans per row
+    using slot_t = typename std::conditional<GLOBALREC, uint16_t, uint8_t>::type;
     const int bid = blockIdx.x, xcd = bid & 7, bi = bid >> 3;
     const int f = bi / groups_per_xcd;
     const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * kPatchRows;
@@ -580,11 +588,11 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;   // (see k_pw_rows)
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
-    __shared__ __align__(16) double s_rec[(kPatchRecs + 1) * 6];            // {m0, m2, m4, m1, m3, m5} per triangle; last = NaN record
-    __shared__ uint32_t s_lohi[kPatchRows * kPatchCap];                     // span cells [lo, hi) of the row, 16 bits each
-    __shared__ int s_key[kPatchRows * kPatchCap];                           // id << 14 | byte offset of the triangle's record
+    __shared__ __align__(16) double s_rec[GLOBALREC ? 6 : (kPatchRecs + 1) * 6];   // {m0, m2, m4, m1, m3, m5} per triangle; last = NaN record
+    __shared__ uint32_t s_lohi[kPatchRows * CAPR];                          // span cells [lo, hi) of the row, 16 bits each
+    __shared__ int s_key[kPatchRows * CAPR];                                // id << 14 | byte offset of the triangle's record (GLOBALREC: the id)
     __shared__ int s_bincnt[kPatchRows * kPatchBins];
-    __shared__ __align__(4) uint8_t s_bin[kPatchRows * kPatchBins * kPatchBinSlots];   // span indices per (row, 64-px column)
+    __shared__ __align__(4) slot_t s_bin[kPatchRows * kPatchBins * kPatchBinSlots];   // span indices per (row, 64-px column)
     __shared__ uint32_t s_tile[4 * kPatchRows * kPatchTilePitch];          // per wave: 4 rows x 64 pixels (+ padding against bank conflicts)
     __shared__ int s_nrec, s_fail;
     uint32_t *s_hash = reinterpret_cast<uint32_t *>(s_bin);                 // id << 16 | (record + 1), 0 = empty; used before the bins
@@ -597,18 +605,18 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
 #pragma unroll
     for (int j = 0; j < kPatchRows; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
     for (int i = threadIdx.x; i < kPatchRows * kPatchBins; i += 256) s_bincnt[i] = 0;
-    for (int i = threadIdx.x; i < kPatchHash; i += 256) s_hash[i] = 0u;
-    if (threadIdx.x == 0) { s_nrec = 0; s_fail = (cmax > rl.cap || cmax > kPatchCap - 1 || nbins > kPatchBins) ? 1 : 0; }
+    if (!GLOBALREC) for (int i = threadIdx.x; i < kPatchHash; i += 256) s_hash[i] = 0u;
+    if (threadIdx.x == 0) { s_nrec = 0; s_fail = (cmax > rl.cap || cmax > CAPR - 1 || nbins > kPatchBins) ? 1 : 0; }
     __syncthreads();
     if ((int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;                    // every wave has read the counters: clean for the next step
     const bool bad0 = s_fail != 0;
 
     // ---- phase 1: span lists -> LDS; each triangle of the group gets ONE matrix record (hash on the id: the thread that
     // claims the bucket writes the record and publishes its index; the others remember the bucket and read it later)
-    int my_bucket[(kPatchRows * kPatchCap + 255) / 256];
+    int my_bucket[(kPatchRows * CAPR + 255) / 256];
     int n_mine = 0;
-    if (!bad0) for (int e = threadIdx.x; e < kPatchRows * kPatchCap; e += 256) {
-        const int rr = e / kPatchCap, i = e - rr * kPatchCap;
+    if (!bad0) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
+        const int rr = e / CAPR, i = e - rr * CAPR;
         const int cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
         int bucket = -1;
         if (i < cnt) {
@@ -616,48 +624,50 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             const uint4 a = reinterpret_cast<const uint4 *>(ent)[0];
             s_lohi[e] = a.x;
             const uint32_t id = a.y;
-            uint32_t hpos = (id * 2654435761u) >> 22;                       // 10 bits
-            for (int probe = 0; probe < kPatchHash; probe++, hpos = (hpos + 1) & (kPatchHash - 1)) {
-                const uint32_t old = atomicCAS(&s_hash[hpos], 0u, (id << 16) | 0xffffu);
-                if (old == 0u) {                                            // claimed: this thread owns the triangle's record
-                    const int rec = atomicAdd(&s_nrec, 1);
-                    if (rec < kPatchRecs) {
-                        const uint4 b = reinterpret_cast<const uint4 *>(ent)[1];
-                        double2 *mrec = reinterpret_cast<double2 *>(s_rec + rec * 6);
-                        mrec[0] = make_double2((double)__uint_as_float(a.z), (double)__uint_as_float(b.x));    // m0, m2
-                        mrec[1] = make_double2((double)__uint_as_float(b.z), (double)__uint_as_float(a.w));    // m4, m1
-                        mrec[2] = make_double2((double)__uint_as_float(b.y), (double)__uint_as_float(b.w));    // m3, m5
-                        s_hash[hpos] = (id << 16) | (uint32_t)(rec + 1);
-                    } else s_fail = 1;
-                    bucket = (int)hpos;
-                    break;
+            if (!GLOBALREC) {
+                uint32_t hpos = (id * 2654435761u) >> 22;                   // 10 bits
+                for (int probe = 0; probe < kPatchHash; probe++, hpos = (hpos + 1) & (kPatchHash - 1)) {
+                    const uint32_t old = atomicCAS(&s_hash[hpos], 0u, (id << 16) | 0xffffu);
+                    if (old == 0u) {                                        // claimed: this thread owns the triangle's record
+                        const int rec = atomicAdd(&s_nrec, 1);
+                        if (rec < kPatchRecs) {
+                            const uint4 b = reinterpret_cast<const uint4 *>(ent)[1];
+                            double2 *mrec = reinterpret_cast<double2 *>(s_rec + rec * 6);
+                            mrec[0] = make_double2((double)__uint_as_float(a.z), (double)__uint_as_float(b.x));    // m0, m2
+                            mrec[1] = make_double2((double)__uint_as_float(b.z), (double)__uint_as_float(a.w));    // m4, m1
+                            mrec[2] = make_double2((double)__uint_as_float(b.y), (double)__uint_as_float(b.w));    // m3, m5
+                            s_hash[hpos] = (id << 16) | (uint32_t)(rec + 1);
+                        } else s_fail = 1;
+                        bucket = (int)hpos;
+                        break;
+                    }
+                    if ((old >> 16) == id) { bucket = (int)hpos; break; }
                 }
-                if ((old >> 16) == id) { bucket = (int)hpos; break; }
             }
             s_key[e] = (int)id;
         }
         my_bucket[n_mine++] = bucket;
     }
-    if (threadIdx.x < 3) reinterpret_cast<double2 *>(s_rec + kPatchRecs * 6)[threadIdx.x] = make_double2(NAN, NAN);
+    if (!GLOBALREC && threadIdx.x < 3) reinterpret_cast<double2 *>(s_rec + kPatchRecs * 6)[threadIdx.x] = make_double2(NAN, NAN);
     __syncthreads();
     // ---- phase 2: keys (id << 14 | record offset), once every record index is published
     const bool bad1 = s_fail != 0;
     n_mine = 0;
-    if (!bad1) for (int e = threadIdx.x; e < kPatchRows * kPatchCap; e += 256) {
+    if (!GLOBALREC && !bad1) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
         const int bucket = my_bucket[n_mine++];
         if (bucket >= 0) s_key[e] = (s_key[e] << kKeyShift) | (int)(((s_hash[bucket] & 0xffffu) - 1u) * 48u);
     }
-    __syncthreads();
+    if (!GLOBALREC) __syncthreads();
     // ---- phase 3: the hash table is dead, its memory becomes the bins: span index -> every 64-pixel column it overlaps
-    if (!bad1) for (int e = threadIdx.x; e < kPatchRows * kPatchCap; e += 256) {
-        const int rr = e / kPatchCap, i = e - rr * kPatchCap;
+    if (!bad1) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
+        const int rr = e / CAPR, i = e - rr * CAPR;
         const int cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
         if (i < cnt) {
             const uint32_t lh = s_lohi[e];
             const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
             for (int b = lo >> 6; b <= (hi - 1) >> 6 && b < nbins; b++) {
                 const int pos = atomicAdd(&s_bincnt[rr * kPatchBins + b], 1);          // (a count beyond the slots marks the bin as overfull)
-                if (pos < kPatchBinSlots) s_bin[(rr * kPatchBins + b) * kPatchBinSlots + pos] = (uint8_t)i;
+                if (pos < kPatchBinSlots) s_bin[(rr * kPatchBins + b) * kPatchBinSlots + pos] = (slot_t)i;
             }
         }
     }
@@ -681,17 +691,18 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
     const double by_lo = (double)mesh.min_src_y + 0.5, by_hi = (double)mesh.H + (double)mesh.min_src_y + 0.5;
     const int pitch4 = mesh.W * 4;
-    const int nan_key = (int)0x80000000u | (kPatchRecs * 48);
-    const int row_base = rr * kPatchCap;
+    const int nan_key = GLOBALREC ? -1 : ((int)0x80000000u | (kPatchRecs * 48));
+    const int row_base = rr * CAPR;
     const int my_cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
     uint32_t *tile = s_tile + wave * (kPatchRows * kPatchTilePitch);
+    const float *__restrict__ ginv = fr.inv + (size_t)f * mesh.n_tris * kInvStride;     // GLOBALREC: this frame's inverse matrices
 
     for (int cw = wave; cw < nbins; cw += 4) {              // this wave's 64-pixel-wide column blocks, all 4 rows at once
         const int c0 = cw << 6;                             // pixel k of the lane: (c0 + ck[k], r0 + rr)
         int best[4] = { nan_key, nan_key, nan_key, nan_key };
         const int bidx = rr * kPatchBins + cw;
         const int nb = s_bincnt[bidx];
-        const uint8_t *bin = s_bin + bidx * kPatchBinSlots;
+        const slot_t *bin = s_bin + bidx * kPatchBinSlots;
         if (!__any(nb > kPatchBinSlots)) {
             for (int p = 0; __any(p < nb); p++) {
                 int lo = 0, len = 0, key = 0;               // len 0: no pixel passes the span test
@@ -717,12 +728,21 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
         double h[8], rd[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_rec) + (best[k] & kKeyOffMask));
-            const double2 m02 = mrec[0], m41 = mrec[1], m35 = mrec[2];
+            double m0, m1, m2, m3, m4, m5;
+            if (GLOBALREC) {                                // the triangle's f32 inverse matrix straight from the tap array
+                const float4 a = *reinterpret_cast<const float4 *>(ginv + (size_t)max(best[k], 0) * kInvStride);
+                const float2 b = *reinterpret_cast<const float2 *>(ginv + (size_t)max(best[k], 0) * kInvStride + 4);
+                const double nanq = best[k] < 0 ? NAN : 0.0;     // no triangle: every coordinate becomes NaN and fails :1047
+                m0 = a.x; m1 = a.y; m2 = a.z; m3 = a.w; m4 = (double)b.x + nanq; m5 = (double)b.y + nanq;
+            } else {
+                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_rec) + (best[k] & kKeyOffMask));
+                const double2 m02 = mrec[0], m41 = mrec[1], m35 = mrec[2];
+                m0 = m02.x; m2 = m02.y; m4 = m41.x; m1 = m41.y; m3 = m35.x; m5 = m35.y;
+            }
             const double xd = (double)(c0 + ck[k] + fd.x_off);
             // :1383-1384  (m0*x) + (m2*y) + m4: m2*y rounded on its own, m0*x exact in fp64 (see k_pw_rows)
-            h[2 * k]     = fma(m02.x, xd, m02.y * y) + m41.x;
-            h[2 * k + 1] = fma(m41.y, xd, m35.x * y) + m35.y;
+            h[2 * k]     = fma(m0, xd, m2 * y) + m4;
+            h[2 * k + 1] = fma(m1, xd, m3 * y) + m5;
         }
         round_x8(h, rd);
         uint32_t px[4];
@@ -1055,11 +1075,13 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
     hipLaunchKernelGGL(k_tri_spans, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl);
 }
 
-void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, hipStream_t stream)
+void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream)
 {
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
     const int gpx = ((fr.max_obj_h + kPatchRows - 1) / kPatchRows + 7) / 8;
-    hipLaunchKernelGGL(k_pw_patch, dim3((unsigned)gpx * 8u * (unsigned)fr.n_frames), dim3(256), 0, stream, mesh, fr, rl, out, gpx, status_next);
+    const dim3 grid((unsigned)gpx * 8u * (unsigned)fr.n_frames);
+    if (global_records) hipLaunchKernelGGL(k_pw_patch<true>, grid, dim3(256), 0, stream, mesh, fr, rl, out, gpx, status_next);
+    else                hipLaunchKernelGGL(k_pw_patch<false>, grid, dim3(256), 0, stream, mesh, fr, rl, out, gpx, status_next);
 }
 
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)

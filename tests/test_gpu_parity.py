@@ -379,7 +379,10 @@ def test_dense_sheared_mesh_takes_the_patch_kernel():
     c = HG.Context(0)
     c.set_option("min_row_groups", 0)            # (these frame sets are small: without this they would all run one row per workgroup)
     try:
-        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 3), (1600, 150, 56, 3, 0.5, 2), (640, 150, 8, 3, 18.0, 1)]:
+        # (dense sheared -> k_pw_patch; dense flat, few spans per window -> k_pw_rows one row per workgroup; sparse -> 4-row
+        #  groups; very dense, ~300 spans per row -> k_pw_patch in its global-record variant)
+        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 3), (3200, 150, 17, 3, 0.5, 2), (640, 150, 8, 3, 18.0, 1),
+                                               (3000, 100, 110, 2, 5.0, 3)]:
             img = G.lcg_image(W, H, 31)
             sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
             frames = [WL.sin_dst(sp, A, 8 + f) for f in range(3)]
