@@ -803,10 +803,11 @@ static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
     const int force = c->opt_patch >= 0 ? c->opt_patch : env_force;
     int mw = 0;
     for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
-    const bool patch = c->pw_fast && !map_out && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force == 1 : c->pw_patch);
+    const bool patch = c->pw_fast && !map_out && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force >= 1 : c->pw_patch);
+    const bool global_records = force == 2 ? true : (force == 1 ? false : c->pw_patch_dense);
     c->pw_used_patch = patch;
     c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
-    if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, c->pw_patch_dense, c->stream); c->rows_clean = true; }
+    if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
     else if (c->pw_fast) { launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true; }
     else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
 }

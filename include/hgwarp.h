@@ -174,7 +174,8 @@ long hg_redone_frames(hg_ctx *ctx);
 /* Layout knobs of the piecewise fast path; they never change results (tests run the parity suite under each setting), only
  * which kernel layout the next hg_piecewise_set_frames picks:
  *   "min_row_groups" (default 1536): frame sets with fewer 4-row groups run one row per workgroup;
- *   "patch" (default -1 = by estimate): 0 never use k_pw_patch, 1 use it whenever the frame width allows. */
+ *   "patch" (default -1 = by estimate): 0 never use k_pw_patch, 1 use it whenever the frame width allows, 2 the same in its
+ *           global-record variant. */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);
 /* Host-side proof obligation of that division (no GPU needed): 1 if every pixel of the window `geom` under the inverse
  * projective matrix m[8] keeps numerators and denominator in the plain range (entries 0 or in [2^-100, 2^100], coordinates

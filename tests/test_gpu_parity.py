@@ -18,7 +18,7 @@ GOLD = G.load()
 # The piecewise fast path picks a kernel layout from the frame set (rows per workgroup, k_pw_patch for dense sheared meshes);
 # results must not depend on it, so every test that takes `ctx` runs under each layout policy.
 LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0}, "rows1": {"min_row_groups": 1 << 30, "patch": 0},
-           "patch": {"min_row_groups": 0, "patch": 1}}
+           "patch": {"min_row_groups": 0, "patch": 1}, "patch_global": {"min_row_groups": 0, "patch": 2}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))
