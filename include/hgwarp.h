@@ -48,7 +48,8 @@ enum { HG_AFFINE = 0, HG_PROJECTIVE = 1 };
 
 typedef struct hg_ctx hg_ctx;
 
-/* Output window of one frame, the reference's (_xOutputOffset, _yOutputOffset, _objectiveWidth, _objectiveHeight). */
+/* Output window of one frame, the reference's (_xOutputOffset, _yOutputOffset, _objectiveWidth, _objectiveHeight).
+ * Accepted: up to 2^31 pixels, offsets up to 2^26 in magnitude (HG_ERR_INVALID beyond); obj_w / obj_h <= 0 = empty frame. */
 typedef struct hg_geom { int32_t x_off, y_off, obj_w, obj_h; } hg_geom;
 
 /* ------------------------------------------------------------------------------------------------ library / context */
