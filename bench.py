@@ -2,25 +2,42 @@
 """bench.py -- headline metric of BASELINE.json on MI355X: Mpixels/s warped, piecewise-affine, 4K RGBA.
 
 A "step" is one pass of the hot path over one batch of synthetic input: F destination point sets of the C3 workload
-(3840x2160 RGBA, 11x11-point sinusoidal grid = 200 triangles; frame f uses sin((8 + f mod 4) x / pi), the pattern of the
-reference's own harness test/benchmark.js:68,107-110) on a shared source image.  Per step and per frame the library
-does what the reference redoes per frame (`setDestinyPoints(dst_f); warp()`): per-triangle affine solves + inverses +
-triangle spans (k_tri_spans) and the inverse piecewise warp (k_pw_rows, the dominant kernel).  Inputs (source RGBA, meshes, destination points) are
-resident in HBM before the timed region; outputs stay in HBM.
+(3840x2160 RGBA, 11x11-point sinusoidal grid = 200 triangles; frame f uses sin((8 + f mod 4) x / pi): 4 distinct point
+sets cycled over the F frames, the pattern of the reference's own harness test/benchmark.js:68,107-110).  Per step and
+per frame the library does what the reference redoes per frame (`setDestinyPoints(dst_f); warp()`): per-triangle affine
+solves + inverses + triangle spans (k_tri_spans) and the inverse piecewise warp (k_pw_rows, the dominant kernel); for the
+projective config C2 the 8x8 DLT solve of every frame (k_solve_projective) is part of the step as well.  Inputs (source
+RGBA, meshes, destination points) are resident in HBM before the timed region; outputs stay in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config C3|C4|C5|C2]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config C3|C4|C5|C2] [--sources both|shared|distinct]
+
+--gpus N > 1 without a torchrun environment re-executes itself under
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+(one rank per GPU over RCCL); launched by torchrun directly it reads RANK/LOCAL_RANK/WORLD_SIZE as usual.
+
+Two source layouts are measured:
+  shared    BASELINE.json's configuration: all F frames warp ONE source image (test/benchmark.js:107-110).  This is `value`
+            and `roofline`.  Its source reads are largely served by L2 / the 256 MiB Infinity Cache, so `roofline` also
+            carries `hbm_compulsory_frac` (output written once + source read once).
+  distinct  the video case (README.md:121-137): every frame has its own 33 MB source (F x 33 MB >> Infinity Cache), where
+            the algorithmic bytes ARE HBM bytes: `roofline_distinct`.
+After each timed region the bytes the timed kernels wrote are checked (untimed): frame 0 against the reference-generated
+golden SHA-256 (tests/golden/golden.json; a data fixture, not the oracle), the other frames against frame f mod 4, the
+distinct-source frames through XOR-linearity against the shared-source frames.  `verified` must be true; exit status 3
+otherwise.
 
 Multi-GPU: frames shard across ranks (independent units, weak scaling: F frames per GPU); the only exchange is the
 one-off broadcast of the shared source texture over RCCL (scatter + all_gather so each xGMI link carries 1/N of it),
 done before the timed region and reported as `broadcast_ms`.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. `roofline`, `roofline_distinct` and `cpu_baseline`.
 """
 import argparse
+import hashlib
 import importlib.util
 import json
 import os
+import socket
 import sys
 import time
 
@@ -29,6 +46,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "homography.js_amd")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+GOLDEN_CASE = {"C3": "C3_piecewise_4k", "C2": "C2_projective_1080p", "C5": "C5_piecewise_8k"}
 
 
 def _load(name, path):
@@ -41,18 +59,48 @@ def _load(name, path):
     return mod
 
 
-def _pmc_traffic(config, frames, piecewise):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, profiles/hbm_traffic.json), when they were collected for this very workload; else null."""
+def _pmc_traffic(config, frames, sources):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json:
+    FETCH_SIZE / WRITE_SIZE in separate runs of this very command, corrected by the factors tools/calib_fetch measured
+    for this library's 4 B/lane access forms).  rocprofv3 cannot run inside the timed process, so this is a number FROM A
+    PROFILE of the same workload, labelled as such; null when no matching profile was committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             entries = json.load(f)
+        best = None
         for t in entries if isinstance(entries, list) else [entries]:
-            if piecewise and t.get("config") == config and t.get("frames_per_launch") == frames:
-                return int(t["hbm_bytes_per_launch"])
+            if t.get("config") == config and t.get("frames_per_launch") == frames and t.get("sources", "shared") == sources:
+                if best is None or t.get("round", 0) >= best.get("round", 0):
+                    best = t
+        if best:
+            return int(best["hbm_bytes_per_launch"]), f"profiles/hbm_traffic.json round {best.get('round')}: {best.get('source', '')}"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
+
+
+def _golden_sha(config):
+    """SHA-256 the reference itself produced for frame 0 of this config (tests/golden/gen_golden.mjs), or None."""
+    name = GOLDEN_CASE.get(config)
+    if not name:
+        return None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+            for c in json.load(f)["cases"]:
+                if c["name"] == name:
+                    return c["warps"][0]["out"]["sha"]
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def launch_command(argv, n):
+    """The torchrun command line `bench.py --gpus n` re-executes itself under (127.0.0.1 rendezvous, one rank per GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--launch-dry-run"]
 
 
 def main():
@@ -62,9 +110,26 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=64, help="frames (destination point sets) per GPU per step")
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "C5", "C2", "C5flat"])
+    ap.add_argument("--sources", default="both", choices=["both", "shared", "distinct"],
+                    help="shared: one source for all frames (BASELINE config, `value`); distinct: one source per frame; both (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) output checks")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
+    ap.add_argument("--launch-dry-run", action="store_true", help="print the torchrun command --gpus N would re-execute under, and exit")
     args = ap.parse_args()
+
+    # ---------------------------------------------------------------- self-launch (the driver calls `python bench.py --gpus N ...`)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = launch_command(sys.argv[1:], args.gpus)
+        if args.launch_dry_run:
+            print(json.dumps({"launch": cmd}))
+            return 0
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execve(cmd[0], cmd, os.environ)               # never returns
+    if args.launch_dry_run:
+        print(json.dumps({"launch": None}))
+        return 0
 
     import torch
     import torch.distributed as dist
@@ -74,46 +139,57 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback to measure)")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl == RCCL on ROCm
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     hg = _load("hgwarp", os.path.join(PKG, "hgwarp.py"))
     wl = _load("hg_workloads", os.path.join(PKG, "workloads.py"))
     hgdist = _load("hg_dist", os.path.join(PKG, "dist.py"))
     cfg = wl.CONFIGS[args.config]
     W, H, F = cfg["W"], cfg["H"], args.frames
+    do_shared, do_distinct = args.sources in ("both", "shared"), args.sources in ("both", "distinct")
 
     # ---------------------------------------------------------------- inputs -> HBM (untimed)
     img_t = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
     if rank == 0:
         img_t.copy_(torch.from_numpy(wl.lcg_image(W, H, 1)))
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    img_t = hgdist.broadcast_source(img_t, rank, world, dist)
-    torch.cuda.synchronize()
-    broadcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else 0.0
+    broadcast_ms = 0.0
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img_t = hgdist.broadcast_source(img_t, rank, world, dist, verify=False)
+        torch.cuda.synchronize()
+        broadcast_ms = (time.perf_counter() - t0) * 1e3
+        hgdist.verify_replicas(img_t, dist)                 # untimed: every rank holds the same bytes, or this raises
 
     stream = torch.cuda.Stream(device=dev)
     ctx = hg.Context(local_rank, stream=stream.cuda_stream)
     ctx.set_image_device(img_t.data_ptr(), W, H)
 
     piecewise = cfg["kind"] in ("piecewise", "face")
+    frame_ids = [rank * F + f for f in range(F)]            # different ranks get different frames of the same sequence
     if piecewise:
-        # different ranks get different frames of the same sequence (frame index = rank*F + f)
         if cfg["kind"] == "face":
             sp = wl.face_mesh(W, H, cfg["landmarks"])
             tris = hg.triangulate(sp)                                  # host Delaunay, where the reference calls Delaunator
             seq = wl.face_frames(sp, W, cfg["total_frames"])
-            frames = [seq[(rank * F + f) % len(seq)] for f in range(F)]
+            frames = [seq[i % len(seq)] for i in frame_ids]
+            same_as = [None] * F
             mesh_txt = f"{cfg['landmarks']}-landmark face mesh"
+            pts_txt = f"frames {frame_ids[0]}..{frame_ids[-1]} of the {cfg['total_frames']}-frame orbit"
         else:
             sp, tris = wl.grid_points(W, H, cfg["nx"], cfg["ny"]), wl.grid_triangles(cfg["nx"], cfg["ny"])
-            frames = [wl.sin_dst(sp, cfg["A"], 8 + ((rank * F + f) % 4)) for f in range(F)]
+            frames = [wl.sin_dst(sp, cfg["A"], 8 + (i % 4)) for i in frame_ids]
+            same_as = [None if f < 4 else f % 4 for f in range(F)]     # local frame f has the point set of local frame f mod 4
             mesh_txt = f"{cfg['nx']}x{cfg['ny']}-cell sinusoidal grid"
+            pts_txt = "4 distinct destination point sets, sin((8 + f mod 4) x / pi), cycled over the frames (test/benchmark.js:68)"
         geoms = [wl.piecewise_geom(d) for d in frames]
         msx, msy = wl.src_min(sp)
         ctx.piecewise_set_mesh(sp, tris, msx, msy)
@@ -121,92 +197,177 @@ def main():
         ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
         run = ctx.warp_inverse_piecewise_frames_device
         workload = (f"{args.config}: {W}x{H} RGBA piecewise-affine, {mesh_txt} "
-                    f"({tris.size // 3} triangles), {F} frames/GPU/step on a shared source")
+                    f"({tris.size // 3} triangles), {F} frames/GPU/step")
     else:
         s4 = wl.corners(W, H)
-        mats, geoms = [], []
-        for f in range(F):
-            d4 = wl.projective_dst(W, H, 0.0125 * ((rank * F + f) % 10))
-            fwd = hg.solve_projective(s4, d4)
-            geoms.append(tuple(int(v) for v in hg.transform_limits(1, fwd, W, H)))
-            mats.append(hg.solve_projective(d4, s4))
+        d4s = [wl.projective_dst(W, H, 0.0125 * (i % 10)) for i in frame_ids]
+        same_as = [None if f < 10 else f % 10 for f in range(F)]
+        pts_txt = "10 distinct corner sets cycled over the frames (test/benchmark.js:282-283 pattern, animated)"
+        # output windows (calculateTransformLimits :1503-1527 on the forward matrix) are host-side scalar work done at
+        # setDestinyPoints time; the INVERSE 8x8 solve the reference repeats on every warp (:994) runs on the device inside
+        # the timed step (hg_projective_set_frames_points -> k_solve_projective)
+        geoms = [tuple(int(v) for v in hg.transform_limits(1, hg.solve_projective(s4, d4), W, H)) for d4 in d4s]
+        mats = [hg.solve_projective(d4, s4) for d4 in d4s]              # host copies: CPU baseline + cross-check only
         offs, total = hg.pack_offsets(geoms)
-        ctx.geometric_set_frames(1, np.concatenate(mats), geoms, offs)
+        if hasattr(ctx, "projective_set_frames_points"):
+            ctx.projective_set_frames_points(np.tile(s4, F), np.concatenate(d4s), geoms, offs, swap=True)
+            solve_txt = ", 8x8 DLT solve per frame on the device inside the step"
+        else:
+            ctx.geometric_set_frames(1, np.concatenate(mats), geoms, offs)
+            solve_txt = ""
         run = ctx.warp_inverse_geometric_frames_device
-        workload = f"{args.config}: {W}x{H} RGBA projective, 4 corner points, {F} frames/GPU/step on a shared source"
+        workload = f"{args.config}: {W}x{H} RGBA projective, 4 corner points, {F} frames/GPU/step{solve_txt}"
 
     out_t = torch.empty(total, dtype=torch.uint8, device=dev)
     d_out = out_t.data_ptr()
     n_out = [g[2] * g[3] for g in geoms]
     px_per_step = float(sum(n_out))
 
+    def frame_view(t, f):
+        return t[offs[f]: offs[f] + n_out[f] * 4]
+
     # N_hit per frame (algorithmic read bytes): alpha==255 count when the same frames run on an all-255 source (untimed)
     solid = torch.full((H, W, 4), 255, dtype=torch.uint8, device=dev)
     ctx.set_image_device(solid.data_ptr(), W, H)
     run(d_out)
     ctx.sync()
-    n_hit = []
-    for f, g in enumerate(geoms):
-        a = out_t[offs[f]: offs[f] + g[2] * g[3] * 4].view(-1, 4)[:, 3]
-        n_hit.append(int((a == 255).sum().item()))
+    hit_masks = [frame_view(out_t, f).view(-1, 4)[:, 3] == 255 for f in range(F)]
+    n_hit = [int(m.sum().item()) for m in hit_masks]
+    if not do_distinct or args.no_verify:
+        hit_masks = None
     ctx.set_image_device(img_t.data_ptr(), W, H)
     del solid
     algo_bytes_per_launch = float(sum(4 * no + 4 * nh for no, nh in zip(n_out, n_hit)))
+    compulsory_bytes_shared = float(sum(4 * no for no in n_out)) + 4.0 * W * H      # every output byte once + the shared source once
 
-    # ---------------------------------------------------------------- warmup + timed region
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The GPU sat idle while the host counted N_hit: ~50 ms of the same work first, so that the W warmup steps and the
-    # timed region run at the sustained clocks (a 0.3 ms step is far shorter than the power-state ramp).  Untimed.
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.05:
-        for _ in range(16):
+    def timed_region():
+        """ramp -> W warmup steps -> K timed steps (barrier + synchronize on both sides); returns (elapsed_s, kernel_ms, launches)"""
+        # The GPU sat idle during the untimed host work: ~50 ms of the same steps first, so that warmup and the timed region
+        # run at the sustained clocks (a 0.6 ms step is far shorter than the power-state ramp).  Untimed.
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < 0.05:
+            for _ in range(16):
+                run(d_out)
+            ctx.sync()
+        for _ in range(args.warmup):
             run(d_out)
         ctx.sync()
-    for _ in range(args.warmup):
-        run(d_out)
-    ctx.sync()
-    ctx.set_timing(True)                       # hipEvent pairs around the dominant kernel, on the launch stream
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run(d_out)
-    ctx.sync()                                 # waits for the stream (and settles any frame the fused path deferred)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    k_total_ms, k_launches = ctx.kernel_ms_stats()
-    ctx.set_timing(False)
+        ctx.set_timing(True)                       # hipEvent pairs around the dominant kernel, on the launch stream
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run(d_out)
+        ctx.sync()                                 # waits for the stream (and settles any frame the fused path deferred)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        k_total_ms, k_launches = ctx.kernel_ms_stats()
+        ctx.set_timing(False)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, k_total_ms / max(k_launches, 1), k_launches
 
+    kernel_name = None
+
+    def roofline_block(k_ms, launches, sources):
+        achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, traffic_src = _pmc_traffic(args.config, F, sources)
+        return {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_ms": round(k_ms, 5), "launches_timed": launches, "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
+                "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel"}
+
+    verified, checks = True, []
+
+    def check(name, ok):
+        nonlocal verified
+        checks.append({"check": name, "ok": bool(ok)})
+        verified = verified and bool(ok)
+
+    # ---------------------------------------------------------------- shared source: BASELINE.json's configuration -> `value`
+    px_all = px_per_step
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         px = torch.tensor([px_per_step], dtype=torch.float64, device=dev)
         dist.all_reduce(px, op=dist.ReduceOp.SUM)
         px_all = float(px.item())
-    else:
-        px_all = px_per_step
+    res = {}
+    shared_copy = None
+    if do_shared:
+        elapsed, k_ms, k_launches = timed_region()
+        kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
+        rf = roofline_block(k_ms, k_launches, "shared")
+        comp = compulsory_bytes_shared / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        rf["hbm_compulsory_frac"] = round(comp / HBM_PEAK_GBS, 4)
+        rf["note"] += ("; all frames share ONE source, whose reads are largely served by L2 / the 256 MiB Infinity Cache: "
+                       "hbm_compulsory_frac prices only what must cross HBM (every output byte once + the source once); "
+                       "roofline_distinct is the layout where algorithmic bytes are HBM bytes")
+        res["shared"] = (elapsed, rf)
+        if not args.no_verify:                      # the bytes the timed kernels wrote (untimed checks)
+            want = _golden_sha(args.config) if rank == 0 else None
+            if want:
+                got = hashlib.sha256(frame_view(out_t, 0).cpu().numpy().tobytes()).hexdigest()
+                check(f"frame 0 of the timed output == reference golden {GOLDEN_CASE[args.config]} (sha256)", got == want)
+            for f in range(F):
+                if same_as[f] is not None and n_out[f] == n_out[same_as[f]]:
+                    if not torch.equal(frame_view(out_t, f), frame_view(out_t, same_as[f])):
+                        check(f"frame {f} == frame {same_as[f]} (same point set)", False)
+                        break
+            else:
+                check("every frame == the frame with its point set among the first few (f mod period)", True)
+            if do_distinct:
+                shared_copy = out_t.clone()
 
+    # ---------------------------------------------------------------- distinct sources: one 4*W*H source per frame (video case)
+    if do_distinct:
+        srcs = img_t.unsqueeze(0).repeat(F, 1, 1, 1)                    # F x H x W x 4; image f = image 0 XOR c_f (c_0 = 0)
+        consts = [0] + [((f * 37 + 11) & 0xFF) or 1 for f in range(1, F)]
+        for f in range(1, F):
+            srcs[f] ^= consts[f]
+        ctx.set_images_device(srcs.data_ptr(), W, H, F, W * H * 4)
+        elapsed_d, k_ms_d, k_launches_d = timed_region()
+        if kernel_name is None:
+            kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
+        rd = roofline_block(k_ms_d, k_launches_d, "distinct")
+        rd["sources"] = f"{F} distinct {W}x{H} RGBA sources per step ({F * W * H * 4 / 1e6:.0f} MB >> 256 MiB Infinity Cache): algorithmic bytes are HBM bytes"
+        rd["ms_per_step"] = round(elapsed_d * 1e3 / args.steps, 4)
+        rd["value_mpixels_per_s"] = round(px_all * args.steps / elapsed_d / 1e6, 1)
+        res["distinct"] = (elapsed_d, rd)
+        if not args.no_verify and hit_masks is not None:
+            # XOR-linearity of a pure gather: out(img ^ c) == out(img) ^ (c on pixels that read a source pixel, 0 elsewhere)
+            base = shared_copy
+            if base is None:                        # --sources distinct: produce the shared-source frames now (untimed)
+                ctx.set_image_device(img_t.data_ptr(), W, H)
+                base = torch.empty_like(out_t)
+                run(base.data_ptr())
+                ctx.sync()
+            ok = True
+            for f in range(F):
+                d = (frame_view(out_t, f) ^ frame_view(base, f)).view(-1, 4)
+                exp = (hit_masks[f].to(torch.uint8) * consts[f]).unsqueeze(1).expand(-1, 4)
+                if not torch.equal(d, exp):
+                    ok = False
+                    break
+            check("distinct-source frames == shared-source frames XOR per-frame constant on exactly the hit pixels (all frames)", ok)
+            if "shared" not in res and rank == 0 and _golden_sha(args.config):
+                got = hashlib.sha256(frame_view(out_t, 0).cpu().numpy().tobytes()).hexdigest()
+                check(f"frame 0 == reference golden {GOLDEN_CASE[args.config]} (sha256)", got == _golden_sha(args.config))
+        del srcs, shared_copy
+        ctx.set_image_device(img_t.data_ptr(), W, H)
+
+    primary = "shared" if "shared" in res else "distinct"
+    elapsed, roofline = res[primary]
     ms_per_step = elapsed * 1e3 / args.steps
     value = px_all * args.steps / elapsed / 1e6          # Mpixels/s, whole job
-
-    # ---------------------------------------------------------------- roofline of the dominant kernel (rank 0's launches)
-    k_ms = k_total_ms / max(k_launches, 1)
-    achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    kernel_name = {3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo<projective>"
-    roofline = {"bound": "hbm", "kernel": kernel_name,
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": _pmc_traffic(args.config, F, piecewise), "kernel_ms": round(k_ms, 5), "launches_timed": k_launches,
-                "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
-                "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel"}
-    if roofline["traffic"] is not None and roofline["traffic"] < algo_bytes_per_launch:
-        roofline["note"] += ("; source reads shared by neighbouring rows and frames hit in L2 / the 256 MiB Infinity Cache, so the measured "
-                             "fabric traffic is below the algorithmic bytes and the fraction can touch 1.0 without exceeding the memory system")
-    elif roofline["traffic"] is not None:
-        roofline["note"] += "; measured fabric traffic exceeds the algorithmic bytes: scattered source lines are fetched more than once"
+    if world > 1:
+        v = torch.tensor([1.0 if verified else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified = bool(v.item() == 1.0)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample
     cpu = None
@@ -229,7 +390,7 @@ def main():
         cpu = {"value": round(px_done / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
                "sample": f"{n_done} frames of the same workload through oracle/hg_oracle.c (C restatement of the reference's JS loops, "
                          f"gcc -O2, single thread) in {dt:.1f} s; the reference itself is single-threaded JavaScript "
-                         f"(24.3 Mpix/s on C3 under Node 12, BASELINE.md \u00a72)"}
+                         f"(24.3 Mpix/s on C3 under Node 12, BASELINE.md §2)"}
         # the same C restatement on every host core: one frame per thread at a time (ctypes releases the GIL), ~6 s sample
         if piecewise:
             from concurrent.futures import ThreadPoolExecutor
@@ -246,10 +407,10 @@ def main():
                 return done, j
             t1 = time.perf_counter()
             with ThreadPoolExecutor(cores) as ex:
-                res = list(ex.map(_work, range(cores)))
+                r_mt = list(ex.map(_work, range(cores)))
             dt_mt = time.perf_counter() - t1
-            cpu["all_cores"] = {"value": round(sum(r[0] for r in res) / dt_mt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-                                "sample": f"{sum(r[1] for r in res)} frames on {cores} threads (one frame per thread at a time, "
+            cpu["all_cores"] = {"value": round(sum(r[0] for r in r_mt) / dt_mt / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                                "sample": f"{sum(r[1] for r in r_mt)} frames on {cores} threads (one frame per thread at a time, "
                                           f"fresh output buffers per frame) in {dt_mt:.1f} s"}
         # the same algorithm as plain JavaScript under this box's Node (what the reference's own loops achieve here)
         if piecewise and args.config in ("C3", "C5"):
@@ -271,15 +432,20 @@ def main():
                 "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u8 pixels / f64 coordinates", "data": "synthetic",
-                "config": {"workload": workload, "frames_per_gpu_per_step": F, "output_pixels_per_step_per_gpu": int(px_per_step),
-                           "parallelism": f"frames sharded over {world} GPU(s); source broadcast once (scatter+all_gather over RCCL)",
+                "config": {"workload": workload + (" on a shared source" if primary == "shared" else ", one source per frame"),
+                           "frames_per_gpu_per_step": F, "point_sets": pts_txt,
+                           "output_pixels_per_step_per_gpu": int(px_per_step), "sources": primary,
+                           "parallelism": f"frames sharded over {world} GPU(s); shared source broadcast once (scatter+all_gather over RCCL)",
                            "broadcast_ms": round(broadcast_ms, 3)},
-                "roofline": roofline, "cpu_baseline": cpu}
+                "verified": None if args.no_verify else verified, "checks": checks,
+                "roofline": roofline, "roofline_distinct": res["distinct"][1] if "distinct" in res and primary != "distinct" else None,
+                "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    return 0 if (verified or args.no_verify) else 3
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

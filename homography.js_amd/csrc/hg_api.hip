@@ -27,6 +27,7 @@ struct hg_ctx {
     // source image
     uint8_t *d_img = nullptr; size_t img_cap = 0; bool img_aliased = false;
     int W = 0, H = 0;
+    int n_imgs = 1; size_t img_stride = 0;                     // hg_set_images_device: frame f reads image f % n_imgs
 
     // mesh (source side)
     float *d_src = nullptr; size_t src_cap = 0;
@@ -115,8 +116,8 @@ template <typename T>
 static int ensure(hg_ctx *c, T *&p, size_t &cap, size_t need)
 {
     if (need <= cap) return HG_OK;
+    const size_t n = std::max(need, cap + cap / 2);          // geometric growth from the OLD capacity
     if (p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); p = nullptr; cap = 0; }
-    size_t n = std::max(need, cap + cap / 2);
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, n * sizeof(T));
     if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -396,7 +397,7 @@ extern "C" int hg_set_image(hg_ctx *c, const uint8_t *rgba, int w, int h)
     HG_TRY(ensure(c, c->d_img, c->img_cap, bytes));
     HIP_TRY(c, hipMemcpyAsync(c->d_img, rgba, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));       // caller memory is not retained after return
-    c->W = w; c->H = h;
+    c->W = w; c->H = h; c->n_imgs = 1; c->img_stride = 0;
     return HG_OK;
 }
 
@@ -408,7 +409,16 @@ extern "C" int hg_set_image_device(hg_ctx *c, const void *d_rgba, int w, int h)
     if (c->d_img && !c->img_aliased) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_img)); }
     c->d_img = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_rgba));
     c->img_cap = 0; c->img_aliased = true;
-    c->W = w; c->H = h;
+    c->W = w; c->H = h; c->n_imgs = 1; c->img_stride = 0;
+    return HG_OK;
+}
+
+extern "C" int hg_set_images_device(hg_ctx *c, const void *d_rgba, int w, int h, int n_images, size_t stride_bytes)
+{
+    if (n_images <= 0 || (w > 0 && h > 0 && n_images > 1 && (stride_bytes < (size_t)w * h * 4 || (stride_bytes & 3))))
+        return fail(c, HG_ERR_INVALID, "hg_set_images_device: n_images must be >= 1 and the stride a multiple of 4 bytes >= width*height*4");
+    HG_TRY(hg_set_image_device(c, d_rgba, w, h));
+    c->n_imgs = n_images; c->img_stride = n_images > 1 ? stride_bytes : 0;
     return HG_OK;
 }
 
@@ -485,12 +495,18 @@ extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, con
 {
     HG_TRY(bind(c));
     if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m || !geoms || n <= 0) return fail(c, HG_ERR_INVALID, "hg_geometric_set_frames: bad arguments");
-    HG_TRY(fill_frames(c, c->geo_frames, geoms, offs, n));
+    // Transactional: the live frame set is dropped first and the new one only becomes visible once validation, every
+    // allocation and the uploads have succeeded; after a failure the next *_frames_device call returns HG_ERR_STATE
+    // instead of launching F new frames against buffers sized for the old set.
+    c->geo_frames.clear();
+    std::vector<FrameDesc> fresh;
+    HG_TRY(fill_frames(c, fresh, geoms, offs, n));
     HG_TRY(ensure(c, c->d_geo_frames, c->geo_frames_cap, (size_t)n));
     HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)n * 8));
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, c->geo_frames.data(), sizeof(FrameDesc) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, fresh.data(), sizeof(FrameDesc) * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_mats, m, sizeof(double) * 8 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->geo_frames.swap(fresh);
     c->geo_kind = kind;
     bool exact = kind == HG_AFFINE;
     for (int f = 0; f < n && exact; f++) {
@@ -515,7 +531,7 @@ extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
     for (const FrameDesc &d : c->geo_frames) { mw = std::max(mw, d.obj_w); mh = std::max(mh, d.obj_h); }
     HG_TRY(time_begin(c));
     launch_geo(c->geo_kind, c->geo_f32_exact, c->d_geo_frames, c->d_mats, (int)c->geo_frames.size(), mw, mh, c->d_img, c->W, c->H,
-               static_cast<uint8_t *>(d_out), c->stream);
+               c->n_imgs, (uint64_t)c->img_stride, static_cast<uint8_t *>(d_out), c->stream);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
     return HG_OK;
@@ -652,7 +668,23 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
     return worst;
 }
 
+static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n);
+
+// Transactional wrapper: if validation, an allocation or an upload fails part-way, the context is left WITHOUT a frame set
+// (the next warp returns HG_ERR_STATE) rather than with n new host-side frames over device buffers sized for the old set.
 extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n)
+{
+    const int rc = pw_set_frames_impl(c, dst, geoms, offs, n);
+    if (rc != HG_OK && c) {
+        const std::string why = c->err;
+        (void)hg_sync(c);                                   // queued runs of the old set are settled against the old set
+        c->pw_frames.clear(); c->pw_setup_done = false; c->rows_clean = false;
+        c->err = why; g_err = why;
+    }
+    return rc;
+}
+
+static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n)
 {
     HG_TRY(bind(c));
     if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
@@ -732,6 +764,7 @@ static PwMesh mesh_of(const hg_ctx *c)
     PwMesh m;
     m.src_pts = c->d_src; m.tris = c->d_tris; m.n_pts = c->n_pts; m.n_tris = c->n_tris;
     m.min_src_x = c->min_src_x; m.min_src_y = c->min_src_y; m.img = c->d_img; m.W = c->W; m.H = c->H;
+    m.n_imgs = c->n_imgs; m.img_stride = c->img_stride;
     return m;
 }
 
@@ -799,7 +832,11 @@ static int run_setup(hg_ctx *c)
 
 static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
 {
-    static const int env_force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;    // experiments only: 0 = never, 1 = whenever allowed by size
+#ifdef HG_EXPERIMENTS
+    static const int env_force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;    // experiments build only: 0 = never, 1 = whenever allowed by size
+#else
+    constexpr int env_force = -1;                            // the shipped library reads no environment variable
+#endif
     const int force = c->opt_patch >= 0 ? c->opt_patch : env_force;
     int mw = 0;
     for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
@@ -827,8 +864,10 @@ static int run_frame_via_map(hg_ctx *c, int f, uint8_t *d_out)
     const size_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h : 0;
     if (n == 0) return HG_OK;
     HG_TRY(ensure(c, c->d_map32, c->map32_cap, n));
-    launch_map_build(mesh_of(c), frames_of(c), f, fd, c->d_map32, c->stream);
-    launch_pw_from_map(mesh_of(c), frames_of(c), f, fd, c->d_map32, d_out, c->stream);
+    PwMesh mesh = mesh_of(c);
+    mesh.img = frame_img(mesh, f); mesh.n_imgs = 1;          // this frame's own source
+    launch_map_build(mesh, frames_of(c), f, fd, c->d_map32, c->stream);
+    launch_pw_from_map(mesh, frames_of(c), f, fd, c->d_map32, d_out, c->stream);
     HIP_TRY(c, hipGetLastError());
     return HG_OK;
 }

@@ -37,9 +37,17 @@ struct PwMesh {                     // source side of the mesh + source image (s
     const uint32_t *tris;           // n_tris x 3
     int32_t n_pts, n_tris;
     int32_t min_src_x, min_src_y;
-    const uint8_t *img;             // RGBA8 source, W*H*4 bytes
+    const uint8_t *img;             // RGBA8 source, W*H*4 bytes (image 0)
     int32_t W, H;
+    int32_t n_imgs;                 // >= 1: frame f reads image f % n_imgs (1 = one source shared by every frame)
+    uint64_t img_stride;            // bytes between consecutive source images (hg_set_images_device)
 };
+
+// source image of frame f
+__host__ __device__ __forceinline__ const uint8_t *frame_img(const PwMesh &m, int f)
+{
+    return m.n_imgs > 1 ? m.img + (uint64_t)(f % m.n_imgs) * m.img_stride : m.img;
+}
 
 struct PwFrames {                   // per-frame device arrays, frame-major
     const FrameDesc *frames;
@@ -96,8 +104,9 @@ void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream
 
 // k_geo: _inverseGeometricWarp pixel loop :997-1011 for all frames.  mats = F x 8 doubles (inverse matrices).
 // f32_exact: every affine matrix entry is a float value and |x| < 2^28 (lets the kernel use an exact-product fma).
+// n_imgs / img_stride: frame f reads the source at img + (f % n_imgs) * img_stride.
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
-                const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
+                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, hipStream_t stream);
 // (f32_exact doubles as "plain division range proved" for kind 1: see geo_plain_division() in hg_api.hip)
 // div2_plain vs IEEE division on `samples` pseudo-random operand triples; returns the number of mismatching quotients
 unsigned long long run_selftest_division(uint64_t seed, uint64_t samples, unsigned long long *d_counter, hipStream_t stream);

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwin = (W + 255) >> 8;
     const float *__restrict__ invm = fr.inv + (size_t)f * T * kInvStride;
-    const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(mesh.img);
+    const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(frame_img(mesh, f));
     const int64_t n_src_px = (int64_t)mesh.W * mesh.H;
     uint32_t *__restrict__ orow = reinterpret_cast<uint32_t *>(out + fd.out_off) + row0;
     const bool vec_ok = ((W & 3) == 0) && ((fd.out_off & 15) == 0);
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
 
     // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
     // from the hardware range check == the JS `undefined` -> 0 of :1051.
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mesh.img), 0, mesh.W * mesh.H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 0, mesh.W * mesh.H * 4, 0x00020000);
     // :1047 on h = RTN(s + 0.5):  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= hx < W + minSrcX + 0.5, same for y.
     // All four are tested on the doubles: the rounded coordinates are only 32-bit (a source row of 300 * 2^24 must be
     // rejected, not wrapped back into the image); what the range check of the buffer load still provides is the `undefined`
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
 #pragma unroll
     for (int k = 0; k < 4; k++) ck[k] = (lane & 15) + 16 * k;
     const double y = (double)(r0 + rr + fd.y_off);
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(mesh.img), 0, mesh.W * mesh.H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 0, mesh.W * mesh.H * 4, 0x00020000);
     // output: the group's rows as one raw buffer; lanes of rows past the frame end and pixels past the row end get an
     // offset the hardware range check drops
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r0 * W * 4, 0, nrows * W * 4, 0x00020000);
@@ -832,9 +832,10 @@ __global__ __launch_bounds__(256) void k_pw_from_map(PwMesh mesh, const float *_
 // _inverseGeometricWarp pixel loop :997-1011.  Block = 64 x 4 threads = 4 rows x 256 pixels; blockIdx.z = frame.
 template <int KIND>
 __global__ __launch_bounds__(256) void k_geo(const FrameDesc *__restrict__ frames, const double *__restrict__ mats,
-                                             const uint8_t *__restrict__ img, int W, int H, uint8_t *__restrict__ out)
+                                             const uint8_t *__restrict__ img0, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *__restrict__ out)
 {
     const FrameDesc fd = frames[blockIdx.z];
+    const uint8_t *__restrict__ img = n_imgs > 1 ? img0 + (uint64_t)(blockIdx.z % n_imgs) * img_stride : img0;
     const int r = blockIdx.y * 4 + threadIdx.y;
     const int cq = (blockIdx.x * 64 + threadIdx.x) << 2;
     const int OW = fd.obj_w;
@@ -919,9 +920,10 @@ __global__ void k_selftest_division(uint64_t seed, uint64_t n_per_thread, unsign
 //     range-checked buffer load (0 outside the array), stores through a per-row buffer descriptor (no tail guards).
 template <int KIND>
 __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ frames, const double *__restrict__ mats,
-                                                  const uint8_t *__restrict__ img, int W, int H, uint8_t *__restrict__ out)
+                                                  const uint8_t *__restrict__ img0, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *__restrict__ out)
 {
     const FrameDesc fd = frames[blockIdx.z];
+    const uint8_t *__restrict__ img = n_imgs > 1 ? img0 + (uint64_t)(blockIdx.z % n_imgs) * img_stride : img0;
     const int r = blockIdx.y * 4 + threadIdx.y;            // one wave per row of the block
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x << 8;
@@ -1096,16 +1098,21 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
         return;
     }
     if (map_out) { hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return; }
-    static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;      // experiments only
+#ifdef HG_EXPERIMENTS
+    // Timing experiments of DESIGN.md §6 (ablated variants produce WRONG pixels): only in the separate experiments build
+    // (`make experiments` -> lib/libhgwarp_exp.so); the shipped library has neither the instantiations nor the switch.
+    static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;
     switch (abl) {
-    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
-    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
-    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
-    case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
-    case 16: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 16, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
-    case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
-    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
+    case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
+    case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
+    case 8: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 8, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
+    case 16: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 16, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
+    case 14: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 14, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
+    default: break;
     }
+#endif
+    hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next);
 }
 
 void launch_map_build(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, int32_t *map32, hipStream_t stream)
@@ -1135,20 +1142,20 @@ void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream
 }
 
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
-                const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream)
+                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, hipStream_t stream)
 {
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     dim3 grid((max_w + 255) / 256, (max_h + 3) / 4, n_frames);
     const bool fast = ((int64_t)H + 2) * W * 4 < ((int64_t)1 << 31) && W < (1 << 21) && H < (1 << 22) && max_w < (1 << 28);
     if (fast) {
-        if (kind == 1 && f32_exact) hipLaunchKernelGGL(k_geo_fast<3>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
-        else if (kind == 1) hipLaunchKernelGGL(k_geo_fast<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
-        else if (f32_exact) hipLaunchKernelGGL(k_geo_fast<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
-        else                hipLaunchKernelGGL(k_geo_fast<2>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+        if (kind == 1 && f32_exact) hipLaunchKernelGGL(k_geo_fast<3>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
+        else if (kind == 1) hipLaunchKernelGGL(k_geo_fast<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
+        else if (f32_exact) hipLaunchKernelGGL(k_geo_fast<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
+        else                hipLaunchKernelGGL(k_geo_fast<2>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
         return;
     }
-    if (kind == 0) hipLaunchKernelGGL(k_geo<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
-    else           hipLaunchKernelGGL(k_geo<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, out);
+    if (kind == 0) hipLaunchKernelGGL(k_geo<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
+    else           hipLaunchKernelGGL(k_geo<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
 }
 
 unsigned long long run_selftest_division(uint64_t seed, uint64_t samples, unsigned long long *d_counter, hipStream_t stream)

@@ -24,7 +24,7 @@ EXPORTS = [
     "hg_device_alloc", "hg_device_free", "hg_copy_to_host",
     "hg_solve_affine", "hg_invert_affine", "hg_solve_projective", "hg_transform_limits", "hg_minmax_xy", "hg_js_round",
     "hg_triangulate",
-    "hg_set_image", "hg_set_image_device",
+    "hg_set_image", "hg_set_image_device", "hg_set_images_device",
     "hg_warp_inverse_geometric", "hg_warp_inverse_geometric_device", "hg_geometric_set_frames",
     "hg_warp_inverse_geometric_frames_device", "hg_warp_inverse_geometric_batch_device", "hg_pack_offsets",
     "hg_piecewise_set_mesh", "hg_piecewise_prepare", "hg_warp_inverse_piecewise", "hg_warp_inverse_piecewise_device",
@@ -67,6 +67,7 @@ def lib():
         "hg_transform_limits": (i, [i, f64p, d, d, f64p]), "hg_minmax_xy": (i, [f32p, i, f64p]), "hg_js_round": (d, [d]),
         "hg_triangulate": (i, [f32p, i, C.POINTER(C.c_uint32), i, C.POINTER(i)]),
         "hg_set_image": (i, [vp, u8p, i, i]), "hg_set_image_device": (i, [vp, vp, i, i]),
+        "hg_set_images_device": (i, [vp, vp, i, i, i, sz]),
         "hg_warp_inverse_geometric": (i, [vp, i, f64p, Geom, u8p]), "hg_warp_inverse_geometric_device": (i, [vp, i, f64p, Geom, vp]),
         "hg_geometric_set_frames": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i]),
         "hg_warp_inverse_geometric_frames_device": (i, [vp, vp]),
@@ -281,6 +282,9 @@ class Context:
 
     def set_image_device(self, dptr, w, h):
         self._c(lib().hg_set_image_device(self._h, C.c_void_p(int(dptr)), int(w), int(h)))
+
+    def set_images_device(self, dptr, w, h, n_images, stride_bytes):
+        self._c(lib().hg_set_images_device(self._h, C.c_void_p(int(dptr)), int(w), int(h), int(n_images), int(stride_bytes)))
 
     # ---- affine / projective
     def warp_inverse_geometric(self, kind, m, geom):

@@ -102,6 +102,10 @@ int hg_set_image(hg_ctx *ctx, const uint8_t *rgba, int width, int height);
 /* Same, source already in GPU memory (aliased, not copied: it must stay alive and unchanged while warps run).
  * This is how a source texture received by an RCCL broadcast is attached without another copy. */
 int hg_set_image_device(hg_ctx *ctx, const void *d_rgba, int width, int height);
+/* The video case `for (f) { warp(frame_f) }` (README.md:121-137: every warp() gets its own image, setImage :290 per
+ * frame): n_images sources of identical size, `stride_bytes` apart in GPU memory (aliased).  Frame f of a frame set
+ * (hg_*_set_frames) then reads image f % n_images; n_images == 1 is hg_set_image_device. */
+int hg_set_images_device(hg_ctx *ctx, const void *d_rgba, int width, int height, int n_images, size_t stride_bytes);
 
 /* ------------------------------------------------------------------------------------------------ affine / projective
  * _inverseGeometricWarp pixel loop :997-1011 (+ applyAffineTransformToPoint :1382 / applyProjectiveTransformToPoint

@@ -42,8 +42,16 @@ def _worker(rank, world, port, shape, q):
         h, w = shape
         want = torch.from_numpy(WL.lcg_image(w, h, 5))
         img = want.clone() if rank == 0 else torch.zeros_like(want)
-        got = D.broadcast_source(img, rank, world, dist)
+        got = D.broadcast_source(img, rank, world, dist, verify=True)
         ok = bool(torch.equal(got, want))
+        bad = got.clone()
+        if rank == 1:
+            bad.view(-1)[5] ^= 1                               # one flipped bit on one rank must be noticed by every rank
+        try:
+            D.verify_replicas(bad, dist)
+            ok = False
+        except RuntimeError:
+            pass
         frames = list(D.shard_frames(11, rank, world))
         q.put((rank, ok, frames))
     finally:
@@ -67,3 +75,22 @@ def test_broadcast_source_gloo_world2(shape):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
     assert sorted(f for _, _, fr in res for f in fr) == list(range(11))
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` (what the driver runs) re-executes itself under torch.distributed.run: the dry run prints
+    the exact command without needing a GPU."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2", "--launch-dry-run"],
+                       capture_output=True, text=True, timeout=120, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert p.returncode == 0, p.stderr
+    cmd = json.loads(p.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    # under torchrun's environment the same invocation does not re-launch
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-dry-run"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, WORLD_SIZE="8", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["launch"] is None

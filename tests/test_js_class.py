@@ -12,7 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NODE = shutil.which("node")
 ADDON = os.path.join(ROOT, "homography.js_amd", "lib", "hgwarp.node")
 
-pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON), reason="node or the N-API addon is missing")
+HAVE_JS = NODE is not None and os.path.exists(ADDON)
+# CPU-side JS tests skip without Node; the GPU ones FAIL instead (below): on a GPU box a missing node / addon must not make
+# the JavaScript drop-in's parity tests silently vanish.
+needs_js = pytest.mark.skipif(not HAVE_JS, reason="node or the N-API addon is missing")
+
+
+def _require_js_on_gpu():
+    assert NODE is not None, "node is not on PATH on this GPU box: the JavaScript drop-in (the product's host side) cannot be tested"
+    assert os.path.exists(ADDON), f"{ADDON} is missing: run `make -C homography.js_amd` (needs /usr/include/node/node_api.h)"
 
 
 def _node(script, *args, timeout=900):
@@ -22,22 +30,26 @@ def _node(script, *args, timeout=900):
     return p.returncode, json.loads(line[-1])
 
 
+@needs_js
 def test_state_machine_replay_matches_reference():
     rc, res = _node("replay_golden.mjs", "--dry")
     assert res["failures"] == [] and rc == 0
     assert res["cases"] >= 78 and res["warps"] >= 83
 
 
+@needs_js
 def test_host_side_javascript():
     rc, res = _node("test_host.mjs")
     assert res["failures"] == [] and rc == 0
 
 
+@needs_js
 def test_png_codec_on_reference_fixture():
     rc, res = _node("test_png.mjs")
     assert res["failures"] == [] and rc == 0
 
 
+@needs_js
 def test_warp_without_gpu_throws_a_string():
     import torch
     if torch.cuda.is_available():
@@ -56,6 +68,7 @@ catch (e) { console.log(JSON.stringify({threw: true, type: typeof e, msg: String
 
 @pytest.mark.gpu
 def test_full_replay_on_gpu_matches_reference_hashes():
+    _require_js_on_gpu()
     rc, res = _node("replay_golden.mjs", timeout=1500)
     assert res["failures"] == [] and rc == 0
     assert res["mode"] == "gpu" and res["warps"] >= 83
@@ -63,6 +76,7 @@ def test_full_replay_on_gpu_matches_reference_hashes():
 
 @pytest.mark.gpu
 def test_batch_and_buffer_aliasing_on_gpu():
+    _require_js_on_gpu()
     rc, res = _node("test_gpu_batch.mjs", timeout=600)
     assert res["failures"] == [] and rc == 0
 
@@ -70,5 +84,6 @@ def test_batch_and_buffer_aliasing_on_gpu():
 @pytest.mark.gpu
 def test_reference_known_answer_png_through_js_class_on_gpu():
     """test/nodeTest.js flow on the reference's own input PNG == the reference's own expected output PNG, byte for byte."""
+    _require_js_on_gpu()
     rc, res = _node("test_png.mjs", "--gpu", timeout=600)
     assert res["failures"] == [] and rc == 0
