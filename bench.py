@@ -186,7 +186,7 @@ def main():
             pts_txt = f"frames {frame_ids[0]}..{frame_ids[-1]} of the {cfg['total_frames']}-frame orbit"
         else:
             sp, tris = wl.grid_points(W, H, cfg["nx"], cfg["ny"]), wl.grid_triangles(cfg["nx"], cfg["ny"])
-            frames = [wl.sin_dst(sp, cfg["A"], 8 + (i % 4)) for i in frame_ids]
+            frames = [wl.sin_grid_dst(W, H, cfg["nx"], cfg["ny"], cfg["A"], 8 + (i % 4)) for i in frame_ids]
             same_as = [None if f < 4 else f % 4 for f in range(F)]     # local frame f has the point set of local frame f mod 4
             mesh_txt = f"{cfg['nx']}x{cfg['ny']}-cell sinusoidal grid"
             pts_txt = "4 distinct destination point sets, sin((8 + f mod 4) x / pi), cycled over the frames (test/benchmark.js:68)"

@@ -61,6 +61,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t max_obj_h;              // max over frames (grid size)
     int32_t row_group;              // output rows per k_pw_rows workgroup: kRowGroup (sparse rows) or 1 (dense meshes)
     int32_t tri_threads;            // k_tri_spans workgroup size: 128, or 64 when the triangles are short (one row per thread)
+    int32_t phase;                  // k_pw_rows: windows whose gathers are issued before their stores (1, 2 or 4)
 };
 
 // Per-output-row span lists of the fast path (k_tri_spans -> k_pw_rows), in global memory.

@@ -391,7 +391,7 @@ __device__ __forceinline__ void span_max4d(int best[4], int d0, int d1, int d2, 
         : "vcc");
 }
 
-template <int CAP, int ABL, bool MAP>
+template <int CAP, int ABL, bool MAP, int PH = 1>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
                                                  int32_t *__restrict__ status_next)
@@ -469,72 +469,95 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     };
 
     // All 256-pixel windows w0, w0 + wstep, ... of one row whose spans sit in LDS slots [base, base + cnt).
+    // PH windows per phase: the gathers of PH windows are issued (each right after its window is resolved, so they overlap
+    // the next window's arithmetic), then the PH x 4 stores.  On gfx9 loads and stores share one in-order counter (vmcnt): with
+    // one window per phase every wait for gather data also waits for the previous window's write acknowledgements, and only 4
+    // requests per wave are ever in flight.  A streaming copy in the same instruction forms (tools/calib_fetch: 4 loads + 4
+    // stores per step 4.7 TB/s, 16 + 16 per step 5.7 TB/s) shows what that costs once the source comes from HBM.
     auto do_row = [&](int row, int cnt, int base, int nan_slot, int w0, int wstep) {
         // "no triangle": smaller than every real key, its low bits address the NaN record
         const int nan_key = (int)0x80000000u | ((base + nan_slot) * 48);
-        double xd0 = (double)(w0 * 256 + lane + fd.x_off);  // x of this lane's first pixel of the window, kept as a double
-        const double xstep = (double)(wstep * 256);
         const int r = r0 + row;
         const int64_t row_px = (int64_t)r * W;
         // Output row: raw buffer of 4*W bytes, so the ragged last window needs no per-pixel guard (stores past the row
         // end are dropped by the hardware range check).
         const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + row_px * 4, 0, W * 4, 0x00020000);
-        for (int w = w0; w < nwin; w += wstep) {
-            const int c0 = w << 8, cq = c0 + lane;          // lane l owns pixels c0 + l + 64k: every gather instruction covers
-            int best[4];                                    // 64 consecutive pixels and every store instruction 256 contiguous bytes
-            uint32_t px[4];
+        // (16-byte stores need 16-byte aligned addresses and must not straddle the row end: the range check drops a store whole)
+        const bool vec_zero = ((W & 3) == 0) && (((fd.out_off + (uint64_t)row_px * 4) & 15) == 0);
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u zero4 = { 0u, 0u, 0u, 0u };
+        for (int wb = w0; wb < nwin; wb += wstep * PH) {
+            uint32_t px[PH][4];
+            bool empty[PH];                                 // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 4; k++) best[k] = nan_key;
-            unsigned long long any = (ABL & 8) ? 1ull : 0ull;
-            if (ABL & 8) { best[0] = best[1] = best[2] = best[3] = (base + w % (cnt > 0 ? cnt : 1)) * 48; }     // (experiments only) no triangle search
-            else for (int j = 0; j < cnt; j += 64) {
-                const int idx = j + lane;
-                int lo = 0x7fffffff, hi = 0;
-                if (idx < cnt) { lo = s_lo[base + idx]; hi = s_hi[base + idx]; }
-                unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
-                any |= mask;
-                while (mask) {
-                    const int bit = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const int slot = base + j + bit;
-                    const int d = cq - s_lo[slot];
-                    span_max4(best, d, s_len[slot], s_key[slot]);   // larger id wins (== last writer of :852-858); its slot rides along
+            for (int p = 0; p < PH; p++) {
+                const int w = wb + p * wstep;               // wave-uniform
+                if (w >= nwin) break;
+                const int c0 = w << 8, cq = c0 + lane;      // lane l owns pixels c0 + l + 64k: every gather instruction covers
+                int best[4];                                // 64 consecutive pixels and every store instruction 256 contiguous bytes
+#pragma unroll
+                for (int k = 0; k < 4; k++) best[k] = nan_key;
+                unsigned long long any = (ABL & 8) ? 1ull : 0ull;
+                if (ABL & 8) { best[0] = best[1] = best[2] = best[3] = (base + w % (cnt > 0 ? cnt : 1)) * 48; }     // (experiments only) no triangle search
+                else for (int j = 0; j < cnt; j += 64) {
+                    const int idx = j + lane;
+                    int lo = 0x7fffffff, hi = 0;
+                    if (idx < cnt) { lo = s_lo[base + idx]; hi = s_hi[base + idx]; }
+                    unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
+                    any |= mask;
+                    while (mask) {
+                        const int bit = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int slot = base + j + bit;
+                        const int d = cq - s_lo[slot];
+                        span_max4(best, d, s_len[slot], s_key[slot]);   // larger id wins (== last writer of :852-858); its slot rides along
+                    }
+                }
+                empty[p] = any == 0;                         // no span of this row reaches the window
+                if (empty[p]) px[p][0] = px[p][1] = px[p][2] = px[p][3] = 0u;
+                else {
+                    double h[8], rd[8];
+                    const double xd0 = (double)(cq + fd.x_off);     // exact: integers far below 2^53
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KMASK));
+                        const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+                        // (ABL & 16, timing experiment only: the access pattern of a 16 px x 4 row lane patch instead of 64 px x 1 row)
+                        const double xd = (ABL & 16) ? (double)(c0 + (lane & 15) + 16 * k + fd.x_off) : xd0 + (double)(k * 64);
+                        // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
+                        // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
+                        h[2 * k]     = fma(m0.x, xd, m0.y) + m1.x;
+                        h[2 * k + 1] = fma(m1.y, xd, m2.x) + m2.y;
+                        if (ABL & 16) h[2 * k + 1] += (double)(lane >> 4);
+                    }
+                    round_x8(h, rd);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi);   // NaN fails
+                        const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
+                        const uint32_t off = inb ? o : 0xffffffffu;
+                        px[p][k] = (ABL & 2) ? off : __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0);       // outside the array -> 0
+                    }
+                }
+                if (MAP) {                                  // parity tap (hg_get_tri_map_fused): a separate instantiation
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (cq + k * 64 < W) map_out[fd.map_off + row_px + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> KS);
                 }
             }
-            if (any == 0) px[0] = px[1] = px[2] = px[3] = 0u;       // no span of this row reaches the window (wave-uniform)
-            else {
-                double h[8], rd[8];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KMASK));
-                    const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                    // (ABL & 16, timing experiment only: the access pattern of a 16 px x 4 row lane patch instead of 64 px x 1 row)
-                    const double xd = (ABL & 16) ? (double)(c0 + (lane & 15) + 16 * k + fd.x_off) : xd0 + (double)(k * 64);     // exact: integers far below 2^53
-                    // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
-                    // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
-                    h[2 * k]     = fma(m0.x, xd, m0.y) + m1.x;
-                    h[2 * k + 1] = fma(m1.y, xd, m2.x) + m2.y;
-                    if (ABL & 16) h[2 * k + 1] += (double)(lane >> 4);
-                }
-                round_x8(h, rd);
+            for (int p = 0; p < PH; p++) {
+                const int w = wb + p * wstep;
+                if (w >= nwin) break;
+                const int cq = (w << 8) + lane;
+                if (ABL & 4) { if ((px[p][0] ^ px[p][1] ^ px[p][2] ^ px[p][3]) != 0x9e3779b9u) continue; }
+                if (empty[p] && vec_zero) {                 // 1 KB of zeros: which lane writes which pixel does not matter -> one 16-byte store per lane
+                    __builtin_amdgcn_raw_buffer_store_b128(zero4, dst, ((w << 8) + lane * 4) * 4, 0, kStoreNT);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi);   // NaN fails
-                    const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
-                    const uint32_t off = inb ? o : 0xffffffffu;
-                    px[k] = (ABL & 2) ? off : __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0);       // outside the array -> 0
+                    for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[p][k], dst, (cq + k * 64) * 4, 0, kStoreNT);
                 }
             }
-            if (!(ABL & 4) || (px[0] ^ px[1] ^ px[2] ^ px[3]) == 0x9e3779b9u) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[k], dst, (cq + k * 64) * 4, 0, kStoreNT);
-            }
-            if (MAP) {                                      // parity tap (hg_get_tri_map_fused): a separate instantiation
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (cq + k * 64 < W) map_out[fd.map_off + row_px + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> KS);
-            }
-            xd0 += xstep;
         }
     };
 
@@ -1112,7 +1135,11 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     default: break;
     }
 #endif
-    hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next);
+    switch (fr.phase) {
+    case 4:  hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false, 4>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    case 2:  hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false, 2>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    }
 }
 
 void launch_map_build(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, int32_t *map32, hipStream_t stream)

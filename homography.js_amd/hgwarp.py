@@ -21,7 +21,7 @@ HG_AFFINE, HG_PROJECTIVE = 0, 1
 # every symbol include/hgwarp.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "hg_version", "hg_device_count", "hg_create", "hg_create_on_stream", "hg_destroy", "hg_last_error", "hg_sync",
-    "hg_device_alloc", "hg_device_free", "hg_copy_to_host",
+    "hg_device_alloc", "hg_device_free", "hg_copy_to_host", "hg_copy_to_device",
     "hg_solve_affine", "hg_invert_affine", "hg_solve_projective", "hg_transform_limits", "hg_minmax_xy", "hg_js_round",
     "hg_triangulate",
     "hg_set_image", "hg_set_image_device", "hg_set_images_device",
@@ -62,7 +62,7 @@ def lib():
         "hg_version": (i, []), "hg_device_count": (i, [C.POINTER(i)]),
         "hg_create": (i, [i, C.POINTER(vp)]), "hg_create_on_stream": (i, [i, vp, C.POINTER(vp)]), "hg_destroy": (None, [vp]),
         "hg_last_error": (C.c_char_p, [vp]), "hg_sync": (i, [vp]),
-        "hg_device_alloc": (i, [vp, sz, C.POINTER(vp)]), "hg_device_free": (i, [vp, vp]), "hg_copy_to_host": (i, [vp, vp, vp, sz]),
+        "hg_device_alloc": (i, [vp, sz, C.POINTER(vp)]), "hg_device_free": (i, [vp, vp]), "hg_copy_to_host": (i, [vp, vp, vp, sz]), "hg_copy_to_device": (i, [vp, vp, vp, sz]),
         "hg_solve_affine": (i, [f32p, f32p, f32p]), "hg_invert_affine": (i, [f32p, f32p]), "hg_solve_projective": (i, [f32p, f32p, f64p]),
         "hg_transform_limits": (i, [i, f64p, d, d, f64p]), "hg_minmax_xy": (i, [f32p, i, f64p]), "hg_js_round": (d, [d]),
         "hg_triangulate": (i, [f32p, i, C.POINTER(C.c_uint32), i, C.POINTER(i)]),
@@ -241,6 +241,10 @@ class Context:
         out = np.empty(int(nbytes), np.uint8)
         self._c(lib().hg_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr + offset), int(nbytes)))
         return out
+
+    def to_device(self, dptr, arr, offset=0):
+        a = np.ascontiguousarray(arr)
+        self._c(lib().hg_copy_to_device(self._h, C.c_void_p(dptr + offset), a.ctypes.data_as(C.c_void_p), a.nbytes))
 
     def set_timing(self, on=True):
         self._c(lib().hg_set_timing(self._h, 1 if on else 0))

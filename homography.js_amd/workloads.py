@@ -55,6 +55,17 @@ def sin_dst(src_pts, A, n=8):
     return d.astype(np.float32).ravel()
 
 
+def sin_grid_dst(W, H, nx, ny, A, n=8):
+    """Destination points of the sinusoidal grid computed like the reference's harness does (and tests/golden/gen_golden.mjs):
+    from the UNROUNDED double grid coordinates x = i*(W/nx), y = j*(H/ny), then stored as float32.  Differs from
+    sin_dst(grid_points(...)) whenever W/nx is not a float32 value (C5: 153.6), where the f32-rounded x moves the sine."""
+    xs = np.arange(nx + 1, dtype=np.float64) * (W / nx)
+    ys = np.arange(ny + 1, dtype=np.float64) * (H / ny)
+    gx, gy = np.meshgrid(xs, ys)
+    d = np.stack([gx, A + gy + np.sin((n * gx) / np.pi) * A], -1)
+    return d.astype(np.float32).ravel()
+
+
 def piecewise_geom(dst_pts):
     """_induceBestObjectiveWidthAndHeight, piecewise / pixel-coordinate branch (:706-710): round each of min/max, then subtract."""
     p = np.asarray(dst_pts, np.float32).reshape(-1, 2).astype(np.float64)
@@ -91,7 +102,9 @@ CONFIGS = {
     # 68-landmark face mesh, 512 frames in total; triangles from the host Delaunay (hg_triangulate)
     "C4": dict(kind="face", W=3840, H=2160, landmarks=68, total_frames=512),
     "C5": dict(kind="piecewise", W=7680, H=4320, nx=50, ny=50, A=80.0),
-    # experiment only: C5's mesh density without its steep shear
+    # experiments only: the same meshes (almost) without vertical displacement
+    "C3flat": dict(kind="piecewise", W=3840, H=2160, nx=10, ny=10, A=1.0),
+    # C5's mesh density without its steep shear
     "C5flat": dict(kind="piecewise", W=7680, H=4320, nx=50, ny=50, A=8.0),
 }
 
@@ -100,7 +113,7 @@ def piecewise_frames(cfg, n_frames):
     """Source mesh + n_frames destination point sets: sin((8 + f mod 4) * x / pi) as in test/benchmark.js:68."""
     sp = grid_points(cfg["W"], cfg["H"], cfg["nx"], cfg["ny"])
     tris = grid_triangles(cfg["nx"], cfg["ny"])
-    frames = [sin_dst(sp, cfg["A"], 8 + (f % 4)) for f in range(n_frames)]
+    frames = [sin_grid_dst(cfg["W"], cfg["H"], cfg["nx"], cfg["ny"], cfg["A"], 8 + (f % 4)) for f in range(n_frames)]
     geoms = [piecewise_geom(d) for d in frames]
     return sp, tris, frames, geoms
 

@@ -72,6 +72,7 @@ int hg_sync(hg_ctx *ctx);
 int hg_device_alloc(hg_ctx *ctx, size_t bytes, void **dptr);
 int hg_device_free(hg_ctx *ctx, void *dptr);
 int hg_copy_to_host(hg_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+int hg_copy_to_device(hg_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------------ host-side solves
  * Tiny, run on the host in double precision with the reference's exact operation order; no GPU needed. */
@@ -180,7 +181,8 @@ long hg_redone_frames(hg_ctx *ctx);
  * which kernel layout the next hg_piecewise_set_frames picks:
  *   "min_row_groups" (default 1536): frame sets with fewer 4-row groups run one row per workgroup;
  *   "patch" (default -1 = by estimate): 0 never use k_pw_patch, 1 use it whenever the frame width allows, 2 the same in its
- *           global-record variant. */
+ *           global-record variant;
+ *   "phase" (default -1 = 2 for a shared source, 1 with one source per frame): windows per k_pw_rows gather/store phase, 1, 2 or 4. */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);
 /* Host-side proof obligation of that division (no GPU needed): 1 if every pixel of the window `geom` under the inverse
  * projective matrix m[8] keeps numerators and denominator in the plain range (entries 0 or in [2^-100, 2^100], coordinates

@@ -18,7 +18,8 @@ GOLD = G.load()
 # The piecewise fast path picks a kernel layout from the frame set (rows per workgroup, k_pw_patch for dense sheared meshes);
 # results must not depend on it, so every test that takes `ctx` runs under each layout policy.
 LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0}, "rows1": {"min_row_groups": 1 << 30, "patch": 0},
-           "patch": {"min_row_groups": 0, "patch": 1}, "patch_global": {"min_row_groups": 0, "patch": 2}}
+           "patch": {"min_row_groups": 0, "patch": 1}, "patch_global": {"min_row_groups": 0, "patch": 2},
+           "phase1": {"phase": 1, "patch": 0}, "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))
@@ -203,6 +204,84 @@ def test_batch_frames_equal_single_frames(ctx):
             g = ggeoms[f]
             got = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
             assert np.array_equal(got, O.warp_inverse_geometric(1, mats[f], img, *g)), f
+    finally:
+        ctx.free(d_out)
+
+
+def test_one_source_per_frame(ctx):
+    """hg_set_images_device: frame f of a frame set reads image f % n_images (the video case, every warp() its own image).
+    Piecewise (incl. a frame forced through the map path) and projective, against the oracle frame by frame."""
+    W, H, nx, ny, F, NI = 288, 180, 9, 6, 7, 3
+    imgs = [G.lcg_image(W, H, 100 + k) for k in range(NI)]
+    stride = W * H * 4 + 64                                 # images need not be densely packed
+    sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+    frames = [WL.sin_dst(sp, 5.0 + f, 8 + (f % 4)) for f in range(F)]
+    geoms = [WL.piecewise_geom(d) for d in frames]
+    mm = O.minmax_xy(sp)
+    d_src = ctx.alloc(stride * NI)
+    offs, total = HG.pack_offsets(geoms)
+    d_out = ctx.alloc(total)
+    try:
+        for k in range(NI):
+            ctx.to_device(d_src, imgs[k], k * stride)
+        ctx.set_images_device(d_src, W, H, NI, stride)
+        ctx.piecewise_set_mesh(sp, tris, int(mm[0]), int(mm[1]))
+        ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+        ctx.warp_inverse_piecewise_frames_device(d_out)
+        ctx.sync()
+        for f in range(F):
+            g = geoms[f]
+            got = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+            want = O.warp_inverse_piecewise(sp, frames[f], tris, imgs[f % NI], int(mm[0]), int(mm[1]), *g)
+            assert np.array_equal(got, want), ("piecewise", f)
+        mats, ggeoms = [], []
+        s4 = np.array([0, 0, 0, H, W, 0, W, H], np.float32)
+        for f in range(F):
+            d4 = WL.projective_dst(W, H, 0.02 * f)
+            ggeoms.append(tuple(int(v) for v in O.transform_limits(1, O.projective_from_squares(s4, d4), W, H)))
+            mats.append(HG.solve_projective(d4, s4))
+        goffs, gtotal = HG.pack_offsets(ggeoms)
+        assert gtotal <= total
+        ctx.geometric_set_frames(1, np.concatenate(mats), ggeoms, goffs)
+        ctx.warp_inverse_geometric_frames_device(d_out)
+        ctx.sync()
+        for f in range(F):
+            g = ggeoms[f]
+            got = ctx.to_host(d_out, g[2] * g[3] * 4, goffs[f]).reshape(g[3], g[2], 4)
+            assert np.array_equal(got, O.warp_inverse_geometric(1, mats[f], imgs[f % NI], *g)), ("projective", f)
+    finally:
+        ctx.set_image(imgs[0])                               # drop the alias before the buffer goes away
+        ctx.free(d_out)
+        ctx.free(d_src)
+
+
+def test_failed_set_frames_leaves_no_frame_set(ctx):
+    """A frame set that fails validation part-way (offset beyond 2^26 in the LAST frame) must not leave the new
+    host-side frames over device buffers sized for the old set: the next warp reports HG_ERR_STATE."""
+    W, H = 64, 48
+    ctx.set_image(G.lcg_image(W, H, 5))
+    sp, tris = WL.grid_points(W, H, 2, 2), WL.grid_triangles(2, 2)
+    ctx.piecewise_set_mesh(sp, tris, 0, 0)
+    dp = WL.sin_dst(sp, 2.0, 8)
+    g = WL.piecewise_geom(dp)
+    ctx.piecewise_set_frames(dp, [g])
+    d_out = ctx.alloc(g[2] * g[3] * 4 * 4)
+    try:
+        ctx.warp_inverse_piecewise_frames_device(d_out)
+        ctx.sync()
+        bad = [g, g, g, (1 << 27, 0, g[2], g[3])]
+        with pytest.raises(HG.HgError):
+            ctx.piecewise_set_frames(np.concatenate([dp] * 4), bad)
+        with pytest.raises(HG.HgError) as e:
+            ctx.warp_inverse_piecewise_frames_device(d_out)
+        assert e.value.code == 4                             # HG_ERR_STATE
+        m = HG.solve_projective(WL.projective_dst(W, H), WL.corners(W, H))
+        ctx.geometric_set_frames(1, m, [(0, 0, W, H)])
+        with pytest.raises(HG.HgError):
+            ctx.geometric_set_frames(1, np.concatenate([m] * 2), [(0, 0, W, H), (0, 1 << 27, W, H)])
+        with pytest.raises(HG.HgError) as e:
+            ctx.warp_inverse_geometric_frames_device(d_out)
+        assert e.value.code == 4
     finally:
         ctx.free(d_out)
 

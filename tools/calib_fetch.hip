@@ -76,6 +76,35 @@ __global__ __launch_bounds__(256) void calib_store4_nt(uint8_t *__restrict__ p, 
     }
 }
 
+// mixed read + write streams (what a warp kernel with one source per frame does): N/2 bytes read, N/2 bytes written
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void calib_copy16(const v4u *__restrict__ src, v4u *__restrict__ dst, size_t n16)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n16; i += stride) {
+        const v4u v = src[i];
+        if (NT) __builtin_nontemporal_store(v, &dst[i]); else dst[i] = v;
+    }
+}
+
+// 4 B/lane buffer loads + 4 B/lane non-temporal buffer stores, U independent loads in flight per lane
+template <int U>
+__global__ __launch_bounds__(256) void calib_copy4_nt(const uint8_t *__restrict__ s, uint8_t *__restrict__ d, uint32_t len)
+{
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(s), 0, len, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(d, 0, len, 0x00020000);
+    const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = gridDim.x * 4u;
+    for (uint32_t base = wave * (U * 256u); base < len; base += nwaves * (U * 256u)) {
+        uint32_t v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(src, base + k * 256u + lane * 4u, 0, 0);
+#pragma unroll
+        for (int k = 0; k < U; k++) __builtin_amdgcn_raw_buffer_store_b32(v[k], dst, base + k * 256u + lane * 4u, 0, 2);
+    }
+}
+
 int main(int argc, char **argv)
 {
     const size_t bytes = (argc > 1 ? (size_t)atoll(argv[1]) : (size_t)2048) << 20;
@@ -89,7 +118,8 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct { const char *name; int id; } tests[] = { {"calib_load16", 0}, {"calib_load4", 1}, {"calib_load4_line", 2}, {"calib_load4_half", 3},
-                                                     {"calib_store16", 4}, {"calib_store4_nt", 5} };
+                                                     {"calib_store16", 4}, {"calib_store4_nt", 5},
+                                                     {"calib_copy16", 6}, {"calib_copy16_nt", 7}, {"calib_copy4_nt_x4", 8}, {"calib_copy4_nt_x16", 9} };
     for (auto &t : tests) {
         float best = 1e30f;
         for (int r = 0; r < reps; r++) {
@@ -101,6 +131,10 @@ int main(int argc, char **argv)
             case 3: hipLaunchKernelGGL(calib_load4_sparse<64>, grid, block, 0, 0, buf, bytes, sink); break;
             case 4: hipLaunchKernelGGL(calib_store16, grid, block, 0, 0, (uint4 *)buf, bytes / 16); break;
             case 5: hipLaunchKernelGGL(calib_store4_nt, grid, block, 0, 0, buf, bytes); break;
+            case 6: hipLaunchKernelGGL(calib_copy16<false>, grid, block, 0, 0, (const v4u *)buf, (v4u *)(buf + bytes / 2), bytes / 32); break;
+            case 7: hipLaunchKernelGGL(calib_copy16<true>, grid, block, 0, 0, (const v4u *)buf, (v4u *)(buf + bytes / 2), bytes / 32); break;
+            case 8: hipLaunchKernelGGL(calib_copy4_nt<4>, grid, block, 0, 0, buf, buf + bytes / 2, (uint32_t)(bytes / 2)); break;
+            case 9: hipLaunchKernelGGL(calib_copy4_nt<16>, grid, block, 0, 0, buf, buf + bytes / 2, (uint32_t)(bytes / 2)); break;
             }
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));

@@ -11,9 +11,10 @@ import sqlite3, glob, json
 res = {}
 for db in sorted(glob.glob('$out/*/*.db') + glob.glob('$out/*/*/*.db')):
     con = sqlite3.connect(db)
-    for r in con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like 'calib%' group by kernel_name, counter_name"):
-        res.setdefault(r[0].split('(')[0], {})[r[1]] = {"dispatches": r[2], "avg": r[3]}
+    for r in con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%calib%' group by kernel_name, counter_name"):
+        res.setdefault(r[0].split('(')[0].replace('void ', ''), {})[r[1]] = {"dispatches": r[2], "avg": r[3]}
 json.dump(res, open('$out/calib.json', 'w'), indent=1)
 print(json.dumps(res, indent=1))
 PY
 cat $out/plain.jsonl
+rm -rf $out/f $out/w

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Kernel-time sweep over hg_set_option knobs:  python tools/sweep.py CONFIG[,CONFIG..] key=v1,v2,.. [key=...] [--sources shared,distinct] [--frames F]
+Prints the mean hipEvent duration of the dominant kernel and of the whole step for every combination."""
+import importlib.util, itertools, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+def load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "homography.js_amd", rel))
+    m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+
+def main():
+    import numpy as np, torch
+    hg, wl = load("hgwarp", "hgwarp.py"), load("hg_workloads", "workloads.py")
+    args = sys.argv[1:]
+    configs = args[0].split(",")
+    knobs, sources, Fopt = {}, ["shared", "distinct"], None
+    i = 1
+    while i < len(args):
+        if args[i] == "--sources": sources = args[i + 1].split(","); i += 2
+        elif args[i] == "--frames": Fopt = int(args[i + 1]); i += 2
+        else: k, v = args[i].split("="); knobs[k] = [int(x) for x in v.split(",")]; i += 1
+    dev = torch.device("cuda", 0)
+    for config in configs:
+        cfg = wl.CONFIGS[config]; W, H = cfg["W"], cfg["H"]
+        F = Fopt or {"C5": 8, "C5flat": 8}.get(config, 64)
+        img = torch.from_numpy(wl.lcg_image(W, H, 1)).to(dev)
+        srcs = None
+        if cfg["kind"] == "face":
+            sp = wl.face_mesh(W, H, cfg["landmarks"]); tris = hg.triangulate(sp); seq = wl.face_frames(sp, W, cfg["total_frames"])
+            frames = [seq[f] for f in range(F)]
+        else:
+            sp, tris = wl.grid_points(W, H, cfg["nx"], cfg["ny"]), wl.grid_triangles(cfg["nx"], cfg["ny"])
+            frames = [wl.sin_grid_dst(W, H, cfg["nx"], cfg["ny"], cfg["A"], 8 + f % 4) for f in range(F)]
+        geoms = [wl.piecewise_geom(d) for d in frames]
+        msx, msy = wl.src_min(sp)
+        offs, total = hg.pack_offsets(geoms)
+        out = torch.empty(total, dtype=torch.uint8, device=dev)
+        ref = None
+        for src in sources:
+            for combo in itertools.product(*knobs.values()):
+                stream = torch.cuda.Stream(device=dev)
+                ctx = hg.Context(0, stream=stream.cuda_stream)
+                for k, v in zip(knobs, combo): ctx.set_option(k, v)
+                if src == "distinct":
+                    if srcs is None: srcs = img.unsqueeze(0).repeat(F, 1, 1, 1)
+                    ctx.set_images_device(srcs.data_ptr(), W, H, F, W * H * 4)
+                else:
+                    ctx.set_image_device(img.data_ptr(), W, H)
+                ctx.piecewise_set_mesh(sp, tris, msx, msy)
+                ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                out.zero_(); torch.cuda.synchronize()
+                for _ in range(60): ctx.warp_inverse_piecewise_frames_device(out.data_ptr())
+                ctx.sync()
+                if ref is None: ref = out.clone()
+                same = bool(torch.equal(ref, out))
+                ctx.set_timing(True)
+                t0 = time.perf_counter()
+                for _ in range(100): ctx.warp_inverse_piecewise_frames_device(out.data_ptr())
+                ctx.sync()
+                dt = (time.perf_counter() - t0) / 100 * 1e3
+                tot, n = ctx.kernel_ms_stats()
+                print(json.dumps({"config": config, "F": F, "sources": src, **dict(zip(knobs, combo)), "kernel": ctx.last_piecewise_kernel(),
+                                  "kernel_ms": round(tot / n, 4), "step_ms": round(dt, 4), "same_bytes": same, "redone": ctx.redone_frames()}), flush=True)
+                ctx.close()
+
+if __name__ == "__main__":
+    main()
