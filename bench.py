@@ -6,7 +6,7 @@ A "step" is one pass of the hot path over one batch of synthetic input: F destin
 sets cycled over the F frames, the pattern of the reference's own harness test/benchmark.js:68,107-110).  Per step and
 per frame the library does what the reference redoes per frame (`setDestinyPoints(dst_f); warp()`): per-triangle affine
 solves + inverses + triangle spans (k_tri_spans) and the inverse piecewise warp (k_pw_rows, the dominant kernel); for the
-projective config C2 the 8x8 DLT solve of every frame (k_solve_projective) is part of the step as well.  Inputs (source
+projective config C2 the 8x8 DLT solve of every frame (k_solve_frames) is part of the step as well.  Inputs (source
 RGBA, meshes, destination points) are resident in HBM before the timed region; outputs stay in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config C3|C4|C5|C2] [--sources both|shared|distinct]
@@ -205,16 +205,12 @@ def main():
         pts_txt = "10 distinct corner sets cycled over the frames (test/benchmark.js:282-283 pattern, animated)"
         # output windows (calculateTransformLimits :1503-1527 on the forward matrix) are host-side scalar work done at
         # setDestinyPoints time; the INVERSE 8x8 solve the reference repeats on every warp (:994) runs on the device inside
-        # the timed step (hg_projective_set_frames_points -> k_solve_projective)
+        # the timed step (hg_geometric_set_frames_points -> k_solve_frames)
         geoms = [tuple(int(v) for v in hg.transform_limits(1, hg.solve_projective(s4, d4), W, H)) for d4 in d4s]
         mats = [hg.solve_projective(d4, s4) for d4 in d4s]              # host copies: CPU baseline + cross-check only
         offs, total = hg.pack_offsets(geoms)
-        if hasattr(ctx, "projective_set_frames_points"):
-            ctx.projective_set_frames_points(np.tile(s4, F), np.concatenate(d4s), geoms, offs, swap=True)
-            solve_txt = ", 8x8 DLT solve per frame on the device inside the step"
-        else:
-            ctx.geometric_set_frames(1, np.concatenate(mats), geoms, offs)
-            solve_txt = ""
+        ctx.geometric_set_frames_points(1, np.concatenate(d4s), np.tile(s4, F), geoms, offs)     # inverse: dst -> src (:994)
+        solve_txt = ", 8x8 DLT solve per frame on the device inside the step"
         run = ctx.warp_inverse_geometric_frames_device
         workload = f"{args.config}: {W}x{H} RGBA projective, 4 corner points, {F} frames/GPU/step{solve_txt}"
 

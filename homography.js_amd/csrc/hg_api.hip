@@ -77,6 +77,9 @@ struct hg_ctx {
     std::vector<FrameDesc> geo_frames;
     FrameDesc *d_geo_frames = nullptr; size_t geo_frames_cap = 0;
     double *d_mats = nullptr; size_t mats_cap = 0;
+    bool geo_from_points = false;                              // matrices are (re)solved on the device at every warp (hg_geometric_set_frames_points)
+    float *d_geo_pts = nullptr; size_t geo_pts_cap = 0;        // F x (from | to) point sets
+    int32_t *d_geo_plain = nullptr; size_t geo_plain_cap = 0;  // per-frame "plain division range" flags written by k_solve_frames
 
     // scratch
     int32_t *d_map32 = nullptr; size_t map32_cap = 0;
@@ -182,7 +185,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
     void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent,
-                     c->d_geo_frames, c->d_mats, c->d_map32, c->d_fmap, c->d_win32, c->d_map16, c->d_out_tmp };
+                     c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -313,44 +316,12 @@ extern "C" int hg_invert_affine(const float m[6], float out[6])
     return HG_OK;
 }
 
-// projectiveMatrixFromSquares :1320-1333: the 8x8 DLT system, solved exactly as numeric.js does (:1650-1751):
-// Doolittle LU with partial pivoting (strict '<', first maximum wins), rows exchanged by reference, then the
-// permuted forward and the backward substitution.  8x8 once per frame: host side, microseconds.
+// projectiveMatrixFromSquares :1320-1333 + numeric.js solve :1650-1751.  One restatement for host and device
+// (solve_projective_regs, hg_math.h): the same function k_solve_frames runs per frame on the GPU.
 extern "C" int hg_solve_projective(const float s[8], const float d[8], double out[8])
 {
     if (!s || !d || !out) return fail(nullptr, HG_ERR_INVALID, "NULL pointer");
-    double buf[8][8];
-    double *A[8];
-    for (int p = 0; p < 4; p++) {
-        const double x = s[2 * p], y = s[2 * p + 1], u = d[2 * p], v = d[2 * p + 1];
-        const double r0[8] = { x, y, 1, 0, 0, 0, -u * x, -u * y };
-        const double r1[8] = { 0, 0, 0, x, y, 1, -v * x, -v * y };
-        for (int j = 0; j < 8; j++) { buf[2 * p][j] = r0[j]; buf[2 * p + 1][j] = r1[j]; }
-    }
-    for (int i = 0; i < 8; i++) A[i] = buf[i];
-    int P[8];
-    for (int k = 0; k < 8; k++) {
-        int pk = k;
-        double best = fabs(A[k][k]);
-        for (int j = k + 1; j < 8; j++) { const double v = fabs(A[j][k]); if (best < v) { best = v; pk = j; } }
-        P[k] = pk;
-        if (pk != k) std::swap(A[k], A[pk]);
-        const double *Ak = A[k];
-        const double akk = Ak[k];
-        for (int i = k + 1; i < 8; i++) A[i][k] /= akk;
-        for (int i = k + 1; i < 8; i++) { double *Ai = A[i]; for (int j = k + 1; j < 8; j++) Ai[j] -= Ai[k] * Ak[j]; }
-    }
-    double x[8];
-    for (int i = 0; i < 8; i++) x[i] = d[i];
-    for (int i = 0; i < 8; i++) {
-        if (P[i] != i) std::swap(x[i], x[P[i]]);
-        for (int j = 0; j < i; j++) x[i] -= x[j] * A[i][j];
-    }
-    for (int i = 7; i >= 0; i--) {
-        for (int j = i + 1; j < 8; j++) x[i] -= x[j] * A[i][j];
-        x[i] /= A[i][i];
-    }
-    for (int i = 0; i < 8; i++) out[i] = x[i];
+    solve_projective_regs(s, d, out);
     return HG_OK;
 }
 
@@ -455,34 +426,7 @@ static int fill_frames(hg_ctx *c, std::vector<FrameDesc> &v, const hg_geom *geom
 }
 
 // ------------------------------------------------------------------------------------------------ affine / projective
-// Can every division (m0*x + m1*y + m2) / (m6*x + m7*y + 1), (m3*x + m4*y + m5) / (same) of this frame be done by
-// div2_plain (hg_kernels.hip), i.e. without the scaling / special-value steps of the full IEEE expansion?
-//   * matrix entries finite, each 0 or 2^-100 <= |m| <= 2^100; pixel coordinates |x|, |y| < 2^28
-//     => numerators are 0 or in [2^-210, 2^130] (a non-zero sum of two such roundings cannot fall below 2^-206);
-//   * the denominator, evaluated in the kernel's own operation order, is weakly monotone along x and along y (every
-//     rounding is), so over the window it lies between its values at the four corners: same sign at all four and
-//     2^-100 <= |den| <= 2^130 there => the same holds at every pixel.
-static bool geo_plain_division(const double *m, const hg_geom &g)
-{
-    const double lo = 0x1p-100, hi = 0x1p100;
-    for (int k = 0; k < 8; k++) {
-        const double a = std::fabs(m[k]);
-        if (!(a == a) || !(a == 0.0 || (a >= lo && a <= hi))) return false;
-    }
-    if (g.obj_w <= 0 || g.obj_h <= 0) return true;
-    const int64_t x0 = g.x_off, x1 = (int64_t)g.x_off + g.obj_w + 255, y0 = g.y_off, y1 = (int64_t)g.y_off + g.obj_h - 1;   // (+255: the ragged last window is computed too)
-    if (std::max(std::llabs(x0), std::llabs(x1)) >= (1ll << 28) || std::max(std::llabs(y0), std::llabs(y1)) >= (1ll << 28)) return false;
-    double dmin = INFINITY, dmax = -INFINITY;
-    for (int64_t y : {y0, y1}) for (int64_t x : {x0, x1}) {
-        const double ad = m[7] * (double)y;
-        const double den = ((m[6] * (double)x) + ad) + 1.0;                  // :1402-1403, the kernel's order
-        dmin = std::min(dmin, den); dmax = std::max(dmax, den);
-    }
-    if (!(dmin == dmin) || !(dmax == dmax)) return false;
-    if (dmin > 0) return dmin >= lo && dmax <= 0x1p130;
-    if (dmax < 0) return -dmax >= lo && -dmin <= 0x1p130;
-    return false;
-}
+static bool geo_plain_division(const double *m, const hg_geom &g) { return projective_plain_range(m, g.x_off, g.y_off, g.obj_w, g.obj_h); }   // hg_math.h
 
 extern "C" int hg_projective_plain_range(const double *m, hg_geom geom)
 {
@@ -517,7 +461,7 @@ extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, con
     HIP_TRY(c, hipMemcpyAsync(c->d_mats, m, sizeof(double) * 8 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->geo_frames.swap(fresh);
-    c->geo_kind = kind;
+    c->geo_kind = kind; c->geo_from_points = false;
     bool exact = kind == HG_AFFINE;
     for (int f = 0; f < n && exact; f++) {
         for (int k = 0; k < 6; k++) exact = exact && (double)(float)m[8 * f + k] == m[8 * f + k];
@@ -531,6 +475,41 @@ extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, con
     return HG_OK;
 }
 
+extern "C" int hg_geometric_set_frames_points(hg_ctx *c, int kind, const float *from, const float *to, const hg_geom *geoms, const size_t *offs, int n)
+{
+    HG_TRY(bind(c));
+    if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !from || !to || !geoms || n <= 0) return fail(c, HG_ERR_INVALID, "hg_geometric_set_frames_points: bad arguments");
+    const size_t per = kind == HG_AFFINE ? 6 : 8;
+    c->geo_frames.clear();                                  // transactional, like hg_geometric_set_frames
+    std::vector<FrameDesc> fresh;
+    HG_TRY(fill_frames(c, fresh, geoms, offs, n));
+    HG_TRY(ensure(c, c->d_geo_frames, c->geo_frames_cap, (size_t)n));
+    HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)n * 8));
+    HG_TRY(ensure(c, c->d_geo_pts, c->geo_pts_cap, (size_t)n * 16));
+    HG_TRY(ensure(c, c->d_geo_plain, c->geo_plain_cap, (size_t)n));
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, fresh.data(), sizeof(FrameDesc) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_pts, from, sizeof(float) * per * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_pts + (size_t)n * 8, to, sizeof(float) * per * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->geo_frames.swap(fresh);
+    c->geo_kind = kind; c->geo_from_points = true;
+    bool exact = kind == HG_AFFINE;                          // affine: the solve stores float32 values; x stays below 2^28?
+    for (int f = 0; f < n && exact; f++) exact = std::abs((int64_t)geoms[f].x_off) + std::max(geoms[f].obj_w, 0) < (1 << 28);
+    c->geo_f32_exact = exact;
+    return HG_OK;
+}
+
+extern "C" int hg_get_geometric_matrices(hg_ctx *c, double *out, int n_frames)
+{
+    HG_TRY(bind(c));
+    if (!out || n_frames <= 0 || (size_t)n_frames != c->geo_frames.size()) return fail(c, HG_ERR_INVALID, "hg_get_geometric_matrices: n_frames must equal the uploaded frame count");
+    if (c->geo_from_points)
+        launch_solve_frames(c->geo_kind, c->d_geo_pts, c->d_geo_pts + c->geo_frames.size() * 8, c->d_geo_frames, c->d_mats, c->d_geo_plain, n_frames, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_mats, sizeof(double) * 8 * n_frames, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HG_OK;
+}
+
 extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
 {
     HG_TRY(bind(c));
@@ -539,9 +518,14 @@ extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
     if (c->geo_frames.empty()) return fail(c, HG_ERR_STATE, "no frames: call hg_geometric_set_frames first");
     int mw = 0, mh = 0;
     for (const FrameDesc &d : c->geo_frames) { mw = std::max(mw, d.obj_w); mh = std::max(mh, d.obj_h); }
+    // the reference re-solves the inverse matrix from the swapped point sets at the head of every warp (:994): so does the step
+    if (c->geo_from_points)
+        launch_solve_frames(c->geo_kind, c->d_geo_pts, c->d_geo_pts + c->geo_frames.size() * 8, c->d_geo_frames, c->d_mats, c->d_geo_plain,
+                            (int)c->geo_frames.size(), c->stream);
     HG_TRY(time_begin(c));
     launch_geo(c->geo_kind, c->geo_f32_exact, c->d_geo_frames, c->d_mats, (int)c->geo_frames.size(), mw, mh, c->d_img, c->W, c->H,
-               c->n_imgs, (uint64_t)c->img_stride, static_cast<uint8_t *>(d_out), c->stream);
+               c->n_imgs, (uint64_t)c->img_stride, static_cast<uint8_t *>(d_out),
+               (c->geo_from_points && c->geo_kind == HG_PROJECTIVE) ? c->d_geo_plain : nullptr, c->stream);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
     return HG_OK;

@@ -938,12 +938,14 @@ __global__ void k_selftest_division(uint64_t seed, uint64_t n_per_thread, unsign
 //   * row-constant terms are computed once per lane: fl(m1*y), fl(m4*y), fl(m7*y) (projective) / fl(m2*y), fl(m3*y) (affine);
 //   * affine: the matrix holds f32 values, m0*x is exact in fp64, so fma(m0, x, fl(m2*y)) rounds exactly where JS does;
 //     projective: the matrix is full double, every product rounds: plain mul/add and two IEEE divides per pixel (KIND 1),
-//     or div2_plain when the host has shown that no pixel of the frame set leaves the plain range (KIND 3);
+//     or div2_plain when the host has shown that no pixel of the frame set leaves the plain range (KIND 3); KIND 4 = per-frame
+//     choice from the flag the device-side solve wrote (k_solve_frames);
 //   * Math.round + bounds :1001 via two round-toward-minus-infinity adds per coordinate (round_x8), source through a
 //     range-checked buffer load (0 outside the array), stores through a per-row buffer descriptor (no tail guards).
 template <int KIND>
 __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ frames, const double *__restrict__ mats,
-                                                  const uint8_t *__restrict__ img0, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *__restrict__ out)
+                                                  const uint8_t *__restrict__ img0, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *__restrict__ out,
+                                                  const int32_t *__restrict__ plain)
 {
     const FrameDesc fd = frames[blockIdx.z];
     const uint8_t *__restrict__ img = n_imgs > 1 ? img0 + (uint64_t)(blockIdx.z % n_imgs) * img_stride : img0;
@@ -977,12 +979,14 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
         }
     } else {
         const double ax = m[1] * y, ay = m[4] * y, ad = m[7] * y;          // :1402-1403
+        // KIND 4: matrices solved on the device (k_solve_frames), which also proved (or not) the plain range per frame
+        const bool use_plain = KIND == 4 && __builtin_amdgcn_readfirstlane(plain[blockIdx.z]) != 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const double x = (double)(c0 + lane + k * 64 + fd.x_off);
             const double den = ((m[6] * x) + ad) + 1.0;
             const double nx = ((m[0] * x) + ax) + m[2], ny = ((m[3] * x) + ay) + m[5];
-            if (KIND == 3) div2_plain(nx, ny, den, h[2 * k], h[2 * k + 1]);     // same bits, one reciprocal (host-proved range)
+            if (KIND == 3 || (KIND == 4 && use_plain)) div2_plain(nx, ny, den, h[2 * k], h[2 * k + 1]);     // same bits, one reciprocal (proved range)
             else { h[2 * k] = nx / den; h[2 * k + 1] = ny / den; }
         }
     }
@@ -1169,20 +1173,59 @@ void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream
 }
 
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
-                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, hipStream_t stream)
+                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, hipStream_t stream)
 {
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     dim3 grid((max_w + 255) / 256, (max_h + 3) / 4, n_frames);
     const bool fast = ((int64_t)H + 2) * W * 4 < ((int64_t)1 << 31) && W < (1 << 21) && H < (1 << 22) && max_w < (1 << 28);
     if (fast) {
-        if (kind == 1 && f32_exact) hipLaunchKernelGGL(k_geo_fast<3>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
-        else if (kind == 1) hipLaunchKernelGGL(k_geo_fast<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
-        else if (f32_exact) hipLaunchKernelGGL(k_geo_fast<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
-        else                hipLaunchKernelGGL(k_geo_fast<2>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
+        if (kind == 1 && plain) hipLaunchKernelGGL(k_geo_fast<4>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
+        else if (kind == 1 && f32_exact) hipLaunchKernelGGL(k_geo_fast<3>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
+        else if (kind == 1) hipLaunchKernelGGL(k_geo_fast<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
+        else if (f32_exact) hipLaunchKernelGGL(k_geo_fast<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
+        else                hipLaunchKernelGGL(k_geo_fast<2>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
         return;
     }
     if (kind == 0) hipLaunchKernelGGL(k_geo<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
     else           hipLaunchKernelGGL(k_geo<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
+}
+
+// ------------------------------------------------------------------------------------------------ k_solve_frames
+// The solve the reference repeats at the head of every inverse warp (:994: calculateTransformMatrix(dstPoints, srcPoints)),
+// one lane per frame: projective = the 8x8 DLT system through numeric.js' LU in its exact operation order
+// (solve_projective_regs, hg_math.h: all in registers), affine = the closed form of affineMatrixFromTriangles (f32 result,
+// widened).  Also decides per projective frame whether the shared-reciprocal division is admissible for its window.
+// MFMA is not used on purpose: the order of the ~500 roundings of the LU is observable in the result.
+__global__ __launch_bounds__(64) void k_solve_frames(int kind, const float *__restrict__ from, const float *__restrict__ to,
+                                                     const FrameDesc *__restrict__ frames, double *__restrict__ mats, int32_t *__restrict__ plain, int n)
+{
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= n) return;
+    double m[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (kind == 1) {
+        float s[8], d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s[k] = from[8 * (size_t)f + k]; d[k] = to[8 * (size_t)f + k]; }
+        solve_projective_regs(s, d, m);
+        const FrameDesc fd = frames[f];
+        plain[f] = projective_plain_range(m, fd.x_off, fd.y_off, fd.obj_w, fd.obj_h) ? 1 : 0;
+    } else {
+        float s[6], d[6], o[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { s[k] = from[6 * (size_t)f + k]; d[k] = to[6 * (size_t)f + k]; }
+        solve_affine(s, d, o);
+#pragma unroll
+        for (int k = 0; k < 6; k++) m[k] = o[k];
+        plain[f] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) mats[8 * (size_t)f + k] = m[k];
+}
+
+void launch_solve_frames(int kind, const float *from, const float *to, const FrameDesc *frames, double *mats, int32_t *plain, int n, hipStream_t stream)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_solve_frames, dim3((n + 63) / 64), dim3(64), 0, stream, kind, from, to, frames, mats, plain, n);
 }
 
 unsigned long long run_selftest_division(uint64_t seed, uint64_t samples, unsigned long long *d_counter, hipStream_t stream)

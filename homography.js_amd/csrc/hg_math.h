@@ -87,6 +87,100 @@ HG_HD void invert_affine(const float *m, float *out)
     out[5] = (float)((b * e - a * f) / den);
 }
 
+// projectiveMatrixFromSquares :1320-1333 + numeric.js solve = LUsolve(LU(A)) :1650-1751, in registers: every loop has
+// constant bounds and is fully unrolled, so all array indices are compile-time constants (no scratch memory on the GPU);
+// the data-dependent row exchange of the partial pivoting becomes conditional swaps.  Same operations in the same order as
+// the reference: pivot = first row with the largest |A[j][k]| (strict `<`), rows exchanged (by reference there, by value
+// here: same numbers), column scaled by 1/A[k][k] through divisions, rank-1 update with separately rounded product and
+// difference, permuted forward substitution, back substitution.  s, d = 4 points x,y as float32; out = h0..h7 (h8 == 1).
+HG_HD void solve_projective_regs(const float *s, const float *d, double *out)
+{
+    double A[8][8];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const double x = s[2 * p], y = s[2 * p + 1], u = d[2 * p], v = d[2 * p + 1];
+        A[2 * p][0] = x; A[2 * p][1] = y; A[2 * p][2] = 1; A[2 * p][3] = 0; A[2 * p][4] = 0; A[2 * p][5] = 0;
+        A[2 * p][6] = -u * x; A[2 * p][7] = -u * y;                                       // :1322  (-dst) * src
+        A[2 * p + 1][0] = 0; A[2 * p + 1][1] = 0; A[2 * p + 1][2] = 0; A[2 * p + 1][3] = x; A[2 * p + 1][4] = y; A[2 * p + 1][5] = 1;
+        A[2 * p + 1][6] = -v * x; A[2 * p + 1][7] = -v * y;
+    }
+    int P[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int pk = k;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int j = k + 1; j < 8; j++) { const double v = fabs(A[j][k]); if (best < v) { best = v; pk = j; } }      // :1713-1718
+        P[k] = pk;
+#pragma unroll
+        for (int i = k + 1; i < 8; i++) {                                                 // :1722-1726 (A[k] <-> A[pk])
+            const bool sw = pk == i;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const double a = A[k][j], b = A[i][j]; A[k][j] = sw ? b : a; A[i][j] = sw ? a : b; }
+        }
+        const double akk = A[k][k];
+#pragma unroll
+        for (int i = k + 1; i < 8; i++) A[i][k] /= akk;                                   // :1730-1732
+#pragma unroll
+        for (int i = k + 1; i < 8; i++) {
+#pragma unroll
+            for (int j = k + 1; j < 8; j++) A[i][j] -= A[i][k] * A[k][j];                 // :1734-1742 (the 2-way unrolling there keeps this order)
+        }
+    }
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = d[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {                                                         // :1673-1685
+#pragma unroll
+        for (int t = i + 1; t < 8; t++) { const bool sw = P[i] == t; const double a = x[i], b = x[t]; x[i] = sw ? b : a; x[t] = sw ? a : b; }
+#pragma unroll
+        for (int j = 0; j < i; j++) x[i] -= x[j] * A[i][j];
+    }
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {                                                        // :1687-1694
+#pragma unroll
+        for (int j = i + 1; j < 8; j++) x[i] -= x[j] * A[i][j];
+        x[i] /= A[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = x[i];
+}
+
+// Can every division (m0*x + m1*y + m2) / (m6*x + m7*y + 1), (m3*x + m4*y + m5) / (same) of this frame be done by
+// div2_plain (hg_kernels.hip), i.e. without the scaling / special-value steps of the full IEEE expansion?
+//   * matrix entries finite, each 0 or 2^-100 <= |m| <= 2^100; pixel coordinates |x|, |y| < 2^28
+//     => numerators are 0 or in [2^-210, 2^130] (a non-zero sum of two such roundings cannot fall below 2^-206);
+//   * the denominator, evaluated in the kernel's own operation order, is weakly monotone along x and along y (every
+//     rounding is), so over the window it lies between its values at the four corners: same sign at all four and
+//     2^-100 <= |den| <= 2^130 there => the same holds at every pixel.
+HG_HD bool projective_plain_range(const double *m, int32_t x_off, int32_t y_off, int32_t obj_w, int32_t obj_h)
+{
+    const double lo = 0x1p-100, hi = 0x1p100;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const double a = fabs(m[k]);
+        if (!(a == a) || !(a == 0.0 || (a >= lo && a <= hi))) return false;
+    }
+    if (obj_w <= 0 || obj_h <= 0) return true;
+    const int64_t x0 = x_off, x1 = (int64_t)x_off + obj_w + 255, y0 = y_off, y1 = (int64_t)y_off + obj_h - 1;   // (+255: the ragged last window is computed too)
+    const int64_t ax = (x0 < 0 ? -x0 : x0) > (x1 < 0 ? -x1 : x1) ? (x0 < 0 ? -x0 : x0) : (x1 < 0 ? -x1 : x1);
+    const int64_t ay = (y0 < 0 ? -y0 : y0) > (y1 < 0 ? -y1 : y1) ? (y0 < 0 ? -y0 : y0) : (y1 < 0 ? -y1 : y1);
+    if (ax >= ((int64_t)1 << 28) || ay >= ((int64_t)1 << 28)) return false;
+    double dmin = INFINITY, dmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const double x = (double)((c & 1) ? x1 : x0), y = (double)((c & 2) ? y1 : y0);
+        const double ad = m[7] * y;
+        const double den = ((m[6] * x) + ad) + 1.0;                  // :1402-1403, the kernel's order
+        if (!(den == den)) return false;
+        dmin = den < dmin ? den : dmin; dmax = den > dmax ? den : dmax;
+    }
+    if (dmin > 0) return dmin >= lo && dmax <= 0x1p130;
+    if (dmax < 0) return -dmax >= lo && -dmin <= 0x1p130;
+    return false;
+}
+
 // ---------------------------------------------------------------------------------------------- triangle rasteriser
 
 // One edge of defineTriangleLineEquations :1141-1151

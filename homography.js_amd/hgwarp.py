@@ -25,7 +25,7 @@ EXPORTS = [
     "hg_solve_affine", "hg_invert_affine", "hg_solve_projective", "hg_transform_limits", "hg_minmax_xy", "hg_js_round",
     "hg_triangulate",
     "hg_set_image", "hg_set_image_device", "hg_set_images_device",
-    "hg_warp_inverse_geometric", "hg_warp_inverse_geometric_device", "hg_geometric_set_frames",
+    "hg_warp_inverse_geometric", "hg_warp_inverse_geometric_device", "hg_geometric_set_frames", "hg_geometric_set_frames_points", "hg_get_geometric_matrices",
     "hg_warp_inverse_geometric_frames_device", "hg_warp_inverse_geometric_batch_device", "hg_pack_offsets",
     "hg_piecewise_set_mesh", "hg_piecewise_prepare", "hg_warp_inverse_piecewise", "hg_warp_inverse_piecewise_device",
     "hg_piecewise_set_frames", "hg_warp_inverse_piecewise_frames_device", "hg_warp_inverse_piecewise_batch_device",
@@ -70,6 +70,8 @@ def lib():
         "hg_set_images_device": (i, [vp, vp, i, i, i, sz]),
         "hg_warp_inverse_geometric": (i, [vp, i, f64p, Geom, u8p]), "hg_warp_inverse_geometric_device": (i, [vp, i, f64p, Geom, vp]),
         "hg_geometric_set_frames": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i]),
+        "hg_geometric_set_frames_points": (i, [vp, i, f32p, f32p, C.POINTER(Geom), C.POINTER(sz), i]),
+        "hg_get_geometric_matrices": (i, [vp, f64p, i]),
         "hg_warp_inverse_geometric_frames_device": (i, [vp, vp]),
         "hg_warp_inverse_geometric_batch_device": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
         "hg_pack_offsets": (i, [C.POINTER(Geom), i, C.POINTER(sz), C.POINTER(sz)]),
@@ -324,6 +326,19 @@ class Context:
         assert m.size == 8 * len(geoms)
         offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
         self._c(lib().hg_geometric_set_frames(self._h, int(kind), p, _geoms(geoms), offs, len(geoms)))
+
+    def geometric_set_frames_points(self, kind, from_pts, to_pts, geoms, offsets=None):
+        """Frames as point sets: the matrices (from -> to) are solved on the device at every warp, like the reference's :994."""
+        per = 6 if int(kind) == 0 else 8
+        (a, ap), (b, bp) = _f32(from_pts), _f32(to_pts)
+        assert a.size == per * len(geoms) and b.size == per * len(geoms)
+        offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
+        self._c(lib().hg_geometric_set_frames_points(self._h, int(kind), ap, bp, _geoms(geoms), offs, len(geoms)))
+
+    def get_geometric_matrices(self, n_frames):
+        out = np.empty((int(n_frames), 8), np.float64)
+        self._c(lib().hg_get_geometric_matrices(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), int(n_frames)))
+        return out
 
     def warp_inverse_geometric_frames_device(self, d_out):
         self._c(lib().hg_warp_inverse_geometric_frames_device(self._h, C.c_void_p(int(d_out))))

@@ -120,6 +120,16 @@ int hg_warp_inverse_geometric_device(hg_ctx *ctx, int kind, const double *m, hg_
  * (NULL: packed as hg_pack_offsets does).  set_frames uploads the per-frame inputs (kept until replaced);
  * frames_device runs all uploaded frames; batch_device = both. */
 int hg_geometric_set_frames(hg_ctx *ctx, int kind, const double *m, const hg_geom *geoms, const size_t *out_offsets, int n_frames);
+/* Same frame set given as POINT SETS: the reference obtains the inverse matrix at the head of every inverse warp by
+ * re-solving with the swapped sets (:994 calculateTransformMatrix(dstPoints, srcPoints) -> projectiveMatrixFromSquares
+ * :1320-1333 + numeric.js LU/LUsolve :1650-1751, or affineMatrixFromTriangles :1265-1306).  from / to = n_frames x 4 (or
+ * 3) points x,y float32; the matrix of frame f maps from[f] -> to[f] (pass dst, src for the inverse warp).  Every
+ * hg_warp_inverse_geometric_frames_device then runs the solves ON THE DEVICE (one lane per frame, the LU in its exact
+ * operation order; bit patterns equal to hg_solve_projective / hg_solve_affine) followed by the pixel kernel. */
+int hg_geometric_set_frames_points(hg_ctx *ctx, int kind, const float *from, const float *to, const hg_geom *geoms,
+                                   const size_t *out_offsets, int n_frames);
+/* Parity tap: the n_frames x 8 doubles the pixel kernel uses (device-solved when the frames were given as point sets). */
+int hg_get_geometric_matrices(hg_ctx *ctx, double *out, int n_frames);
 int hg_warp_inverse_geometric_frames_device(hg_ctx *ctx, void *d_out);
 int hg_warp_inverse_geometric_batch_device(hg_ctx *ctx, int kind, const double *m, const hg_geom *geoms,
                                            const size_t *out_offsets, int n_frames, void *d_out);

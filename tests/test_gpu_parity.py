@@ -255,6 +255,75 @@ def test_one_source_per_frame(ctx):
         ctx.free(d_src)
 
 
+def test_device_side_frame_solves(ctx):
+    """hg_geometric_set_frames_points: the inverse matrices are solved on the device at every warp (k_solve_frames, one lane
+    per frame, numeric.js LU order).  Bit patterns == host solve == golden vectors; the warped frames == frames warped from
+    host-solved matrices == oracle; incl. a frame whose window crosses the horizon (IEEE divides) next to plain-range ones."""
+    f = GOLD["func"]
+    srcs = np.stack([G.f32_from_bits(v["src"]) for v in f["projective"]])
+    dsts = np.stack([G.f32_from_bits(v["dst"]) for v in f["projective"]])
+    want = np.stack([G.f64_from_hex(v["out"]) for v in f["projective"]])
+    n = len(srcs)
+    ctx.set_image(G.lcg_image(64, 48, 9))
+    ctx.geometric_set_frames_points(1, srcs.ravel(), dsts.ravel(), [(0, 0, 8, 8)] * n)
+    got = ctx.get_geometric_matrices(n)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)) or all(_nan_eq64(a, b) for a, b in zip(got, want))
+    # random squares: device == host, bit for bit
+    rng = np.random.default_rng(99)
+    S = rng.uniform(-500, 3000, (257, 8)).astype(np.float32); D = rng.uniform(-500, 3000, (257, 8)).astype(np.float32)
+    S[5] = S[6]; D[7, 2:4] = D[7, 0:2]                       # + a degenerate one
+    ctx.geometric_set_frames_points(1, S.ravel(), D.ravel(), [(0, 0, 4, 4)] * 257)
+    got = ctx.get_geometric_matrices(257)
+    host = np.stack([HG.solve_projective(S[k], D[k]) for k in range(257)])
+    assert all(_nan_eq64(a, b) for a, b in zip(got, host))
+    A3s = rng.uniform(-100, 900, (65, 6)).astype(np.float32); A3d = rng.uniform(-100, 900, (65, 6)).astype(np.float32)
+    ctx.geometric_set_frames_points(0, A3s.ravel(), A3d.ravel(), [(0, 0, 4, 4)] * 65)
+    got = ctx.get_geometric_matrices(65)[:, :6]
+    host = np.stack([HG.solve_affine(A3s[k], A3d[k]).astype(np.float64) for k in range(65)])
+    assert all(_nan_eq64(a, b) for a, b in zip(got, host))
+    # warps: points path == matrices path == oracle
+    W, H, F = 320, 200, 6
+    img = G.lcg_image(W, H, 31)
+    ctx.set_image(img)
+    s4 = WL.corners(W, H)
+    d4s = [WL.projective_dst(W, H, 0.03 * k) for k in range(F - 1)]
+    d4s.append(np.array([40, 10, 10, 190, 300, 60, 310, 120], np.float32))
+    geoms = [tuple(int(v) for v in O.transform_limits(1, O.projective_from_squares(s4, d4), W, H)) for d4 in d4s]
+    geoms[-1] = (-400, -300, 1200, 900)                      # a window far larger than the quad: the horizon crosses it
+    mats = [HG.solve_projective(d4, s4) for d4 in d4s]
+    assert not HG.projective_plain_range(mats[-1], geoms[-1]) and HG.projective_plain_range(mats[0], geoms[0])
+    offs, total = HG.pack_offsets(geoms)
+    d_out = ctx.alloc(total)
+    try:
+        ctx.geometric_set_frames_points(1, np.concatenate(d4s), np.tile(s4, F), geoms, offs)
+        ctx.warp_inverse_geometric_frames_device(d_out)
+        ctx.sync()
+        for k in range(F):
+            g = geoms[k]
+            got = ctx.to_host(d_out, g[2] * g[3] * 4, offs[k]).reshape(g[3], g[2], 4)
+            assert np.array_equal(got, O.warp_inverse_geometric(1, mats[k], img, *g)), k
+        a3s = np.array([0, 0, 0, H, W, 0], np.float32)
+        a3d = [WL.affine_dst(W, H, 0.01 * k) for k in range(F)]
+        ageoms = [tuple(int(v) for v in O.transform_limits(0, O.affine_from_triangles(a3s, d).astype(np.float64), W, H)) for d in a3d]
+        aoffs, atotal = HG.pack_offsets(ageoms)
+        assert atotal <= total
+        ctx.geometric_set_frames_points(0, np.concatenate(a3d), np.tile(a3s, F), ageoms, aoffs)
+        ctx.warp_inverse_geometric_frames_device(d_out)
+        ctx.sync()
+        for k in range(F):
+            g = ageoms[k]
+            got = ctx.to_host(d_out, g[2] * g[3] * 4, aoffs[k]).reshape(g[3], g[2], 4)
+            m = HG.solve_affine(a3d[k], a3s).astype(np.float64)
+            assert np.array_equal(got, O.warp_inverse_geometric(0, m, img, *g)), ("affine", k)
+    finally:
+        ctx.free(d_out)
+
+
+def _nan_eq64(a, b):
+    a, b = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64)
+    return bool(np.all((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))))
+
+
 def test_failed_set_frames_leaves_no_frame_set(ctx):
     """A frame set that fails validation part-way (offset beyond 2^26 in the LAST frame) must not leave the new
     host-side frames over device buffers sized for the old set: the next warp reports HG_ERR_STATE."""
