@@ -46,7 +46,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "homography.js_amd")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-GOLDEN_CASE = {"C3": "C3_piecewise_4k", "C2": "C2_projective_1080p", "C5": "C5_piecewise_8k"}
+# reference-generated goldens whose k-th warp is frame k of the config's sequence on rank 0 (tests/golden/gen_golden.mjs)
+GOLDEN_CASE = {"C3": "C3_batch_4k", "C2": "C2_projective_1080p", "C5": "C5_batch_8k", "C4": "C4_orbit_4k"}
 
 
 def _load(name, path):
@@ -79,19 +80,20 @@ def _pmc_traffic(config, frames, sources):
     return None, None
 
 
-def _golden_sha(config):
-    """SHA-256 the reference itself produced for frame 0 of this config (tests/golden/gen_golden.mjs), or None."""
+def _golden_shas(config):
+    """{frame index: SHA-256 the reference itself produced for that frame of this config's sequence} (possibly empty)."""
     name = GOLDEN_CASE.get(config)
     if not name:
-        return None
+        return {}
     try:
         with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
             for c in json.load(f)["cases"]:
                 if c["name"] == name:
-                    return c["warps"][0]["out"]["sha"]
+                    ids = c.get("orbitFrames") or list(range(len(c["warps"])))
+                    return {int(i): w["out"]["sha"] for i, w in zip(ids, c["warps"])}
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return {}
 
 
 def launch_command(argv, n):
@@ -305,10 +307,10 @@ def main():
                        "roofline_distinct is the layout where algorithmic bytes are HBM bytes")
         res["shared"] = (elapsed, rf)
         if not args.no_verify:                      # the bytes the timed kernels wrote (untimed checks)
-            want = _golden_sha(args.config) if rank == 0 else None
+            want = {i: h for i, h in _golden_shas(args.config).items() if i in frame_ids}
             if want:
-                got = hashlib.sha256(frame_view(out_t, 0).cpu().numpy().tobytes()).hexdigest()
-                check(f"frame 0 of the timed output == reference golden {GOLDEN_CASE[args.config]} (sha256)", got == want)
+                ok = all(hashlib.sha256(frame_view(out_t, frame_ids.index(i)).cpu().numpy().tobytes()).hexdigest() == h for i, h in want.items())
+                check(f"frames {sorted(want)} of the timed output == reference goldens {GOLDEN_CASE[args.config]} (sha256)", ok)
             for f in range(F):
                 if same_as[f] is not None and n_out[f] == n_out[same_as[f]]:
                     if not torch.equal(frame_view(out_t, f), frame_view(out_t, same_as[f])):
@@ -350,9 +352,10 @@ def main():
                     ok = False
                     break
             check("distinct-source frames == shared-source frames XOR per-frame constant on exactly the hit pixels (all frames)", ok)
-            if "shared" not in res and rank == 0 and _golden_sha(args.config):
-                got = hashlib.sha256(frame_view(out_t, 0).cpu().numpy().tobytes()).hexdigest()
-                check(f"frame 0 == reference golden {GOLDEN_CASE[args.config]} (sha256)", got == _golden_sha(args.config))
+            want = {i: h for i, h in _golden_shas(args.config).items() if i in frame_ids}
+            if "shared" not in res and want:
+                ok = all(hashlib.sha256(frame_view(out_t, frame_ids.index(i)).cpu().numpy().tobytes()).hexdigest() == h for i, h in want.items())
+                check(f"frames {sorted(want)} == reference goldens {GOLDEN_CASE[args.config]} (sha256)", ok)
         del srcs, shared_copy
         ctx.set_image_device(img_t.data_ptr(), W, H)
 

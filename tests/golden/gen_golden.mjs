@@ -126,7 +126,7 @@ function runCase(c) {
                 const fwd = new Float32Array(H._piecewiseMatrices.length * 6), inv = new Float32Array(fwd.length);
                 H._piecewiseMatrices.forEach((m, i) => { fwd.set(m, i * 6); inv.set(M.inverseAffineMatrix(m), i * 6); });
                 rec.fwdSha = sha(fwd); rec.invSha = sha(inv);
-                if (fwd.byteLength <= RAW_LIMIT) { rec.fwd = blob(fwd); rec.inv = blob(inv); }
+                if (fwd.byteLength <= RAW_LIMIT && !c.shaOnly) { rec.fwd = blob(fwd); rec.inv = blob(inv); }
                 const map = H._trianglesCorrespondencesMatrix;       // int16; forward or inverse map depending on the path taken
                 rec.map = { len: map.length, sha: sha(map) };
                 if (map.byteLength <= RAW_LIMIT || c.raw) rec.map.blob = blob(map);
@@ -303,6 +303,28 @@ for (let k = 0; k < 12; k++) {
     const d = [[r() * W * 0.3, r() * Hh * 0.3], [r() * W * 0.3, Hh * (0.7 + r() * 0.8)], [W * (0.7 + r() * 0.8), r() * Hh * 0.3], [W * (0.7 + r() * 0.8), Hh * (0.7 + r() * 0.8)]];
     add({ name: `fuzz_proj_${k}`, images: { a: { w: W, h: Hh, seed: 300 + k } },
           script: [['new', 'projective'], ['setSourcePoints', [[0, 0], [0, Hh], [W, 0], [W, Hh]], 'a', W, Hh, false], ['setDestinyPoints', d, false], ['warp']] });
+}
+
+// ================================================================= 5b. full-size BATCH cases: the benchmarked caller loop `for (f) { setDestinyPoints(dst_f); warp(); }`
+// (test/benchmark.js:107-110) on one Homography instance.  Appended after everything else so that earlier blob offsets stay put.
+// shaOnly: per-frame matrices only as SHA-256 (the blobs of 4 x 5 000 triangles would add a megabyte).
+function addSinBatch(name, W, Hh, nx, ny, A, seed, ns) {
+    const script = [['new', 'piecewiseaffine']];
+    let tri = null;
+    ns.forEach((n, k) => { const c = cfgSinGrid(W, Hh, nx, ny, A, n); tri = c.tri;
+        if (k === 0) script.push(['setSourcePoints', c.src, 'a', W, Hh, false]);
+        script.push(['setDestinyPoints', c.dst, false], ['warp']); });
+    add({ name, images: { a: { w: W, h: Hh, seed } }, triangles: tri, shaOnly: true, script });
+}
+if (FULL) {
+    addSinBatch('C3_batch_4k', 3840, 2160, 10, 10, 40, 1, [8, 9, 10, 11]);
+    addSinBatch('C5_batch_8k', 7680, 4320, 50, 50, 80, 1, [8, 9, 10, 11]);
+    // C4: 68-landmark face mesh, frames of the 512-frame orbit (inputs: tests/golden/c4_inputs.json <- gen_c4_inputs.py)
+    const c4 = JSON.parse(fs.readFileSync(path.join(HERE, 'c4_inputs.json'), 'utf8'));
+    const pairs = (flat) => { const o = []; for (let i = 0; i < flat.length; i += 2) o.push([flat[i], flat[i + 1]]); return o; };
+    const script = [['new', 'piecewiseaffine'], ['setSourcePoints', pairs(c4.src), 'a', c4.W, c4.H, false]];
+    for (const d of c4.dst) script.push(['setDestinyPoints', pairs(d), false], ['warp']);
+    add({ name: 'C4_orbit_4k', images: { a: { w: c4.W, h: c4.H, seed: 1 } }, triangles: c4.triangles, shaOnly: true, orbitFrames: c4.frames, script });
 }
 
 // ================================================================= 6. per-function vectors

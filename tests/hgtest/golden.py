@@ -48,6 +48,20 @@ def sha256(a):
 
 
 def lcg_image(w, h, seed):
+    """(cached: the 8K image takes seconds to build and the full-size cases all share seed 1; callers get a private copy only
+    for small images, the big ones are returned read-only)"""
+    a = _lcg_image_cached(int(w), int(h), int(seed))
+    return a if a.nbytes > (1 << 22) else a.copy()
+
+
+@functools.lru_cache(maxsize=3)
+def _lcg_image_cached(w, h, seed):
+    a = _lcg_image(w, h, seed)
+    a.setflags(write=False)
+    return a
+
+
+def _lcg_image(w, h, seed):
     """SURVEY.md §8d synthetic RGBA: s = s*1664525 + 1013904223 mod 2^32; byte = s >> 24 (vectorised by LCG jump-ahead)."""
     n = w * h * 4
     # s_k = a^k * s0 + c * (a^k - 1)/(a - 1)  (mod 2^32): build a^k and the geometric sum by doubling blocks

@@ -208,6 +208,39 @@ def test_batch_frames_equal_single_frames(ctx):
         ctx.free(d_out)
 
 
+@pytest.mark.parametrize("name", ["C3_batch_4k", "C5_batch_8k", "C4_orbit_4k"])
+def test_full_size_batches_match_reference_shas(ctx, name):
+    """The benchmarked caller loop at FULL size as ONE launch: C3 / C5 with sin((8..11) x / pi) (F = 4) and eight frames of the
+    C4 face-mesh orbit (F = 8); every frame's RGBA SHA-256 and hit count against what the reference itself produced."""
+    case = [c for c in GOLD["cases"] if c["name"] == name][0]
+    ws = case["warps"]
+    img = G.case_images(case)["a"]
+    sp, tris = G.f32_from_bits(ws[0]["srcPoints"]), G.case_triangles(case)
+    frames = [G.f32_from_bits(w["dstPoints"]) for w in ws]
+    geoms = [(w["xOff"], w["yOff"], w["objW"], w["objH"]) for w in ws]
+    assert all(w["path"] == "_inversePiecewiseAffineWarp" for w in ws)
+    ctx.set_image(img)
+    ctx.piecewise_set_mesh(sp, tris, ws[0]["minSrcX"], ws[0]["minSrcY"])
+    offs, total = HG.pack_offsets(geoms)
+    d_out = ctx.alloc(total)
+    try:
+        ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+        ctx.warp_inverse_piecewise_frames_device(d_out)
+        ctx.sync()
+        for f, w in enumerate(ws):
+            got = ctx.to_host(d_out, w["objW"] * w["objH"] * 4, offs[f])
+            assert G.sha256(got) == w["out"]["sha"], (name, f)
+        # N_hit of every frame on an all-255 source (one more launch): the algorithmic read bytes bench.py prices
+        ctx.set_image(np.full_like(img, 255))
+        ctx.warp_inverse_piecewise_frames_device(d_out)
+        ctx.sync()
+        for f, w in enumerate(ws):
+            got = ctx.to_host(d_out, w["objW"] * w["objH"] * 4, offs[f]).reshape(-1, 4)
+            assert int((got[:, 3] == 255).sum()) == w["nhit"], (name, f)
+    finally:
+        ctx.free(d_out)
+
+
 def test_one_source_per_frame(ctx):
     """hg_set_images_device: frame f of a frame set reads image f % n_images (the video case, every warp() its own image).
     Piecewise (incl. a frame forced through the map path) and projective, against the oracle frame by frame."""

@@ -84,7 +84,7 @@ def _same_f64(a, b):
 
 # ------------------------------------------------------------------ end-to-end warps (resolved state -> oracle -> golden output)
 
-SLOW = {"C2_projective_1080p", "C3_piecewise_4k", "C3_piecewise_4k_5000tri", "C5_piecewise_8k"}
+SLOW = {"C2_projective_1080p", "C3_piecewise_4k", "C3_piecewise_4k_5000tri", "C5_piecewise_8k", "C3_batch_4k", "C5_batch_8k", "C4_orbit_4k"}
 
 
 def _warp_params():
