@@ -222,6 +222,37 @@ extern "C" int hg_copy_to_host(hg_ctx *c, void *dst, const void *src, size_t byt
     return HG_OK;
 }
 
+// D2H on the ctx stream, after everything queued so far; the caller keeps dst alive until hg_sync().  Settles queued
+// piecewise runs first (frames the fused path flagged are redone before they are copied).  With pinned destination memory
+// (hg_host_alloc) the copy is a true asynchronous DMA, so several devices / frames overlap.
+extern "C" int hg_copy_to_host_async(hg_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HG_TRY(bind(c));
+    if (!dst || !src) return fail(c, HG_ERR_INVALID, "NULL pointer");
+    if (!c->pw_pending_out.empty()) HG_TRY(hg_sync(c));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return HG_OK;
+}
+
+// Pinned (page-locked, portable across devices) host memory for frames that leave the GPU: DMA at full PCIe rate without
+// the runtime's staging copy, and no first-touch page faults once the buffer is being reused.
+extern "C" int hg_host_alloc(size_t bytes, void **p)
+{
+    if (!p) return fail(nullptr, HG_ERR_INVALID, "p is NULL");
+    *p = nullptr;
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) return fail(nullptr, HG_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return HG_OK;
+}
+
+extern "C" int hg_host_free(void *p)
+{
+    if (p && hipHostFree(p) != hipSuccess) return fail(nullptr, HG_ERR_HIP, "hipHostFree failed");
+    return HG_OK;
+}
+
+extern "C" int hg_ctx_device(const hg_ctx *c) { return c ? c->device : -1; }
+
 extern "C" int hg_copy_to_device(hg_ctx *c, void *dst, const void *src, size_t bytes)
 {
     HG_TRY(bind(c));

@@ -1,0 +1,240 @@
+// hg_multi.hip -- several GPUs of one node behind ONE host thread, on top of the public C ABI (include/hgwarp.h).
+//
+// What it replaces: the caller loop `for (f) { setDestinyPoints(dst_f); warp(); }` (test/benchmark.js:107-110) when the
+// host wants the frames of that loop spread over G devices: frames are independent units, so each device
+// gets a contiguous block of them and there is no data-path collective; the only exchange is the one-off fan-out of the
+// shared source texture.  This is the path for hosts without torch.distributed / RCCL process groups (the Node binding:
+// one process, one thread); bench.py's one-process-per-GPU launch uses homography.js_amd/dist.py over RCCL instead.
+//
+// Source fan-out over xGMI (point-to-point links, 7 x ~153 GB/s per GPU; a ring or a chain is bound by ONE link):
+//   1. H2D of the image into device 0;
+//   2. scatter: device 0 -> peer p, slice p (1/G of the image) -- every link 0->p carries 1/G;
+//   3. all-gather: every device sends the slice it owns to every other device -- every link p->q carries 1/G;
+// all as hipMemcpyPeerAsync on per-device streams ordered by events.  Without peer access (hipDeviceCanAccessPeer == 0)
+// every device gets its own H2D copy instead.
+#include "../../include/hgwarp.h"
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+struct hg_multi {
+    struct Dev {
+        int id = 0;
+        hg_ctx *ctx = nullptr;
+        hipStream_t copy = nullptr;              // fan-out / gather stream of this device
+        hipEvent_t have_slice = nullptr;         // this device's own slice of the source has arrived
+        uint8_t *d_img = nullptr; size_t img_cap = 0;
+        uint8_t *d_out = nullptr; size_t out_cap = 0;
+        int first = 0, count = 0;                // frames of the current batch
+        std::vector<size_t> offs;                // their byte offsets in d_out
+    };
+    std::vector<Dev> devs;
+    bool peer = true;                            // every pair of distinct devices has peer access
+    int W = 0, H = 0;
+    int n_pts = 0;
+    std::vector<hg_geom> geoms;                  // of the current batch
+    std::string err;
+};
+
+static thread_local std::string g_merr;
+
+static int mfail(hg_multi *m, int code, const std::string &msg)
+{
+    if (m) m->err = msg;
+    g_merr = msg;
+    return code;
+}
+
+#define MHIP(m, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return mfail((m), HG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define MHG(m, ctx, expr) do { int s_ = (expr); if (s_ != HG_OK) return mfail((m), s_, hg_last_error(ctx)); } while (0)
+
+extern "C" int hg_multi_partition(int n_frames, int n_devices, int index, int *first, int *count)
+{
+    if (n_frames < 0 || n_devices <= 0 || index < 0 || index >= n_devices || !first || !count) return mfail(nullptr, HG_ERR_INVALID, "hg_multi_partition: bad arguments");
+    const int base = n_frames / n_devices, extra = n_frames % n_devices;
+    *first = index * base + (index < extra ? index : extra);
+    *count = base + (index < extra ? 1 : 0);
+    return HG_OK;
+}
+
+extern "C" const char *hg_multi_last_error(const hg_multi *m) { return m ? m->err.c_str() : g_merr.c_str(); }
+extern "C" int hg_multi_device_count(const hg_multi *m) { return m ? (int)m->devs.size() : 0; }
+extern "C" hg_ctx *hg_multi_ctx(hg_multi *m, int i) { return (m && i >= 0 && i < (int)m->devs.size()) ? m->devs[i].ctx : nullptr; }
+
+extern "C" void hg_multi_destroy(hg_multi *m)
+{
+    if (!m) return;
+    for (auto &d : m->devs) {
+        if (d.ctx) {
+            (void)hg_sync(d.ctx);
+            (void)hipSetDevice(d.id);
+            if (d.copy) { (void)hipStreamSynchronize(d.copy); (void)hipStreamDestroy(d.copy); }
+            if (d.have_slice) (void)hipEventDestroy(d.have_slice);
+            hg_destroy(d.ctx);                   // (drops its alias of d_img first)
+            if (d.d_img) (void)hipFree(d.d_img);
+            if (d.d_out) (void)hipFree(d.d_out);
+        }
+    }
+    delete m;
+}
+
+extern "C" int hg_multi_create(const int *device_ids, int n_devices, hg_multi **out)
+{
+    if (!out) return mfail(nullptr, HG_ERR_INVALID, "hg_multi_create: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices <= 0 || n_devices > 64) return mfail(nullptr, HG_ERR_INVALID, "hg_multi_create: need 1..64 device ids");
+    hg_multi *m = new hg_multi();
+    m->devs.resize(n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        auto &d = m->devs[i];
+        d.id = device_ids[i];
+        int rc = hg_create(d.id, &d.ctx);
+        if (rc != HG_OK) { const std::string why = hg_last_error(nullptr); hg_multi_destroy(m); return mfail(nullptr, rc, why); }
+        if (hipSetDevice(d.id) != hipSuccess || hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&d.have_slice, hipEventDisableTiming) != hipSuccess) {
+            hg_multi_destroy(m);
+            return mfail(nullptr, HG_ERR_HIP, "hg_multi_create: stream / event creation failed");
+        }
+    }
+    // peer access between every pair of distinct devices (a device listed twice talks to itself: plain device copies)
+    for (int i = 0; i < n_devices && m->peer; i++)
+        for (int j = 0; j < n_devices; j++) {
+            const int a = m->devs[i].id, b = m->devs[j].id;
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { m->peer = false; break; }
+            (void)hipSetDevice(a);
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { m->peer = false; break; }
+            (void)hipGetLastError();
+        }
+    *out = m;
+    return HG_OK;
+}
+
+static int ensure_dev(hg_multi *m, hg_multi::Dev &d, uint8_t *&p, size_t &cap, size_t need)
+{
+    if (need <= cap) return HG_OK;
+    MHIP(m, hipSetDevice(d.id));
+    if (p) { MHG(m, d.ctx, hg_sync(d.ctx)); MHIP(m, hipFree(p)); p = nullptr; cap = 0; }
+    void *q = nullptr;
+    if (hipMalloc(&q, need) != hipSuccess) return mfail(m, HG_ERR_NOMEM, "hg_multi: hipMalloc failed");
+    p = static_cast<uint8_t *>(q); cap = need;
+    return HG_OK;
+}
+
+// setImage (:290-316) for every device: the reference's single source image, shared by all frames of a batch.
+extern "C" int hg_multi_set_image(hg_multi *m, const uint8_t *rgba, int w, int h)
+{
+    if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
+    if (!rgba || w <= 0 || h <= 0) return mfail(m, HG_ERR_INVALID, "hg_multi_set_image: bad image");
+    const size_t bytes = (size_t)w * h * 4;
+    const int G = (int)m->devs.size();
+    for (auto &d : m->devs) {
+        MHG(m, d.ctx, hg_sync(d.ctx));                       // queued warps still read the old image
+        if (bytes > d.img_cap) {                             // the ctx aliases d_img: detach before the buffer is replaced
+            if (d.d_img) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipFree(d.d_img)); d.d_img = nullptr; d.img_cap = 0; }
+            MHG(m, d.ctx, ensure_dev(m, d, d.d_img, d.img_cap, bytes));
+        }
+    }
+    auto &root = m->devs[0];
+    MHIP(m, hipSetDevice(root.id));
+    if (G == 1 || !m->peer) {
+        for (auto &d : m->devs) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipMemcpyAsync(d.d_img, rgba, bytes, hipMemcpyHostToDevice, d.copy)); }
+    } else {
+        MHIP(m, hipMemcpyAsync(root.d_img, rgba, bytes, hipMemcpyHostToDevice, root.copy));
+        MHIP(m, hipEventRecord(root.have_slice, root.copy));
+        // slices: 4-byte aligned, the last one takes the remainder
+        const size_t slice = ((bytes / G) + 3) & ~(size_t)3;
+        auto lo = [&](int k) { return std::min(bytes, slice * (size_t)k); };
+        auto hi = [&](int k) { return k == G - 1 ? bytes : std::min(bytes, slice * (size_t)(k + 1)); };
+        // scatter: root -> p, slice p, on p's stream
+        for (int p = 1; p < G; p++) {
+            auto &d = m->devs[p];
+            MHIP(m, hipSetDevice(d.id));
+            MHIP(m, hipStreamWaitEvent(d.copy, root.have_slice, 0));
+            if (hi(p) > lo(p)) MHIP(m, hipMemcpyPeerAsync(d.d_img + lo(p), d.id, root.d_img + lo(p), root.id, hi(p) - lo(p), d.copy));
+            MHIP(m, hipEventRecord(d.have_slice, d.copy));
+        }
+        // all-gather: q pulls slice p from its owner p (the root owns every slice already and pulls nothing)
+        for (int q = 1; q < G; q++) {
+            auto &dq = m->devs[q];
+            MHIP(m, hipSetDevice(dq.id));
+            for (int k = 1; k < G; k++) {
+                const int p = (q + k) % G;                   // staggered so that the pulls of one step use different links
+                if (p == q || hi(p) <= lo(p)) continue;
+                auto &dp = m->devs[p];
+                MHIP(m, hipStreamWaitEvent(dq.copy, dp.have_slice, 0));
+                MHIP(m, hipMemcpyPeerAsync(dq.d_img + lo(p), dq.id, dp.d_img + lo(p), dp.id, hi(p) - lo(p), dq.copy));
+            }
+        }
+    }
+    for (auto &d : m->devs) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipStreamSynchronize(d.copy)); }
+    for (auto &d : m->devs) MHG(m, d.ctx, hg_set_image_device(d.ctx, d.d_img, w, h));
+    m->W = w; m->H = h;
+    return HG_OK;
+}
+
+extern "C" int hg_multi_piecewise_set_mesh(hg_multi *m, const float *src_points, int n_points, const uint32_t *triangles, int n_triangles,
+                                           int min_src_x, int min_src_y)
+{
+    if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
+    for (auto &d : m->devs) MHG(m, d.ctx, hg_piecewise_set_mesh(d.ctx, src_points, n_points, triangles, n_triangles, min_src_x, min_src_y));
+    m->n_pts = n_points;
+    return HG_OK;
+}
+
+// The caller loop for F frames over all devices: device i warps the contiguous block hg_multi_partition gives it, all
+// devices at once.  Frames stay resident (hg_multi_frame) unless out_host is given: then out_host[f] receives frame f
+// (4*obj_w*obj_h bytes; pinned memory from hg_host_alloc makes the copies of different devices overlap).
+extern "C" int hg_multi_warp_piecewise_batch(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
+{
+    if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
+    if (!dst_points || !geoms || n_frames <= 0) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_piecewise_batch: bad arguments");
+    if (m->n_pts <= 0) return mfail(m, HG_ERR_STATE, "no mesh: call hg_multi_piecewise_set_mesh first");
+    if (m->W <= 0) return mfail(m, HG_ERR_STATE, "no source image: call hg_multi_set_image first");
+    const int G = (int)m->devs.size();
+    m->geoms.assign(geoms, geoms + n_frames);
+    // 1. enqueue every device's share (asynchronous: all devices compute at the same time)
+    for (int i = 0; i < G; i++) {
+        auto &d = m->devs[i];
+        hg_multi_partition(n_frames, G, i, &d.first, &d.count);
+        d.offs.assign((size_t)std::max(d.count, 1), 0);
+        if (d.count == 0) continue;
+        size_t total = 0;
+        MHG(m, nullptr, hg_pack_offsets(geoms + d.first, d.count, d.offs.data(), &total));
+        MHG(m, d.ctx, ensure_dev(m, d, d.d_out, d.out_cap, std::max<size_t>(total, 256)));
+        MHG(m, d.ctx, hg_warp_inverse_piecewise_batch_device(d.ctx, dst_points + (size_t)d.first * m->n_pts * 2, geoms + d.first, d.offs.data(), d.count, d.d_out));
+    }
+    // 2. frames leave the devices (each device's copies queue behind its own kernels; pinned destinations overlap)
+    if (out_host) {
+        for (auto &d : m->devs)
+            for (int k = 0; k < d.count; k++) {
+                const hg_geom &g = geoms[d.first + k];
+                const size_t bytes = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h * 4 : 0;
+                if (!bytes) continue;
+                if (!out_host[d.first + k]) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_piecewise_batch: out_host[f] is NULL");
+                MHG(m, d.ctx, hg_copy_to_host_async(d.ctx, out_host[d.first + k], d.d_out + d.offs[k], bytes));
+            }
+    }
+    // 3. settle (also redoes frames the fused path flagged, if frames stay resident)
+    for (auto &d : m->devs) if (d.count) MHG(m, d.ctx, hg_sync(d.ctx));
+    return HG_OK;
+}
+
+extern "C" int hg_multi_frame(hg_multi *m, int frame, int *device_index, void **d_ptr, size_t *bytes)
+{
+    if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
+    for (size_t i = 0; i < m->devs.size(); i++) {
+        const auto &d = m->devs[i];
+        if (frame >= d.first && frame < d.first + d.count) {
+            const hg_geom &g = m->geoms[frame];
+            if (device_index) *device_index = (int)i;
+            if (d_ptr) *d_ptr = d.d_out + d.offs[frame - d.first];
+            if (bytes) *bytes = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h * 4 : 0;
+            return HG_OK;
+        }
+    }
+    return mfail(m, HG_ERR_INVALID, "hg_multi_frame: no such frame in the last batch");
+}

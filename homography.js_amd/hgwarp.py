@@ -21,7 +21,9 @@ HG_AFFINE, HG_PROJECTIVE = 0, 1
 # every symbol include/hgwarp.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "hg_version", "hg_device_count", "hg_create", "hg_create_on_stream", "hg_destroy", "hg_last_error", "hg_sync",
-    "hg_device_alloc", "hg_device_free", "hg_copy_to_host", "hg_copy_to_device",
+    "hg_device_alloc", "hg_device_free", "hg_copy_to_host", "hg_copy_to_device", "hg_copy_to_host_async", "hg_host_alloc", "hg_host_free", "hg_ctx_device",
+    "hg_multi_create", "hg_multi_destroy", "hg_multi_last_error", "hg_multi_device_count", "hg_multi_ctx", "hg_multi_partition", "hg_multi_set_image",
+    "hg_multi_piecewise_set_mesh", "hg_multi_warp_piecewise_batch", "hg_multi_frame",
     "hg_solve_affine", "hg_invert_affine", "hg_solve_projective", "hg_transform_limits", "hg_minmax_xy", "hg_js_round",
     "hg_triangulate",
     "hg_set_image", "hg_set_image_device", "hg_set_images_device",
@@ -63,6 +65,13 @@ def lib():
         "hg_create": (i, [i, C.POINTER(vp)]), "hg_create_on_stream": (i, [i, vp, C.POINTER(vp)]), "hg_destroy": (None, [vp]),
         "hg_last_error": (C.c_char_p, [vp]), "hg_sync": (i, [vp]),
         "hg_device_alloc": (i, [vp, sz, C.POINTER(vp)]), "hg_device_free": (i, [vp, vp]), "hg_copy_to_host": (i, [vp, vp, vp, sz]), "hg_copy_to_device": (i, [vp, vp, vp, sz]),
+        "hg_copy_to_host_async": (i, [vp, vp, vp, sz]), "hg_host_alloc": (i, [sz, C.POINTER(vp)]), "hg_host_free": (i, [vp]), "hg_ctx_device": (i, [vp]),
+        "hg_multi_create": (i, [C.POINTER(i), i, C.POINTER(vp)]), "hg_multi_destroy": (None, [vp]), "hg_multi_last_error": (C.c_char_p, [vp]),
+        "hg_multi_device_count": (i, [vp]), "hg_multi_ctx": (vp, [vp, i]),
+        "hg_multi_partition": (i, [i, i, i, C.POINTER(i), C.POINTER(i)]),
+        "hg_multi_set_image": (i, [vp, u8p, i, i]), "hg_multi_piecewise_set_mesh": (i, [vp, f32p, i, C.POINTER(C.c_uint32), i, i, i]),
+        "hg_multi_warp_piecewise_batch": (i, [vp, f32p, C.POINTER(Geom), i, C.POINTER(vp)]),
+        "hg_multi_frame": (i, [vp, i, C.POINTER(i), C.POINTER(vp), C.POINTER(sz)]),
         "hg_solve_affine": (i, [f32p, f32p, f32p]), "hg_invert_affine": (i, [f32p, f32p]), "hg_solve_projective": (i, [f32p, f32p, f64p]),
         "hg_transform_limits": (i, [i, f64p, d, d, f64p]), "hg_minmax_xy": (i, [f32p, i, f64p]), "hg_js_round": (d, [d]),
         "hg_triangulate": (i, [f32p, i, C.POINTER(C.c_uint32), i, C.POINTER(i)]),
@@ -393,3 +402,109 @@ class Context:
 
     def warp_inverse_piecewise_frames_device(self, d_out):
         self._c(lib().hg_warp_inverse_piecewise_frames_device(self._h, C.c_void_p(int(d_out))))
+
+
+# ------------------------------------------------------------------ several GPUs, one host thread (hg_multi_*)
+
+def multi_partition(n_frames, n_devices, index):
+    """(first, count): the contiguous block of frames device `index` of `n_devices` warps (pure function, no GPU)."""
+    first, count = C.c_int(0), C.c_int(0)
+    _check(lib().hg_multi_partition(int(n_frames), int(n_devices), int(index), C.byref(first), C.byref(count)))
+    return first.value, count.value
+
+
+class PinnedBuffer:
+    """Page-locked host memory from hg_host_alloc, exposed as a numpy uint8 array."""
+
+    def __init__(self, nbytes):
+        self._p = C.c_void_p()
+        _check(lib().hg_host_alloc(int(nbytes), C.byref(self._p)))
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(int(nbytes),))
+
+    @property
+    def ptr(self):
+        return self._p.value
+
+    def free(self):
+        if self._p:
+            self.array = None
+            lib().hg_host_free(self._p)
+            self._p = C.c_void_p()
+
+
+class Multi:
+    """hg_multi: the batch caller loop spread over several devices of one node from ONE host thread."""
+
+    def __init__(self, devices):
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        code = lib().hg_multi_create(ids, len(devices), C.byref(self._h))
+        if code != 0:
+            self._h = C.c_void_p()
+            msg = lib().hg_multi_last_error(None)
+            raise HgError(code, msg.decode() if msg else "?")
+        self._n_pts = 0
+        self._geoms = []
+
+    def _c(self, code):
+        if code != 0:
+            msg = lib().hg_multi_last_error(self._h)
+            raise HgError(code, msg.decode() if msg else "?")
+
+    def close(self):
+        if self._h:
+            lib().hg_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_count(self):
+        return lib().hg_multi_device_count(self._h)
+
+    def set_option(self, key, value):
+        for k in range(self.device_count()):
+            ctx = lib().hg_multi_ctx(self._h, k)
+            _check(lib().hg_set_option(C.c_void_p(ctx), key.encode(), int(value)), C.c_void_p(ctx))
+
+    def set_image(self, rgba):
+        a = np.ascontiguousarray(rgba, dtype=np.uint8)
+        h, w = a.shape[:2]
+        self._c(lib().hg_multi_set_image(self._h, a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h))
+
+    def piecewise_set_mesh(self, src_pts, tris, min_src_x, min_src_y):
+        s, sp = _f32(src_pts)
+        t = np.ascontiguousarray(tris, dtype=np.uint32)
+        self._c(lib().hg_multi_piecewise_set_mesh(self._h, sp, s.size // 2, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size // 3, int(min_src_x), int(min_src_y)))
+        self._n_pts = s.size // 2
+
+    def warp_piecewise_batch(self, dst_pts, geoms, out_ptrs=None):
+        """out_ptrs: None (frames stay on their devices) or one host address per frame."""
+        d, dp = _f32(dst_pts)
+        assert d.size == 2 * self._n_pts * len(geoms)
+        ptrs = (C.c_void_p * len(geoms))(*[C.c_void_p(int(p)) for p in out_ptrs]) if out_ptrs is not None else None
+        self._geoms = [tuple(int(v) for v in g) for g in geoms]
+        self._c(lib().hg_multi_warp_piecewise_batch(self._h, dp, _geoms(geoms), len(geoms), ptrs))
+
+    def frame(self, f):
+        """(device index, device pointer, bytes) of frame f of the last batch."""
+        dev, ptr, n = C.c_int(0), C.c_void_p(), C.c_size_t(0)
+        self._c(lib().hg_multi_frame(self._h, int(f), C.byref(dev), C.byref(ptr), C.byref(n)))
+        return dev.value, ptr.value, n.value
+
+    def frame_to_host(self, f):
+        dev, ptr, n = self.frame(f)
+        out = np.empty(n, np.uint8)
+        ctx = C.c_void_p(lib().hg_multi_ctx(self._h, dev))
+        _check(lib().hg_copy_to_host(ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), n), ctx)
+        g = self._geoms[f]
+        return out.reshape(max(g[3], 0), max(g[2], 0), 4)

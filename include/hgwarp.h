@@ -73,6 +73,12 @@ int hg_device_alloc(hg_ctx *ctx, size_t bytes, void **dptr);
 int hg_device_free(hg_ctx *ctx, void *dptr);
 int hg_copy_to_host(hg_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
 int hg_copy_to_device(hg_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+/* D2H queued on the ctx stream behind the warps issued so far; dst must stay alive until hg_sync().  A true asynchronous
+ * DMA when dst is pinned memory from hg_host_alloc (page-locked, usable by every device). */
+int hg_copy_to_host_async(hg_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+int hg_host_alloc(size_t bytes, void **ptr);
+int hg_host_free(void *ptr);
+int hg_ctx_device(const hg_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------------ host-side solves
  * Tiny, run on the host in double precision with the reference's exact operation order; no GPU needed. */
@@ -180,6 +186,30 @@ int hg_warp_forward_geometric(hg_ctx *ctx, int kind, const double *m, hg_geom ge
 /* _piecewiseAffineWarp :948-972 on the mesh of hg_piecewise_set_mesh (whose min_src_x/y are the loop origin);
  * max_src_x/y = rounded source-point bbox maximum (:758); the forward triangle map :817-832 is rebuilt on the device. */
 int hg_warp_forward_piecewise(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host);
+
+/* ------------------------------------------------------------------------------------------------ several GPUs, one host thread
+ * The caller loop `for (f) { setDestinyPoints(dst_f); warp(); }` (test/benchmark.js:107-110) spread over the devices of one
+ * node for hosts that cannot run one process per GPU (the Node binding).  Frames are independent: device i
+ * of G warps the contiguous block hg_multi_partition() assigns to it, no data-path collective; the shared source texture is
+ * fanned out once per hg_multi_set_image over xGMI peer copies (scatter of 1/G slices from device 0, then an all-gather
+ * between the peers, so that every point-to-point link carries 1/G of the image instead of one link carrying all of it).
+ * A device id may be listed more than once (several contexts on one GPU). */
+typedef struct hg_multi hg_multi;
+int hg_multi_create(const int *device_ids, int n_devices, hg_multi **multi);
+void hg_multi_destroy(hg_multi *multi);
+const char *hg_multi_last_error(const hg_multi *multi);
+int hg_multi_device_count(const hg_multi *multi);
+hg_ctx *hg_multi_ctx(hg_multi *multi, int index);                       /* the per-device context (options, taps) */
+/* Pure function: frames [*first, *first + *count) of n_frames belong to device `index` of n_devices (sizes differ by <= 1). */
+int hg_multi_partition(int n_frames, int n_devices, int index, int *first, int *count);
+int hg_multi_set_image(hg_multi *multi, const uint8_t *rgba, int width, int height);
+int hg_multi_piecewise_set_mesh(hg_multi *multi, const float *src_points, int n_points, const uint32_t *triangles, int n_triangles,
+                                int min_src_x, int min_src_y);
+/* dst_points = n_frames x n_points x,y; out_host = NULL (frames stay on their devices: hg_multi_frame) or n_frames host
+ * pointers of 4*obj_w*obj_h bytes each (pinned memory from hg_host_alloc lets the devices' copies overlap).  Synchronous. */
+int hg_multi_warp_piecewise_batch(hg_multi *multi, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host);
+/* Where frame f of the last batch lives: index into the device list, device pointer, byte size (any of them may be NULL). */
+int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, size_t *bytes);
 
 /* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
  * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general). */

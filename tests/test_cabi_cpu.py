@@ -88,6 +88,26 @@ def test_register_lu_equals_oracle_lu_on_random_and_degenerate_squares():
     assert n_nan > 100                                       # the degenerate branch was exercised
 
 
+def test_multi_device_partition_covers_every_frame_once():
+    """hg_multi_partition (the frame -> device map of hg_multi_warp_piecewise_batch): contiguous blocks, every frame owned
+    exactly once, sizes differ by at most one; the same split as dist.shard_frames of the torch.distributed path."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hg_dist", os.path.join(ROOT, "homography.js_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    for n in (0, 1, 7, 8, 64, 511, 512, 513):
+        for G in (1, 2, 3, 8):
+            blocks = [HG.multi_partition(n, G, k) for k in range(G)]
+            flat = [f for first, cnt in blocks for f in range(first, first + cnt)]
+            assert flat == list(range(n))
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+            assert [list(range(a, a + c)) for a, c in blocks] == [list(D.shard_frames(n, k, G)) for k in range(G)]
+    with pytest.raises(HG.HgError):
+        HG.multi_partition(8, 0, 0)
+    with pytest.raises(HG.HgError):
+        HG.multi_partition(8, 2, 2)
+
+
 def test_pack_offsets():
     offs, total = HG.pack_offsets([(0, 0, 10, 3), (5, -2, 0, 7), (0, 0, 64, 64)])
     assert offs == [0, 256, 256] and total == 256 + 64 * 64 * 4

@@ -707,3 +707,48 @@ def test_far_away_and_absurd_vertices(ctx):
     ctx.piecewise_set_mesh(sp, tris, ms[0], ms[1])
     ctx.piecewise_prepare(d3, geom)
     assert np.array_equal(ctx.warp_inverse_piecewise(), O.warp_inverse_piecewise(sp, d3, tris, img, ms[0], ms[1], *geom))
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_multi_device_batch(devices):
+    """hg_multi_*: the batch caller loop over a device list from one host thread.  [0] is the degenerate single-GPU case;
+    [0, 0(, 0)] puts several contexts on the one GPU of this box, which runs the REAL multi-device code path -- partition,
+    scatter + all-gather fan-out of the source through hipMemcpyPeerAsync, per-device launches, per-device D2H -- with the
+    device talking to itself.  Every frame against the oracle; host outputs (pinned and pageable) and resident frames."""
+    W, H, nx, ny, F = 352, 208, 8, 5, 7
+    img = G.lcg_image(W, H, 321)
+    sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+    frames = [WL.sin_dst(sp, 4.0 + f, 8 + (f % 4)) for f in range(F)]
+    geoms = [WL.piecewise_geom(d) for d in frames]
+    mm = O.minmax_xy(sp)
+    want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, int(mm[0]), int(mm[1]), *geoms[f]) for f in range(F)]
+    with HG.Multi(devices) as m:
+        assert m.device_count() == len(devices)
+        m.set_image(img)
+        m.piecewise_set_mesh(sp, tris, int(mm[0]), int(mm[1]))
+        m.warp_piecewise_batch(np.concatenate(frames), geoms)                      # frames stay resident
+        seen = set()
+        for f in range(F):
+            dev, ptr, n = m.frame(f)
+            assert n == want[f].nbytes and (dev, ptr) not in seen
+            seen.add((dev, ptr))
+            assert dev == [k for k in range(len(devices)) if HG.multi_partition(F, len(devices), k)[0] <= f][-1]
+            assert np.array_equal(m.frame_to_host(f), want[f]), ("resident", f)
+        pinned = [HG.PinnedBuffer(w.nbytes) for w in want]
+        try:
+            m.warp_piecewise_batch(np.concatenate(frames), geoms, [p.ptr for p in pinned])
+            for f in range(F):
+                assert np.array_equal(pinned[f].array.reshape(want[f].shape), want[f]), ("pinned", f)
+        finally:
+            for p in pinned:
+                p.free()
+        outs = [np.zeros_like(w) for w in want]
+        m.warp_piecewise_batch(np.concatenate(frames), geoms, [o.ctypes.data for o in outs])
+        for f in range(F):
+            assert np.array_equal(outs[f], want[f]), ("pageable", f)
+        # a second image of another size through the same object (buffers regrow, aliases are re-attached)
+        img2 = G.lcg_image(W + 64, H + 32, 322)
+        m.set_image(img2)
+        m.warp_piecewise_batch(np.concatenate(frames), geoms)
+        for f in (0, F - 1):
+            assert np.array_equal(m.frame_to_host(f), O.warp_inverse_piecewise(sp, frames[f], tris, img2, int(mm[0]), int(mm[1]), *geoms[f])), ("regrown", f)
