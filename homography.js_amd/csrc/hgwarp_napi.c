@@ -5,7 +5,10 @@
  * and creates the result arrays; failures are thrown as bare strings like the reference does (`throw("...")`).
  * Built with plain gcc against /usr/include/node (Makefile target lib/hgwarp.node); no node-gyp, no C++.
  */
+#define _GNU_SOURCE
 #include <node_api.h>
+#include <sys/mman.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -82,6 +85,9 @@ static int get_i32(napi_env env, napi_value v, int *out)
 {
     double d;
     if (napi_get_value_double(env, v, &d) != napi_ok) { throw_str(env, "hgwarp: expected a number"); return 0; }
+    /* NaN, +-Infinity and anything outside int32 would be undefined behaviour in the conversion (degenerate matrices give
+     * such window sizes; the reference then dies with a RangeError on its allocation) */
+    if (!(d >= -2147483648.0 && d <= 2147483647.0)) { throw_str(env, "hgwarp: number is not finite or does not fit an int32 (Invalid typed array length)"); return 0; }
     *out = (int)d;
     return 1;
 }
@@ -91,6 +97,110 @@ static napi_value make_typed(napi_env env, napi_typedarray_type t, size_t n, siz
     napi_value ab, ta;
     NAPI_OK(napi_create_arraybuffer(env, n * elem, data, &ab));
     NAPI_OK(napi_create_typedarray(env, t, n, ab, 0, &ta));
+    return ta;
+}
+
+/* ---------------------------------------------------------------- pinned frame pool
+ * A fresh 34 MB Uint8ClampedArray per 4K frame is what the reference's contract asks for (:991, :1040), and in V8 that is a
+ * calloc -> mmap -> ~8 400 first-touch page faults (8-9 ms, far more than the 1.3 ms of PCIe traffic).  Frames of 1 MiB and
+ * more therefore come from a pool of page-locked buffers (hg_host_alloc) handed to JavaScript as EXTERNAL ArrayBuffers: the
+ * GPU DMAs straight into them and a buffer returns to the pool when its ArrayBuffer is collected.  Node 12 runs N-API
+ * finalizers from the event loop only, so a loop that never yields gets no buffer back: the pool then grows up to
+ * `pin_limit` bytes (default 2 GiB, setPinnedLimit()) and after that warp() falls back to plain V8 arrays (slower, still
+ * correct).  To get buffers back inside such a loop anyway, every pooled frame also carries a WEAK reference to its ArrayBuffer:
+ * V8 clears it during the collection itself, so pin_acquire() can see synchronously that a frame is dead and reuse its
+ * buffer long before the deferred finalizer runs (and the JS class asks for a collection when poolPressure() says the pool is
+ * starving: see there).  release(typedArray) hands a frame back at once (its ArrayBuffer is detached). */
+typedef struct { void *ptr; size_t cap; int in_use; unsigned gen; napi_ref weak; } pin_t;
+typedef struct { int idx; unsigned gen; } pin_ref_t;
+#define PIN_MAX 512
+static pin_t g_pins[PIN_MAX];
+static int g_npins = 0;
+static size_t g_pin_bytes = 0, g_pin_limit = (size_t)2 << 30;
+static const size_t PIN_MIN_FRAME = (size_t)1 << 20;
+static double g_stat_forced_gc = 0;
+#define PIN_GC_EVERY 32
+static int g_since_gc = 0;                                   /* pooled frames handed out since the last requested collection */
+static int g_pool_malloc = 0;                                /* _poolTestFrames(): plain malloc instead of pinned memory (no GPU needed) */
+static double g_stat_hit = 0, g_stat_new = 0, g_stat_fallback = 0, g_stat_reaped = 0, g_stat_finalized = 0;   /* poolStats() */
+
+static void pin_drop(int i)
+{
+    if (g_pins[i].ptr) { if (g_pool_malloc) free(g_pins[i].ptr); else hg_host_free(g_pins[i].ptr); g_pin_bytes -= g_pins[i].cap; }
+    g_pins[i].ptr = NULL; g_pins[i].cap = 0; g_pins[i].in_use = 0;
+}
+
+/* frames whose ArrayBuffer has been collected (weak reference cleared) although their finalizer has not run yet */
+static void pin_reap(napi_env env)
+{
+    for (int i = 0; i < g_npins; i++) {
+        if (!g_pins[i].ptr || !g_pins[i].in_use || !g_pins[i].weak) continue;
+        napi_value v = NULL;
+        if (napi_get_reference_value(env, g_pins[i].weak, &v) == napi_ok && v == NULL) {
+            napi_delete_reference(env, g_pins[i].weak);
+            g_pins[i].weak = NULL; g_pins[i].in_use = 0; g_pins[i].gen++;      /* the late finalizer will not match */
+            g_stat_reaped++;
+            int64_t adj; napi_adjust_external_memory(env, -(int64_t)g_pins[i].cap, &adj);
+        }
+    }
+}
+
+static int pin_acquire(napi_env env, size_t bytes)
+{
+    if (bytes < PIN_MIN_FRAME || g_pin_limit == 0) return -1;
+    int best = -1, empty = -1;
+    for (int pass = 0; pass < 2 && best < 0; pass++) {
+        if (pass == 1) pin_reap(env);
+        for (int i = 0; i < g_npins; i++) {
+            if (!g_pins[i].ptr) continue;
+            if (!g_pins[i].in_use && g_pins[i].cap >= bytes && g_pins[i].cap <= bytes + bytes / 2 && (best < 0 || g_pins[i].cap < g_pins[best].cap)) best = i;
+        }
+    }
+    g_since_gc++;
+    if (best >= 0) { g_pins[best].in_use = 1; g_stat_hit++; return best; }
+    for (int i = 0; i < g_npins; i++) if (!g_pins[i].ptr) { empty = i; break; }
+    /* make room: idle buffers of the wrong size go first */
+    for (int i = 0; i < g_npins && g_pin_bytes + bytes > g_pin_limit; i++) if (g_pins[i].ptr && !g_pins[i].in_use) { pin_drop(i); if (empty < 0) empty = i; }
+    if (g_pin_bytes + bytes > g_pin_limit) { g_stat_fallback++; return -1; }
+    if (empty < 0) { if (g_npins == PIN_MAX) { g_stat_fallback++; return -1; } empty = g_npins++; }
+    void *p = NULL;
+    if (g_pool_malloc) p = malloc(bytes);
+    else if (hg_host_alloc(bytes, &p) != HG_OK) p = NULL;
+    if (!p) { g_stat_fallback++; return -1; }
+    g_stat_new++;
+    g_pins[empty].ptr = p; g_pins[empty].cap = bytes; g_pins[empty].in_use = 1; g_pins[empty].gen++;
+    g_pin_bytes += bytes;
+    return empty;
+}
+
+static void pin_finalize(napi_env env, void *data, void *hint)
+{
+    (void)data;
+    pin_ref_t *r = (pin_ref_t *)hint;
+    if (r && r->idx >= 0 && r->idx < g_npins && g_pins[r->idx].gen == r->gen && g_pins[r->idx].in_use) {
+        if (g_pins[r->idx].weak) { napi_delete_reference(env, g_pins[r->idx].weak); g_pins[r->idx].weak = NULL; }
+        g_stat_finalized++;
+        g_pins[r->idx].in_use = 0;
+        int64_t adj; napi_adjust_external_memory(env, -(int64_t)g_pins[r->idx].cap, &adj);
+    }
+    free(r);
+}
+
+/* a Uint8ClampedArray of `bytes` bytes over a pooled pinned buffer, or NULL (pool exhausted / small frame) */
+static napi_value make_pinned(napi_env env, size_t bytes, void **data)
+{
+    const int i = pin_acquire(env, bytes);
+    if (i < 0) return NULL;
+    pin_ref_t *r = (pin_ref_t *)malloc(sizeof *r);
+    napi_value ab, ta;
+    if (!r) { g_pins[i].in_use = 0; return NULL; }
+    r->idx = i; r->gen = g_pins[i].gen;
+    if (napi_create_external_arraybuffer(env, g_pins[i].ptr, bytes, pin_finalize, r, &ab) != napi_ok) { g_pins[i].in_use = 0; free(r); return NULL; }
+    int64_t adj; napi_adjust_external_memory(env, (int64_t)g_pins[i].cap, &adj);     /* V8 learns about the memory pressure */
+    g_pins[i].weak = NULL;
+    if (napi_create_reference(env, ab, 0, &g_pins[i].weak) != napi_ok) g_pins[i].weak = NULL;
+    if (napi_create_typedarray(env, napi_uint8_clamped_array, bytes, ab, 0, &ta) != napi_ok) return NULL;
+    *data = g_pins[i].ptr;
     return ta;
 }
 
@@ -113,7 +223,126 @@ static napi_value make_pixels(napi_env env, size_t bytes, napi_value reuse, int 
             return ta;
         }
     }
-    return make_typed(env, napi_uint8_clamped_array, bytes, 1, data);
+    napi_value pinned = make_pinned(env, bytes, data);        /* fresh frame, pooled page-locked memory (see above) */
+    if (pinned) return pinned;
+    napi_value ta = make_typed(env, napi_uint8_clamped_array, bytes, 1, data);
+    /* Pool exhausted (or switched off): a plain V8 array.  Its memory is a fresh anonymous mapping nobody has touched yet;
+     * asking for transparent huge pages BEFORE the first write turns ~8 400 4-KiB page faults of a 4K frame into ~17 (where
+     * the kernel runs THP in `madvise` mode, as on the MI355X hosts).  Advice only: failure changes nothing. */
+    if (ta && bytes >= ((size_t)4 << 20) && *data) {
+        const uintptr_t lo = ((uintptr_t)*data + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)*data + bytes) & ~(uintptr_t)4095;
+        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+    }
+    return ta;
+}
+
+/* release(typedArray): a frame produced by warp() goes back to the pool now; its ArrayBuffer is detached (length 0). */
+static napi_value fn_release(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    bool is = false;
+    napi_typedarray_type t; size_t n = 0, off = 0; void *p = NULL; napi_value ab;
+    napi_value res; napi_get_boolean(env, false, &res);
+    if (napi_is_typedarray(env, a[0], &is) != napi_ok || !is || napi_get_typedarray_info(env, a[0], &t, &n, &p, &ab, &off) != napi_ok || !p) return res;
+    for (int i = 0; i < g_npins; i++)
+        if (g_pins[i].ptr == (char *)p - off && g_pins[i].in_use) {
+            if (napi_detach_arraybuffer(env, ab) != napi_ok) return res;
+            if (g_pins[i].weak) { napi_delete_reference(env, g_pins[i].weak); g_pins[i].weak = NULL; }
+            g_pins[i].in_use = 0; g_pins[i].gen++;                /* the pending finalizer of this ArrayBuffer no longer matches */
+            int64_t adj; napi_adjust_external_memory(env, -(int64_t)g_pins[i].cap, &adj);
+            napi_get_boolean(env, true, &res);
+            break;
+        }
+    return res;
+}
+
+/* _poolTestFrames(n, bytes): n frames of `bytes` bytes through the very allocation path warp() / warpBatch() use, without any
+ * GPU work (tests of the pool's life cycle on machines without a GPU; the pool is switched to plain malloc memory). */
+static napi_value fn_pool_test_frames(napi_env env, napi_callback_info info)
+{
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    int n; double bytes;
+    if (!get_i32(env, a[0], &n) || napi_get_value_double(env, a[1], &bytes) != napi_ok || n < 0 || !(bytes >= 0)) return throw_str(env, "hgwarp: _poolTestFrames(n, bytes)");
+    if (!g_pool_malloc) { for (int i = 0; i < g_npins; i++) if (g_pins[i].ptr && !g_pins[i].in_use) pin_drop(i); g_pool_malloc = 1; }
+    napi_value arr;
+    NAPI_OK(napi_create_array_with_length(env, n, &arr));
+    for (int f = 0; f < n; f++) {
+        void *out; napi_value ta = make_pixels(env, (size_t)bytes, NULL, 0, &out);
+        if (!ta) return NULL;
+        if (bytes > 0) ((uint8_t *)out)[0] = (uint8_t)f;
+        napi_set_element(env, arr, f, ta);
+    }
+    return arr;
+}
+
+/* poolPressure(bytes, n): should the caller run a collection before asking for n frames of `bytes` bytes?  True when the pool
+ * cannot serve them from free (or already collected) buffers AND at least `g_next_gc_live` pooled frames are alive or the
+ * cap would be exceeded.  A loop that allocates little JavaScript (warpBatch: 8 frames per call) can go a long time without
+ * a collection although dozens of 34 MB frames are garbage; V8's own external-memory heuristics start incremental cycles
+ * that treat everything allocated meanwhile as live.  The JS class then calls a real collector (js/Homography.mjs) and
+ * poolCollected(), which reaps and restarts the count: the next collection is due after another PIN_GC_EVERY pooled frames
+ * (a caller that really keeps all its frames alive pays one useless collection per PIN_GC_EVERY frames), or when the cap is hit. */
+
+static napi_value fn_pool_pressure(napi_env env, napi_callback_info info)
+{
+    napi_value a[2], res;
+    if (!get_args(env, info, 2, a)) return NULL;
+    double bytes; int n;
+    napi_get_boolean(env, false, &res);
+    if (napi_get_value_double(env, a[0], &bytes) != napi_ok || !get_i32(env, a[1], &n)) return res;
+    if (!(bytes >= (double)PIN_MIN_FRAME) || g_pin_limit == 0 || n <= 0) return res;
+    pin_reap(env);
+    int fit = 0, live = 0;
+    for (int i = 0; i < g_npins; i++) {
+        if (!g_pins[i].ptr) continue;
+        if (g_pins[i].in_use) live++;
+        else if (g_pins[i].cap >= (size_t)bytes && g_pins[i].cap <= (size_t)bytes + (size_t)bytes / 2) fit++;
+    }
+    if (fit >= n) return res;
+    (void)live;
+    if (g_since_gc >= PIN_GC_EVERY || (double)g_pin_bytes + (n - fit) * bytes > (double)g_pin_limit) napi_get_boolean(env, true, &res);
+    return res;
+}
+
+static napi_value fn_pool_collected(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    const double before = g_stat_reaped;
+    pin_reap(env);
+    g_since_gc = 0;
+    g_stat_forced_gc++;
+    napi_value v; NAPI_OK(napi_create_double(env, g_stat_reaped - before, &v));
+    return v;
+}
+
+/* poolStats(): counters of the pinned frame pool since the addon was loaded */
+static napi_value fn_pool_stats(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    int in_use = 0, total = 0;
+    for (int i = 0; i < g_npins; i++) if (g_pins[i].ptr) { total++; in_use += g_pins[i].in_use; }
+    const struct { const char *k; double x; } kv[] = { {"pinnedBytes", (double)g_pin_bytes}, {"buffers", total}, {"inUse", in_use}, {"reused", g_stat_hit},
+        {"allocated", g_stat_new}, {"fallbackToV8", g_stat_fallback}, {"reapedByWeakRef", g_stat_reaped}, {"forcedCollections", g_stat_forced_gc}, {"finalized", g_stat_finalized} };
+    for (size_t i = 0; i < sizeof kv / sizeof kv[0]; i++) { NAPI_OK(napi_create_double(env, kv[i].x, &v)); NAPI_OK(napi_set_named_property(env, o, kv[i].k, v)); }
+    return o;
+}
+
+/* setPinnedLimit(bytes): cap of the pinned frame pool (0 disables it: every frame is a plain V8 array); returns bytes in use */
+static napi_value fn_set_pinned_limit(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    double d;
+    if (napi_get_value_double(env, a[0], &d) != napi_ok || !(d >= 0)) return throw_str(env, "hgwarp: setPinnedLimit needs a non-negative number of bytes");
+    g_pin_limit = d > 1e15 ? (size_t)1e15 : (size_t)d;
+    for (int i = 0; i < g_npins; i++) if (g_pins[i].ptr && !g_pins[i].in_use && g_pin_bytes > g_pin_limit) pin_drop(i);
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)g_pin_bytes, &v));
+    return v;
 }
 
 /* optional trailing argument: argv[want] if present and not undefined/null */
@@ -328,7 +557,7 @@ static napi_value fn_warp_forward_geometric(napi_env env, napi_callback_info inf
     if (n < (size_t)(kind == HG_AFFINE ? 6 : 8)) return throw_str(env, "hgwarp: matrix too short");
     if (!get_geom(env, a + 3, &g)) return NULL;
     const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
-    void *out; napi_value r = make_typed(env, napi_uint8_clamped_array, px * 4, 1, &out); if (!r) return NULL;
+    void *out; napi_value r = make_pixels(env, px * 4, NULL, 0, &out); if (!r) return NULL;
     if (px) HG_CALL(h->ctx, "hg_warp_forward_geometric", hg_warp_forward_geometric(h->ctx, kind, m, g, (uint8_t *)out));
     return r;
 }
@@ -344,7 +573,7 @@ static napi_value fn_warp_forward_piecewise(napi_env env, napi_callback_info inf
     if (!get_geom(env, a + 4, &g)) return NULL;
     if (h->n_pts == 0 || n < 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold one x,y pair per mesh point (piecewiseSetMesh first)");
     const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
-    void *out; napi_value r = make_typed(env, napi_uint8_clamped_array, px * 4, 1, &out); if (!r) return NULL;
+    void *out; napi_value r = make_pixels(env, px * 4, NULL, 0, &out); if (!r) return NULL;
     if (px) HG_CALL(h->ctx, "hg_warp_forward_piecewise", hg_warp_forward_piecewise(h->ctx, dst, mx, my, g, (uint8_t *)out));
     return r;
 }
@@ -406,20 +635,130 @@ static napi_value fn_warp_inverse_piecewise_batch(napi_env env, napi_callback_in
     }
     void *d_out = h->d_batch;
     if (rc == HG_OK) rc = hg_warp_inverse_piecewise_batch_device(h->ctx, dst, (const hg_geom *)gv, offs, F, d_out);
-    if (rc == HG_OK) rc = hg_sync(h->ctx);
     napi_value arr = NULL;
     if (rc == HG_OK && napi_create_array_with_length(env, F, &arr) == napi_ok) {
+        /* every frame's copy queues behind the kernels on the ctx stream (pinned pool memory: asynchronous DMA), one sync at the end */
         for (int f = 0; f < F && rc == HG_OK; f++) {
             const hg_geom *g = (const hg_geom *)gv + f;
             const size_t px = (g->obj_w > 0 && g->obj_h > 0) ? (size_t)g->obj_w * g->obj_h : 0;
-            void *out; napi_value ta = make_typed(env, napi_uint8_clamped_array, px * 4, 1, &out);
+            void *out; napi_value ta = make_pixels(env, px * 4, NULL, 0, &out);
             if (!ta) { rc = HG_ERR_NOMEM; break; }
-            if (px) rc = hg_copy_to_host(h->ctx, out, (const uint8_t *)d_out + offs[f], px * 4);
+            if (px) rc = hg_copy_to_host_async(h->ctx, out, (const uint8_t *)d_out + offs[f], px * 4);
             napi_set_element(env, arr, f, ta);
         }
+        const int rc2 = hg_sync(h->ctx);
+        if (rc == HG_OK) rc = rc2;
     }
     free(offs);
     if (rc != HG_OK) return throw_hg(env, h->ctx, "warpInversePiecewiseBatch", rc);
+    return arr;
+}
+
+/* ---------------------------------------------------------------- several GPUs (hg_multi_*) */
+typedef struct { hg_multi *m; size_t n_pts; } mhandle_t;
+
+static void mhandle_finalize(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    mhandle_t *h = (mhandle_t *)data;
+    if (h) { if (h->m) hg_multi_destroy(h->m); free(h); }
+}
+
+static mhandle_t *get_mhandle(napi_env env, napi_value v)
+{
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((mhandle_t *)p)->m) { throw_str(env, "hgwarp: invalid or destroyed multi-device handle"); return NULL; }
+    return (mhandle_t *)p;
+}
+
+static napi_value throw_multi(napi_env env, hg_multi *m, const char *what, int code)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "hgwarp %s failed (%d): %s", what, code, hg_multi_last_error(m));
+    return throw_str(env, buf);
+}
+
+static napi_value fn_multi_create(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    size_t n;
+    int32_t *ids = (int32_t *)get_typed(env, a[0], napi_int32_array, &n, "devices"); if (!ids) return NULL;
+    if (n == 0) return throw_str(env, "hgwarp: multiCreate needs at least one device id");
+    mhandle_t *h = (mhandle_t *)calloc(1, sizeof *h);
+    int rc = hg_multi_create((const int *)ids, (int)n, &h->m);
+    if (rc != HG_OK) { free(h); return throw_multi(env, NULL, "hg_multi_create", rc); }
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, h, mhandle_finalize, NULL, &ext));
+    return ext;
+}
+
+static napi_value fn_multi_destroy(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    void *p = NULL;
+    if (napi_get_value_external(env, a[0], &p) == napi_ok && p && ((mhandle_t *)p)->m) { hg_multi_destroy(((mhandle_t *)p)->m); ((mhandle_t *)p)->m = NULL; }
+    return NULL;
+}
+
+static napi_value fn_multi_set_image(napi_env env, napi_callback_info info)
+{
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return NULL;
+    mhandle_t *h = get_mhandle(env, a[0]); if (!h) return NULL;
+    size_t n; int w, hh;
+    uint8_t *px = (uint8_t *)get_typed(env, a[1], napi_uint8_clamped_array, &n, "image.data"); if (!px) return NULL;
+    if (!get_i32(env, a[2], &w) || !get_i32(env, a[3], &hh)) return NULL;
+    if (w <= 0 || hh <= 0 || n < (size_t)w * (size_t)hh * 4) return throw_str(env, "hgwarp: image.data is smaller than width*height*4");
+    int rc = hg_multi_set_image(h->m, px, w, hh);
+    if (rc != HG_OK) return throw_multi(env, h->m, "hg_multi_set_image", rc);
+    return NULL;
+}
+
+static napi_value fn_multi_set_mesh(napi_env env, napi_callback_info info)
+{
+    napi_value a[5];
+    if (!get_args(env, info, 5, a)) return NULL;
+    mhandle_t *h = get_mhandle(env, a[0]); if (!h) return NULL;
+    size_t np, nt; int msx, msy;
+    float *src = (float *)get_typed(env, a[1], napi_float32_array, &np, "srcPoints"); if (!src) return NULL;
+    uint32_t *tris = (uint32_t *)get_typed(env, a[2], napi_uint32_array, &nt, "triangles"); if (!tris) return NULL;
+    if (!get_i32(env, a[3], &msx) || !get_i32(env, a[4], &msy)) return NULL;
+    int rc = hg_multi_piecewise_set_mesh(h->m, src, (int)(np / 2), tris, (int)(nt / 3), msx, msy);
+    if (rc != HG_OK) return throw_multi(env, h->m, "hg_multi_piecewise_set_mesh", rc);
+    h->n_pts = np / 2;
+    return NULL;
+}
+
+/* warpBatch over the device list: dst = F x 2N float32, geoms = Int32Array F x 4; returns an Array of F Uint8ClampedArray
+ * (pooled pinned memory where possible, so that the D2H copies of different devices run at the same time). */
+static napi_value fn_multi_warp_batch(napi_env env, napi_callback_info info)
+{
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return NULL;
+    mhandle_t *h = get_mhandle(env, a[0]); if (!h) return NULL;
+    size_t nd, ng;
+    float *dst = (float *)get_typed(env, a[1], napi_float32_array, &nd, "dstPoints"); if (!dst) return NULL;
+    int32_t *gv = (int32_t *)get_typed(env, a[2], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
+    const int F = (int)(ng / 4);
+    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
+    if (h->n_pts == 0 || nd < (size_t)F * 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold frames x mesh points x,y pairs (multiSetMesh first)");
+    napi_value arr;
+    NAPI_OK(napi_create_array_with_length(env, F, &arr));
+    uint8_t **outs = (uint8_t **)calloc((size_t)F, sizeof *outs);
+    uint8_t dummy = 0;
+    for (int f = 0; f < F; f++) {
+        const hg_geom *g = (const hg_geom *)gv + f;
+        const size_t px = (g->obj_w > 0 && g->obj_h > 0) ? (size_t)g->obj_w * g->obj_h : 0;
+        void *out = NULL; napi_value ta = make_pixels(env, px * 4, NULL, 0, &out);
+        if (!ta) { free(outs); return NULL; }
+        outs[f] = px ? (uint8_t *)out : &dummy;
+        napi_set_element(env, arr, f, ta);
+    }
+    int rc = hg_multi_warp_piecewise_batch(h->m, dst, (const hg_geom *)gv, F, outs);
+    free(outs);
+    if (rc != HG_OK) return throw_multi(env, h->m, "hg_multi_warp_piecewise_batch", rc);
     return arr;
 }
 
@@ -435,6 +774,9 @@ static napi_value init(napi_env env, napi_value exports)
         { "warpInversePiecewise", fn_warp_inverse_piecewise }, { "getTriMap", fn_get_tri_map }, { "getMatrices", fn_get_matrices },
         { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch },
         { "warpForwardGeometric", fn_warp_forward_geometric }, { "warpForwardPiecewise", fn_warp_forward_piecewise },
+        { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },
+        { "multiCreate", fn_multi_create }, { "multiDestroy", fn_multi_destroy }, { "multiSetImage", fn_multi_set_image },
+        { "multiSetMesh", fn_multi_set_mesh }, { "multiWarpBatch", fn_multi_warp_batch },
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

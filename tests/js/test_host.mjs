@@ -80,5 +80,28 @@ for (let k = 0; k < 12; k++) {
     ok(css.startsWith('matrix3d(') && css.split(',').length === 16, `projective css ${css}`);
     expectThrow(() => new Homography('piecewiseaffine').getTransformationMatrixAsCSS([[0, 0], [0, 1], [1, 0], [1, 1], [2, 2]], [[0, 0], [0, 1], [1, 0], [1, 1], [2, 2]], 10, 10), 'Transform matrix can not be calculated', 'css piecewise');
 }
+{   // life cycle of the page-locked frame pool, without a GPU (_poolTestFrames: the allocation path of warp() on malloc memory):
+    // a loop that never yields to the event loop must not grow the pool without bound (weak references + requested collections),
+    // frames that are alive never share memory, release() detaches, limit 0 means plain V8 arrays
+    const B = 8 * 1024 * 1024;
+    const require = createRequire(import.meta.url), hg = require('../../homography.js_amd/lib/hgwarp.node');
+    const room = (n) => { if (hg.poolPressure(B, n)) { const v8 = require('v8'), vm = require('vm'); v8.setFlagsFromString('--expose-gc'); vm.runInNewContext('gc')(); hg.poolCollected(); } };
+    let sum = 0;
+    for (let it = 0; it < 400; it++) { room(1); const o = hg._poolTestFrames(1, B)[0]; ok(o.length === B, 'frame size'); sum += o[0]; }
+    for (let it = 0; it < 60; it++) { room(8); for (const o of hg._poolTestFrames(8, B)) sum += o.length; }
+    let st = hg.poolStats();
+    ok(st.fallbackToV8 === 0 && st.buffers <= 80, `pool should stay bounded in a loop that never yields: ${JSON.stringify(st)}`);
+    const live = hg._poolTestFrames(6, B);
+    ok(new Set(live.map((o) => o.buffer)).size === 6, 'live frames share memory');
+    live.forEach((o, k) => { o.fill(k + 1); });
+    ok(live.every((o, k) => o[0] === k + 1 && o[B - 1] === k + 1), 'live frames overlap');
+    ok(hg.release(live[2]) === true && live[2].length === 0 && hg.release(live[2]) === false, 'release');
+    hg.setPinnedLimit(0);
+    const before = hg.poolStats().allocated;
+    const plain = hg._poolTestFrames(2, B);
+    ok(plain[0].length === B && hg.poolStats().allocated === before, 'limit 0: plain V8 arrays');
+    hg.setPinnedLimit(2 * 2 ** 30);
+    ok(hg._poolTestFrames(1, 1000)[0].length === 1000, 'small frames are plain arrays');
+}
 console.log(JSON.stringify({ failures: fails }));
 process.exit(fails.length ? 1 : 0);

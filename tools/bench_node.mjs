@@ -17,33 +17,78 @@ h.setTriangles(gridTriangles(nx, ny));
 h.setDestinyPoints(dsts[0], false);
 let out = h.warp();                                             // first call: context creation, buffers
 const res = { workload: `C3 ${W}x${H}, 200 triangles`, node: process.version };
-{   // the reference's per-frame loop: setDestinyPoints(dst_f); warp()
+// between the blocks: a few event-loop turns (+ a collection when run with --expose-gc) so that frames of the previous block
+// are finalized and their pooled buffers come back (Node 12 runs N-API finalizers from the event loop only)
+const snap = () => { const p = Homography.poolStats(); return `${p.buffers} buffers/${p.inUse} in use, reused ${p.reused}, new ${p.allocated}, v8 ${p.fallbackToV8}, reaped ${p.reapedByWeakRef}, forced gc ${p.forcedCollections}, finalized ${p.finalized}`; };
+const settle = async () => { out = null; for (let k = 0; k < 4; k++) { if (global.gc) global.gc(); await new Promise((r) => setImmediate(r)); } };
+(async () => {
+{   // plain V8 arrays only (pool off): what a fresh Uint8ClampedArray per frame costs by itself
+    Homography.setPinnedLimit(0);
     let frames = 0, px = 0; const t0 = now();
     while (now() - t0 < budget * 1e3) { h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(); frames++; px += out.width * out.height; }
     const ms = now() - t0;
-    res.warp_loop = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) };
+    res.warp_loop_v8_arrays = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
+    Homography.setPinnedLimit(2 * 2 ** 30);
 }
+await settle();
+{   // the reference's per-frame loop: setDestinyPoints(dst_f); warp()  (never yields: pooled buffers only come back when the pool cap is hit ... never)
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) { h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(); frames++; px += out.width * out.height; }
+    const ms = now() - t0;
+    res.warp_loop = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
+}
+await settle();
+{   // the same loop when the consumer hands each frame back before asking for the next (Homography.release): pooled pinned buffers
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) { h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(); frames++; px += out.width * out.height; Homography.release(out); }
+    const ms = now() - t0;
+    res.warp_loop_release = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
+}
+await settle();
 {   // the same loop with the opt-in single output buffer (reuseOutput)
     h.reuseOutput = true;
     let frames = 0, px = 0; const t0 = now();
     while (now() - t0 < budget * 1e3) { h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(); frames++; px += out.width * out.height; }
     const ms = now() - t0;
-    res.warp_loop_reuse = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) };
+    res.warp_loop_reuse = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
 }
 {   // ... and a source the caller promises not to mutate (staticImage): no re-upload per warp either
     h.staticImage = true;
     let frames = 0, px = 0; const t0 = now();
     while (now() - t0 < budget * 1e3) { h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(); frames++; px += out.width * out.height; }
     const ms = now() - t0;
-    res.warp_loop_reuse_static = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) };
+    res.warp_loop_reuse_static = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
     h.reuseOutput = false; h.staticImage = false;
 }
+await settle();
 {   // the same frames as one GPU pass
     const F = 8, sets = Array.from({ length: F }, (_, f) => dsts[f % 4]);
     let frames = 0, px = 0; const t0 = now();
     while (now() - t0 < budget * 1e3) { const outs = h.warpBatch(sets); frames += F; for (const o of outs) px += o.width * o.height; }
     const ms = now() - t0;
-    res.warp_batch8 = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) };
+    res.warp_batch8 = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
+}
+await settle();
+{   // batch with release of every frame after use
+    const F = 8, sets = Array.from({ length: F }, (_, f) => dsts[f % 4]);
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) { const outs = h.warpBatch(sets); frames += F; for (const o of outs) { px += o.width * o.height; Homography.release(o); } }
+    const ms = now() - t0;
+    res.warp_batch8_release = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
+}
+await settle();
+res.pinned_bytes = Homography.setPinnedLimit(2 * 2 ** 30);
+// the reference-style loop driven from the event loop (one frame per tick, like a requestAnimationFrame / stream consumer):
+// Node runs the finalizers of collected frames between ticks, so pooled buffers come back without release()
+{
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) {
+        h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(); frames++; px += out.width * out.height;
+        await new Promise((r) => setImmediate(r));
+    }
+    const ms = now() - t0;
+    res.warp_loop_async_tick = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1), pinned_bytes: Homography.setPinnedLimit(2 * 2 ** 30) , pool: snap() };
 }
 h.close();
 console.log(JSON.stringify(res));
+})();
