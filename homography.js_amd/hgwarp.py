@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libhgwarp.so")
+# HGWARP_LIB: another build of the SAME library (the sanitizer build lib/libhgwarp_asan.so, tools/run_asan.sh)
+LIB_PATH = os.environ.get("HGWARP_LIB") or os.path.join(HERE, "lib", "libhgwarp.so")
 
 HG_AFFINE, HG_PROJECTIVE = 0, 1
 
