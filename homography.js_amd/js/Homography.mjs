@@ -20,9 +20,12 @@
 //     here the forward map is simply rebuilt (what the author evidently meant);
 //   * frames of 1 MiB and more live in pooled page-locked memory handed out as external ArrayBuffers (no behavioural
 //     difference; `Homography.release(imageData)` optionally returns a frame to the pool at once);
-//   * Delaunator is not bundled: `Homography.triangulate` (default: ./delaunay.mjs, own Bowyer-Watson) supplies triangles;
-//     parity of the triangulation with delaunator@5.0.0 is NOT claimed (its source is absent from the reference tree);
-//     pass your own with setTriangles() or by assigning Homography.triangulate.
+//   * Delaunator is not bundled: `Homography.triangulate` (default: ./delaunay.mjs, a restatement of delaunator 5's
+//     sweep-hull algorithm that follows it step for step, so that triangle order and the diagonals of cocircular quads --
+//     which decide pixels where triangles meet -- come out the same) supplies the triangles.  delaunator@5.0.0's source is
+//     absent from the reference tree and none of its tests pins the triangulation, so identity with it is NOT claimed as
+//     tested ("triangulation parity unpinned"); for guaranteed identical meshes pass delaunator's own output through
+//     setTriangles() or assign Homography.triangulate.
 import { createRequire } from 'module';
 import { fileURLToPath } from 'url';
 import path from 'path';

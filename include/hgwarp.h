@@ -96,10 +96,12 @@ int hg_minmax_xy(const float *points, int n_values, double out[4]);
 /* Math.round (ties toward +Infinity), exposed so that bindings share one definition. */
 double hg_js_round(double x);
 /* Host Delaunay triangulation, where the reference calls `new Delaunator(points).triangles` (:1216-1218 <- :262, :742).
- * points = n_points interleaved x,y.  Writes up to `capacity` triangles (3 vertex ids each, counter-clockwise in a
- * y-up frame) and stores the total count in *n_triangles; pass out_triangles = NULL to query the count (at most
- * 2*n_points).  A valid Delaunay triangulation, identical (order included) to js/delaunay.mjs; NOT delaunator's
- * triangle order, which no reference test pins.  HG_ERR_INVALID for non-finite input or a too-small buffer. */
+ * points = n_points interleaved x,y.  Writes up to `capacity` triangles (3 vertex ids each) and stores the total count in
+ * *n_triangles; pass out_triangles = NULL to query the count (at most 2*n_points).  The algorithm is a restatement of
+ * delaunator 5.0.0's (sweep-hull, its seed choice, sort, hull hash and flip order; orientation by an exact-sign predicate), so
+ * the LIST is meant to equal delaunator's -- order and diagonals decide pixels where triangles meet -- but delaunator's
+ * source is absent from the reference tree and no reference test pins it: "triangulation parity unpinned".  Identical
+ * (order included) to js/delaunay.mjs.  HG_ERR_INVALID for non-finite input or a too-small buffer. */
 int hg_triangulate(const float *points, int n_points, uint32_t *out_triangles, int capacity, int *n_triangles);
 
 /* ------------------------------------------------------------------------------------------------ source image */
