@@ -269,6 +269,7 @@ constexpr int kStoreNT = 2;
 // one signed max picks the last writer AND carries the address of its matrix; ids are < 2^15 (pw_fast_ok)
 constexpr int kKeyShift = 14, kKeyOffMask = (1 << kKeyShift) - 1;
 
+template <int ABL>      // ABL != 0: timing experiments only (HG_EXPERIMENTS build): 32 = no slot atomics, 64 = no entry stores
 __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, RowLists rl)
 {
     const int t = blockIdx.x, f = blockIdx.y;
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
         if (r < 0 || r >= fd.obj_h || k < r * W || k >= (r + 1) * W) r = k / W;
         for (; r * W < fin; r++) {
             const int64_t lo = (k > r * W ? k : r * W) - r * W, hi = (fin < (r + 1) * W ? fin : (r + 1) * W) - r * W;
-            const int slot = atomicAdd(&rowcnt[r], 1);
-            if (slot < rl.cap) {
+            const int slot = (ABL & 32) ? (int)((t * 7 + (int)y) & 31) : atomicAdd(&rowcnt[r], 1);
+            if (slot < rl.cap && !(ABL & 64)) {
                 RowEnt e;
                 e.lo_hi = (uint32_t)lo | ((uint32_t)hi << 16);
                 e.id = t;
@@ -720,7 +721,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     uint32_t *tile = s_tile + wave * (kPatchRows * kPatchTilePitch);
     const float *__restrict__ ginv = fr.inv + (size_t)f * mesh.n_tris * kInvStride;     // GLOBALREC: this frame's inverse matrices
 
-    for (int cw = wave; cw < nbins; cw += 4) {              // this wave's 64-pixel-wide column blocks, all 4 rows at once
+    // One 64-pixel-wide column block, all 4 rows: span lookup, coordinates, gathers issued (not waited for).
+    auto resolve_gather = [&](int cw, uint32_t px[4]) {
         const int c0 = cw << 6;                             // pixel k of the lane: (c0 + ck[k], r0 + rr)
         int best[4] = { nan_key, nan_key, nan_key, nan_key };
         const int bidx = rr * kPatchBins + cw;
@@ -768,15 +770,16 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             h[2 * k + 1] = fma(m1, xd, m3 * y) + m5;
         }
         round_x8(h, rd);
-        uint32_t px[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi);   // :1047 (NaN fails)
             const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
             px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
         }
-        // 64 x 4 transpose through this wave's LDS tile (wave-synchronous: no barrier), so that each store instruction
-        // writes 256 contiguous bytes of ONE row instead of four 64-byte pieces (measured: 0.62 -> 0.50 ms on C5)
+    };
+    // 64 x 4 transpose through this wave's LDS tile (wave-synchronous: no barrier), so that each store instruction
+    // writes 256 contiguous bytes of ONE row instead of four 64-byte pieces (measured: 0.62 -> 0.50 ms on C5)
+    auto transpose_store = [&](int cw, const uint32_t px[4]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) tile[rr * kPatchTilePitch + ck[k]] = px[k];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -789,6 +792,13 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && k < nrows) ? (uint32_t)(k * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    // This wave's column blocks cw = wave, wave + 4, ...  (Measured and dropped: two blocks per phase -- the gathers of block A
+    // in flight while block B is resolved -- 0.504 vs 0.503 ms on C5: the wait for a block's gathers is not what limits it.)
+    for (int cw = wave; cw < nbins; cw += 4) {
+        uint32_t px[4];
+        resolve_gather(cw, px);
+        transpose_store(cw, px);
     }
 }
 
@@ -1101,7 +1111,13 @@ bool pw_fast_ok(const PwMesh &mesh, int max_obj_w)
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream)
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
-    hipLaunchKernelGGL(k_tri_spans, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl);
+#ifdef HG_EXPERIMENTS
+    static const int abl = getenv("HG_ABLATE_TRI") ? atoi(getenv("HG_ABLATE_TRI")) : 0;
+    if (abl == 32) { hipLaunchKernelGGL(k_tri_spans<32>, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl); return; }
+    if (abl == 64) { hipLaunchKernelGGL(k_tri_spans<64>, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl); return; }
+    if (abl == 96) { hipLaunchKernelGGL(k_tri_spans<96>, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl); return; }
+#endif
+    hipLaunchKernelGGL(k_tri_spans<0>, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl);
 }
 
 void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream)
