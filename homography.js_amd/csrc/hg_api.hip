@@ -437,6 +437,7 @@ extern "C" int hg_set_images_device(hg_ctx *c, const void *d_rgba, int w, int h,
 // ------------------------------------------------------------------------------------------------ frames helpers
 static int fill_frames(hg_ctx *c, std::vector<FrameDesc> &v, const hg_geom *geoms, const size_t *offs, int n)
 {
+    if (n > 65535) return fail(c, HG_ERR_INVALID, "more than 65535 frames in one set (the frame index is a grid dimension)");
     v.resize(n);
     size_t off = 0, moff = 0;
     for (int i = 0; i < n; i++) {
@@ -1060,44 +1061,78 @@ extern "C" int hg_get_matrices(hg_ctx *c, float *fwd, float *inv)
 }
 
 // ------------------------------------------------------------------------------------------------ forward (scatter) paths
+// Limits shared by the forward (scatter) entry points: the raster rank of a source pixel is an int32 (y*W + x resp. the
+// cell of the source-bbox map), the scatter kernels put source rows in grid.y, and every window passes the same checks as the
+// inverse paths (fill_frames: 2^31 pixels, offsets within 2^26, 4-byte aligned output offsets).
+static int forward_limits(hg_ctx *c, int64_t w, int64_t h, const char *what)
+{
+    if (w <= 0 || h <= 0) return HG_OK;
+    if (w * h >= ((int64_t)1 << 31)) return fail(c, HG_ERR_INVALID, std::string(what) + " has 2^31 pixels or more: the forward path ranks source pixels in 32 bits");
+    if (h > 65535) return fail(c, HG_ERR_INVALID, std::string(what) + " is taller than 65535 rows: not supported by the forward path");
+    return HG_OK;
+}
+
+extern "C" int hg_warp_forward_geometric_batch_device(hg_ctx *c, int kind, const double *m, const hg_geom *geoms, const size_t *offs, int n, void *d_out)
+{
+    HG_TRY(bind(c));
+    if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m || !geoms || n <= 0 || !d_out) return fail(c, HG_ERR_INVALID, "hg_warp_forward_geometric: bad arguments");
+    if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    HG_TRY(forward_limits(c, c->W, c->H, "the source image"));
+    std::vector<FrameDesc> fds;
+    HG_TRY(fill_frames(c, fds, geoms, offs, n));
+    size_t max_px = 0;
+    for (const FrameDesc &fd : fds) if (fd.obj_w > 0 && fd.obj_h > 0) max_px = std::max(max_px, (size_t)fd.obj_w * fd.obj_h);
+    if (max_px == 0) return HG_OK;
+    HG_TRY(hg_sync(c));
+    HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)8 * n));
+    HG_TRY(ensure(c, c->d_win32, c->win32_cap, max_px));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mats, m, sizeof(double) * 8 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));         // caller memory is not retained
+    c->geo_frames.clear();                               // the uploaded geometric frame set was overwritten
+    for (int f = 0; f < n; f++)                          // frames run back to back on the stream (one winner buffer, reused in order)
+        launch_fwd_geo(kind, c->d_mats + 8 * (size_t)f, c->d_img, c->W, c->H, fds[f], c->d_win32, static_cast<uint8_t *>(d_out), c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
+extern "C" int hg_warp_forward_geometric_device(hg_ctx *c, int kind, const double *m, hg_geom geom, void *d_out)
+{
+    if (!m) return fail(c, HG_ERR_INVALID, "m is NULL");
+    double m8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    std::memcpy(m8, m, sizeof(double) * (kind == HG_AFFINE ? 6 : 8));
+    const size_t zero = 0;
+    return hg_warp_forward_geometric_batch_device(c, kind, m8, &geom, &zero, 1, d_out);
+}
+
 extern "C" int hg_warp_forward_geometric(hg_ctx *c, int kind, const double *m, hg_geom geom, uint8_t *out_host)
 {
     HG_TRY(bind(c));
-    if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m || !out_host) return fail(c, HG_ERR_INVALID, "hg_warp_forward_geometric: bad arguments");
-    if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    if (!out_host) return fail(c, HG_ERR_INVALID, "hg_warp_forward_geometric: bad arguments");
     if (geom.obj_w <= 0 || geom.obj_h <= 0) return HG_OK;
-    HG_TRY(hg_sync(c));
     const size_t n = (size_t)geom.obj_w * geom.obj_h;
-    double m8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    std::memcpy(m8, m, sizeof(double) * (kind == HG_AFFINE ? 6 : 8));
-    HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)8));
-    HG_TRY(ensure(c, c->d_win32, c->win32_cap, n));
     HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, n * 4));
-    HIP_TRY(c, hipMemcpyAsync(c->d_mats, m8, sizeof(m8), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->geo_frames.clear();                               // the uploaded geometric frame set was overwritten
-    FrameDesc fd; fd.x_off = geom.x_off; fd.y_off = geom.y_off; fd.obj_w = geom.obj_w; fd.obj_h = geom.obj_h; fd.out_off = 0; fd.map_off = 0;
-    launch_fwd_geo(kind, c->d_mats, c->d_img, c->W, c->H, fd, c->d_win32, c->d_out_tmp, c->stream);
-    HIP_TRY(c, hipGetLastError());
+    HG_TRY(hg_warp_forward_geometric_device(c, kind, m, geom, c->d_out_tmp));
     HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HG_OK;
 }
 
-extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host)
+// _piecewiseAffineWarp :948-972 for n destination point sets on the current mesh (the caller loop `setDestinyPoints(d_f); warp()`
+// when warp() takes the forward path, :421), asynchronous, frames in GPU memory.
+extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *dst_points, int max_src_x, int max_src_y, const hg_geom *geoms,
+                                                      const size_t *offs, int n, void *d_out)
 {
     HG_TRY(bind(c));
-    if (!dst_points || !out_host) return fail(c, HG_ERR_INVALID, "hg_warp_forward_piecewise: bad arguments");
+    if (!dst_points || !geoms || n <= 0 || !d_out) return fail(c, HG_ERR_INVALID, "hg_warp_forward_piecewise: bad arguments");
     if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
     if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
-    if (geom.obj_w <= 0 || geom.obj_h <= 0) return HG_OK;
-    const int map_w = max_src_x - c->min_src_x, map_h = max_src_y - c->min_src_y;
-    const size_t n = (size_t)geom.obj_w * geom.obj_h;
+    const int64_t map_w = (int64_t)max_src_x - c->min_src_x, map_h = (int64_t)max_src_y - c->min_src_y;
+    HG_TRY(forward_limits(c, map_w, map_h, "the source-point bounding box"));
     const size_t n_map = (map_w > 0 && map_h > 0) ? (size_t)map_w * map_h : 0;
     // (A) forward triangle map over the source bbox: _buildTrianglesCorrespondencesMatrix :817-832 == the same
     //     rasteriser on the SOURCE triangles with width maxSrcX-minSrcX and y offset minSrcY.  It depends on the mesh only,
     //     so it is kept until the mesh (or the bbox) changes -- like the reference's cached _trianglesCorrespondencesMatrix.
-    hg_geom gmap = { 0, c->min_src_y, map_w, map_h };
+    hg_geom gmap = { 0, c->min_src_y, (int32_t)map_w, (int32_t)map_h };
     const size_t zero = 0;
     if (n_map && !(c->fmap_valid && c->fmap_w == map_w && c->fmap_h == map_h)) {
         HG_TRY(hg_piecewise_set_frames(c, c->h_src.data(), &gmap, &zero, 1));
@@ -1107,18 +1142,40 @@ extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int
         HG_TRY(ensure(c, c->d_fmap, c->fmap_cap, n_map));
         launch_map_build(mesh_of(c), frames_of(c), 0, c->pw_frames[0], c->d_fmap, c->stream);
         HIP_TRY(c, hipGetLastError());
-        c->fmap_valid = true; c->fmap_w = map_w; c->fmap_h = map_h;
+        c->fmap_valid = true; c->fmap_w = (int)map_w; c->fmap_h = (int)map_h;
     }
-    // (B) forward matrices of the real frame (:785-804), then scatter + gather
-    HG_TRY(hg_piecewise_set_frames(c, dst_points, &geom, &zero, 1));
+    // (B) forward matrices of every frame (:785-804) in one launch, then scatter + gather frame after frame
+    HG_TRY(hg_piecewise_set_frames(c, dst_points, geoms, offs, n));
     c->status_ptr = c->d_status;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * n, c->stream));
     launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
     c->pw_setup_done = false;
-    HG_TRY(ensure(c, c->d_win32, c->win32_cap, n));
-    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, n * 4));
-    launch_fwd_pw(c->d_fmap, c->d_fwd, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, map_w, map_h, c->pw_frames[0], c->d_win32, c->d_out_tmp, c->stream);
+    size_t max_px = 0;
+    for (const FrameDesc &fd : c->pw_frames) if (fd.obj_w > 0 && fd.obj_h > 0) max_px = std::max(max_px, (size_t)fd.obj_w * fd.obj_h);
+    if (max_px) {
+        HG_TRY(ensure(c, c->d_win32, c->win32_cap, max_px));
+        for (int f = 0; f < n; f++)
+            launch_fwd_pw(c->d_fmap, c->d_fwd + (size_t)f * c->n_tris * 6, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, (int)map_w, (int)map_h,
+                          c->pw_frames[f], c->d_win32, static_cast<uint8_t *>(d_out), c->stream);
+    }
     HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
+extern "C" int hg_warp_forward_piecewise_device(hg_ctx *c, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, void *d_out)
+{
+    const size_t zero = 0;
+    return hg_warp_forward_piecewise_batch_device(c, dst_points, max_src_x, max_src_y, &geom, &zero, 1, d_out);
+}
+
+extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host)
+{
+    HG_TRY(bind(c));
+    if (!out_host) return fail(c, HG_ERR_INVALID, "hg_warp_forward_piecewise: bad arguments");
+    if (geom.obj_w <= 0 || geom.obj_h <= 0) return HG_OK;
+    const size_t n = (size_t)geom.obj_w * geom.obj_h;
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, n * 4));
+    HG_TRY(hg_warp_forward_piecewise_device(c, dst_points, max_src_x, max_src_y, geom, c->d_out_tmp));
     HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HG_OK;

@@ -33,7 +33,8 @@ EXPORTS = [
     "hg_piecewise_set_mesh", "hg_piecewise_prepare", "hg_warp_inverse_piecewise", "hg_warp_inverse_piecewise_device",
     "hg_piecewise_set_frames", "hg_warp_inverse_piecewise_frames_device", "hg_warp_inverse_piecewise_batch_device",
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
-    "hg_warp_forward_geometric", "hg_warp_forward_piecewise",
+    "hg_warp_forward_geometric", "hg_warp_forward_piecewise", "hg_warp_forward_geometric_device", "hg_warp_forward_geometric_batch_device",
+    "hg_warp_forward_piecewise_device", "hg_warp_forward_piecewise_batch_device",
     "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_redone_frames", "hg_set_option", "hg_selftest_division", "hg_projective_plain_range",
 ]
 
@@ -100,6 +101,10 @@ def lib():
         "hg_kernel_ms_stats": (i, [vp, f64p, C.POINTER(i)]),
         "hg_warp_forward_geometric": (i, [vp, i, f64p, Geom, u8p]),
         "hg_warp_forward_piecewise": (i, [vp, f32p, i, i, Geom, u8p]),
+        "hg_warp_forward_geometric_device": (i, [vp, i, f64p, Geom, vp]),
+        "hg_warp_forward_geometric_batch_device": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
+        "hg_warp_forward_piecewise_device": (i, [vp, f32p, i, i, Geom, vp]),
+        "hg_warp_forward_piecewise_batch_device": (i, [vp, f32p, i, i, C.POINTER(Geom), C.POINTER(sz), i, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -330,6 +335,18 @@ class Context:
         out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
         self._c(lib().hg_warp_forward_piecewise(self._h, dp, int(max_src_x), int(max_src_y), g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
+
+    def warp_forward_geometric_batch_device(self, kind, mats, geoms, offsets, d_out):
+        m, p = _f64(mats)
+        assert m.size == 8 * len(geoms)
+        offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
+        self._c(lib().hg_warp_forward_geometric_batch_device(self._h, int(kind), p, _geoms(geoms), offs, len(geoms), C.c_void_p(int(d_out))))
+
+    def warp_forward_piecewise_batch_device(self, dst_pts, max_src_x, max_src_y, geoms, offsets, d_out):
+        d, dp = _f32(dst_pts)
+        assert d.size == 2 * self._n_pts * len(geoms), "frames x mesh points x,y pairs"
+        offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
+        self._c(lib().hg_warp_forward_piecewise_batch_device(self._h, dp, int(max_src_x), int(max_src_y), _geoms(geoms), offs, len(geoms), C.c_void_p(int(d_out))))
 
     def geometric_set_frames(self, kind, mats, geoms, offsets=None):
         m, p = _f64(mats)

@@ -49,7 +49,8 @@ enum { HG_AFFINE = 0, HG_PROJECTIVE = 1 };
 typedef struct hg_ctx hg_ctx;
 
 /* Output window of one frame, the reference's (_xOutputOffset, _yOutputOffset, _objectiveWidth, _objectiveHeight).
- * Accepted: up to 2^31 pixels, offsets up to 2^26 in magnitude (HG_ERR_INVALID beyond); obj_w / obj_h <= 0 = empty frame. */
+ * Accepted: up to 2^31 pixels, offsets up to 2^26 in magnitude, at most 65535 frames per set (HG_ERR_INVALID beyond);
+ * obj_w / obj_h <= 0 = empty frame. */
 typedef struct hg_geom { int32_t x_off, y_off, obj_w, obj_h; } hg_geom;
 
 /* ------------------------------------------------------------------------------------------------ library / context */
@@ -183,11 +184,21 @@ int hg_warp_inverse_piecewise_via_map(hg_ctx *ctx, uint8_t *out_host);
  * What warp() dispatches to when the output is not larger than the input (:421, :426).  `m` is the FORWARD matrix
  * (_transformMatrix).  Sequential "last writer in raster order wins" is reproduced deterministically (atomicMax of the
  * raster rank per output pixel, then a gather).  Synchronous, host output of 4*obj_w*obj_h bytes. */
-/* _geometricWarp :911-932 */
+/* _geometricWarp :911-932.  Limits of the forward paths (HG_ERR_INVALID beyond): source image resp. source-point bounding box
+ * below 2^31 pixels and at most 65535 rows; windows as for the inverse paths. */
 int hg_warp_forward_geometric(hg_ctx *ctx, int kind, const double *m, hg_geom geom, uint8_t *out_host);
+/* Same, asynchronous into GPU memory; batch = n frames (m = n x 8 doubles) back to back, frame f at out_offsets[f]. */
+int hg_warp_forward_geometric_device(hg_ctx *ctx, int kind, const double *m, hg_geom geom, void *d_out);
+int hg_warp_forward_geometric_batch_device(hg_ctx *ctx, int kind, const double *m, const hg_geom *geoms, const size_t *out_offsets,
+                                           int n_frames, void *d_out);
 /* _piecewiseAffineWarp :948-972 on the mesh of hg_piecewise_set_mesh (whose min_src_x/y are the loop origin);
  * max_src_x/y = rounded source-point bbox maximum (:758); the forward triangle map :817-832 is rebuilt on the device. */
 int hg_warp_forward_piecewise(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host);
+/* Same, asynchronous into GPU memory; batch = the caller loop `setDestinyPoints(d_f); warp()` for n destination point sets
+ * (dst_points = n_frames x n_points x,y) when warp() takes the forward path (:421). */
+int hg_warp_forward_piecewise_device(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, void *d_out);
+int hg_warp_forward_piecewise_batch_device(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, const hg_geom *geoms,
+                                           const size_t *out_offsets, int n_frames, void *d_out);
 
 /* ------------------------------------------------------------------------------------------------ several GPUs, one host thread
  * The caller loop `for (f) { setDestinyPoints(dst_f); warp(); }` (test/benchmark.js:107-110) spread over the devices of one

@@ -163,6 +163,54 @@ def test_forward_scatter_matches_oracle(ctx):
         assert np.array_equal(ctx.warp_forward_piecewise(dp, int(ms[2]), int(ms[3]), geom), want), ("piecewise", trial)
 
 
+def test_forward_scatter_batches_stay_on_the_device(ctx):
+    """The forward (scatter) paths as asynchronous batches into GPU memory: F frames back to back == the synchronous
+    single-frame calls == the oracle's sequential loops (last writer in raster order)."""
+    rng = np.random.default_rng(77)
+    W, H, nx, ny, F = 96, 64, 4, 3, 5
+    img = G.lcg_image(W, H, 41)
+    ctx.set_image(img)
+    # affine frames with windows of different sizes
+    mats, geoms = [], []
+    for f in range(F):
+        m6 = np.array([0.8 + 0.05 * f, 0.1 * f - 0.2, -0.15, 0.9, 3.0 * f, 2.0], np.float32).astype(np.float64)
+        mats.append(np.concatenate([m6, [0, 0]]))
+        geoms.append(tuple(int(v) for v in O.transform_limits(0, m6, W, H)))
+    offs, total = HG.pack_offsets(geoms)
+    d_out = ctx.alloc(max(total, 256))
+    try:
+        ctx.warp_forward_geometric_batch_device(0, np.concatenate(mats), geoms, offs, d_out)
+        ctx.sync()
+        for f in range(F):
+            g = geoms[f]
+            got = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+            assert np.array_equal(got, O.warp_forward_geometric(0, mats[f][:6], img, *g)), ("affine", f)
+            assert np.array_equal(got, ctx.warp_forward_geometric(0, mats[f][:6], g)), ("affine sync", f)
+    finally:
+        ctx.free(d_out)
+    # piecewise frames on one mesh
+    sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+    ms = O.minmax_xy(sp)
+    frames = [(sp.reshape(-1, 2) * np.float32(0.9 - 0.05 * f) + rng.uniform(-1.5, 1.5, (sp.size // 2, 2)).astype(np.float32)).astype(np.float32).ravel() for f in range(F)]
+    geoms = [WL.piecewise_geom(d) for d in frames]
+    ctx.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
+    offs, total = HG.pack_offsets(geoms)
+    d_out = ctx.alloc(max(total, 256))
+    try:
+        ctx.warp_forward_piecewise_batch_device(np.concatenate(frames), int(ms[2]), int(ms[3]), geoms, offs, d_out)
+        ctx.sync()
+        fmap = O.build_tri_map(sp, tris, int(ms[2] - ms[0]), int(ms[1]), int((ms[2] - ms[0]) * (ms[3] - ms[1])))
+        for f in range(F):
+            g = geoms[f]
+            got = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+            fwd = O.piecewise_matrices(sp, frames[f], tris)
+            want = O.warp_forward_piecewise(fmap, fwd, img, int(ms[0]), int(ms[1]), int(ms[2]), int(ms[3]), *g)
+            assert np.array_equal(got, want), ("piecewise", f)
+            assert np.array_equal(got, ctx.warp_forward_piecewise(frames[f], int(ms[2]), int(ms[3]), g)), ("piecewise sync", f)
+    finally:
+        ctx.free(d_out)
+
+
 def test_batch_frames_equal_single_frames(ctx):
     """F destination point sets in one launch == F single-frame calls (frames differ in geometry and offsets)."""
     W, H, nx, ny, F = 320, 200, 10, 6, 5
