@@ -51,7 +51,9 @@ struct hg_ctx {
     bool pw_setup_done = false;                                // the per-triangle solves ran for the uploaded frames
     // fast path: per-output-row span lists
     int32_t *d_rowcnt = nullptr; size_t rowcnt_cap = 0;
-    RowEnt *d_rowent = nullptr; size_t rowent_cap = 0;
+    uint8_t *d_rowent = nullptr; size_t rowent_cap = 0;        // bytes
+    int pw_cover = 0;                                          // estimated longest per-row span list of the uploaded frames
+    bool pw_compact = false;                                   // span lists use 8-byte entries (dense rows / k_pw_patch), else 32-byte
     int row_cap = 64;                                          // entries per row; grows (sticky) after an overflow
     bool pw_fast = false;                                      // uploaded frames are eligible for k_tri_spans/k_pw_rows
     bool rows_clean = false;                                   // span counters + the next status set were zeroed by the last k_pw_rows
@@ -750,6 +752,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     } else {
         cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear);
     }
+    c->pw_cover = cover;
     c->pw_row_group = cover <= 56 ? kRowGroup : 1;
     {   // few rows in total (a single 4K frame has 560 four-row groups for 256 CUs): one row per workgroup fills the chip better
         int64_t groups = 0;
@@ -813,11 +816,26 @@ static PwFrames frames_of(const hg_ctx *c)
 static RowLists rows_of(const hg_ctx *c)
 {
     RowLists r;
-    r.cnt = c->d_rowcnt; r.ent = c->d_rowent; r.cap = c->row_cap;
+    r.cnt = c->d_rowcnt; r.ent = c->d_rowent; r.cap = c->row_cap; r.compact = c->pw_compact ? 1 : 0;
     int mh = 0;
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     r.row_stride = std::max(mh, 1);
     return r;
+}
+
+// Would the next fused warp of this frame set go through k_pw_patch (the parity tap, which passes a map, never does)?
+static bool patch_preferred(const hg_ctx *c, bool *global_records)
+{
+#ifdef HG_EXPERIMENTS
+    static const int env_force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;    // experiments build only: 0 = never, 1 = whenever allowed by size
+#else
+    constexpr int env_force = -1;                            // the shipped library reads no environment variable
+#endif
+    const int force = c->opt_patch >= 0 ? c->opt_patch : env_force;
+    int mw = 0;
+    for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
+    if (global_records) *global_records = force == 2 ? true : (force == 1 ? false : c->pw_patch_dense);
+    return c->pw_fast && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force >= 1 : c->pw_patch);
 }
 
 // per-frame solves; status words are reset first.  Fast path: k_tri_spans (solves + per-row span lists);
@@ -829,13 +847,16 @@ static int run_setup(hg_ctx *c)
     for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
     c->pw_fast = pw_fast_ok(mesh_of(c), mw);
     if (c->pw_fast) {
+        // entry format of the span lists (hg_kernels.h): 8 bytes for dense rows and whenever k_pw_patch will read them
+        const bool compact = patch_preferred(c, nullptr) || c->pw_cover > 56;
+        if (compact != c->pw_compact) { c->pw_compact = compact; c->rows_clean = false; }
         RowLists rl = rows_of(c);
         // Row counters + kStatusRing sets of per-frame status words share one allocation.  It is zeroed by a memset only
         // for the first step after new frames (or after a setup whose warp never ran): k_pw_rows leaves the counters and
         // the next status set zeroed for the step that follows it.
         const int32_t *before = c->d_rowcnt;
         HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, F * rl.row_stride + kStatusRing * F));
-        HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, F * (size_t)rl.row_stride * rl.cap));
+        HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt))));
         rl = rows_of(c);
         if (before != c->d_rowcnt) c->rows_clean = false;
         if (c->rows_clean) c->status_slot = (c->status_slot + 1) % (int)kStatusRing;
@@ -861,16 +882,8 @@ static int run_setup(hg_ctx *c)
 
 static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
 {
-#ifdef HG_EXPERIMENTS
-    static const int env_force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;    // experiments build only: 0 = never, 1 = whenever allowed by size
-#else
-    constexpr int env_force = -1;                            // the shipped library reads no environment variable
-#endif
-    const int force = c->opt_patch >= 0 ? c->opt_patch : env_force;
-    int mw = 0;
-    for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
-    const bool patch = c->pw_fast && !map_out && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force >= 1 : c->pw_patch);
-    const bool global_records = force == 2 ? true : (force == 1 ? false : c->pw_patch_dense);
+    bool global_records = false;
+    const bool patch = patch_preferred(c, &global_records) && !map_out && c->pw_compact;
     c->pw_used_patch = patch;
     c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
     if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }

@@ -65,11 +65,20 @@ struct PwFrames {                   // per-frame device arrays, frame-major
 };
 
 // Per-output-row span lists of the fast path (k_tri_spans -> k_pw_rows), in global memory.
-struct RowEnt { uint32_t lo_hi; int32_t id; float m[6]; };      // cells [lo,hi) of the row (16 bits each), triangle id, inverse matrix
-static_assert(sizeof(RowEnt) == 32, "RowEnt must be 32 bytes");
+// Two entry formats, chosen per frame set (RowLists::compact):
+//   full    32 bytes: cells [lo,hi) of the row (16 bits each), triangle id, the triangle's inverse matrix.  Sparse rows
+//           (<= 56 spans, k_pw_rows' packed 4-row groups): the matrix arrives with the entry, no dependent load in the prologue.
+//   compact  8 bytes: cells + id only; consumers fetch the matrix by id from the per-(frame, triangle) tap array fr.inv (L2
+//           resident).  Dense rows (k_pw_patch, k_pw_rows one row per workgroup): a quarter of the list traffic -- C5's
+//           k_pw_patch 0.508 -> 0.415 ms, k_tri_spans 79 -> 68 us -- at the price of one dependent L2 load per row, which costs
+//           sparse C3 3 % and is why both formats exist.
+struct RowEnt { uint32_t lo_hi; int32_t id; float m[6]; };
+struct RowEnt8 { uint32_t lo_hi; int32_t id; };
+static_assert(sizeof(RowEnt) == 32 && sizeof(RowEnt8) == 8, "span entry sizes");
 struct RowLists {
     int32_t *cnt;            // F x row_stride   (zeroed before every k_tri_spans launch)
-    RowEnt *ent;             // F x row_stride x cap
+    void *ent;               // F x row_stride x cap entries of 32 (RowEnt) or 8 (RowEnt8) bytes
+    int32_t compact;         // 1: RowEnt8
     int32_t row_stride;      // >= max obj_h
     int32_t cap;             // entries per row
 };

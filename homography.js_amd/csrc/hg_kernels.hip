@@ -269,7 +269,7 @@ constexpr int kStoreNT = 2;
 // one signed max picks the last writer AND carries the address of its matrix; ids are < 2^15 (pw_fast_ok)
 constexpr int kKeyShift = 14, kKeyOffMask = (1 << kKeyShift) - 1;
 
-template <int ABL>      // ABL != 0: timing experiments only (HG_EXPERIMENTS build): 32 = no slot atomics, 64 = no entry stores
+template <int ABL, bool COMPACT>      // ABL != 0: timing experiments only (HG_EXPERIMENTS build): 32 = no slot atomics, 64 = no entry stores
 __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, RowLists rl)
 {
     const int t = blockIdx.x, f = blockIdx.y;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
     if (W <= 0 || fd.obj_h <= 0) return;
     const int64_t len = (int64_t)W * fd.obj_h;
     int32_t *__restrict__ rowcnt = rl.cnt + (size_t)f * rl.row_stride;
-    RowEnt *__restrict__ rowent = rl.ent + (size_t)f * rl.row_stride * rl.cap;
+    const size_t ent0 = (size_t)f * rl.row_stride * rl.cap;
     int64_t y_first = y_min, y_stop = y_end;
     clamp_rows(y_first, y_stop, fd.y_off, W, len);           // rows that cannot write a cell are skipped (hg_math.h)
     for (int64_t y = y_first + threadIdx.x; y < y_stop; y += blockDim.x) {
@@ -324,14 +324,14 @@ __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
             const int64_t lo = (k > r * W ? k : r * W) - r * W, hi = (fin < (r + 1) * W ? fin : (r + 1) * W) - r * W;
             const int slot = (ABL & 32) ? (int)((t * 7 + (int)y) & 31) : atomicAdd(&rowcnt[r], 1);
             if (slot < rl.cap && !(ABL & 64)) {
-                RowEnt e;
-                e.lo_hi = (uint32_t)lo | ((uint32_t)hi << 16);
-                e.id = t;
-#pragma unroll
-                for (int q = 0; q < 6; q++) e.m[q] = inv[q];
-                uint4 *dst = reinterpret_cast<uint4 *>(rowent + (size_t)r * rl.cap + slot);
-                const uint4 *srcv = reinterpret_cast<const uint4 *>(&e);
-                dst[0] = srcv[0]; dst[1] = srcv[1];
+                const size_t idx = ent0 + (size_t)r * rl.cap + slot;
+                const uint32_t lh = (uint32_t)lo | ((uint32_t)hi << 16);
+                if (COMPACT) static_cast<uint2 *>(rl.ent)[idx] = make_uint2(lh, (uint32_t)t);
+                else {
+                    uint4 *dst = static_cast<uint4 *>(rl.ent) + 2 * idx;
+                    dst[0] = make_uint4(lh, (uint32_t)t, __float_as_uint(inv[0]), __float_as_uint(inv[1]));
+                    dst[1] = make_uint4(__float_as_uint(inv[2]), __float_as_uint(inv[3]), __float_as_uint(inv[4]), __float_as_uint(inv[5]));
+                }
             }
         }
     }
@@ -392,7 +392,7 @@ __device__ __forceinline__ void span_max4d(int best[4], int d0, int d1, int d2, 
         : "vcc");
 }
 
-template <int CAP, int ABL, bool MAP, int PH = 1>
+template <int CAP, int ABL, bool MAP, int PH = 1, bool COMPACT = false>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
                                                  int32_t *__restrict__ status_next)
@@ -449,18 +449,29 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     const double by_lo = sgpr_f64((double)mesh.min_src_y + 0.5), by_hi = sgpr_f64((double)mesh.H + (double)mesh.min_src_y + 0.5);
     const int pitch4 = mesh.W * 4;
 
+    const float *__restrict__ ginv = fr.inv + (size_t)f * mesh.n_tris * kInvStride;
     // row `row` of the group -> LDS slots [base, base + cnt) (+ a NaN record in slot base + nan_slot that pixels without a
     // triangle point at); threads t0, t0 + step, ... of the caller's thread set do the copying
     auto load_row = [&](int row, int cnt, int base, int nan_slot, int t0, int step) {
         const double y = (double)(r0 + row + fd.y_off);
-        const RowEnt *__restrict__ ent = rl.ent + ((size_t)f * rl.row_stride + r0 + row) * rl.cap;
+        const size_t e0 = ((size_t)f * rl.row_stride + r0 + row) * rl.cap;
         for (int i = t0; i < cnt; i += step) {
-            const uint4 a = reinterpret_cast<const uint4 *>(ent + i)[0];
-            const uint4 b = reinterpret_cast<const uint4 *>(ent + i)[1];
-            const int elo = (int)(a.x & 0xffffu), ehi = (int)(a.x >> 16);
-            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)a.y << KS) | ((base + i) * 48);
-            const double m0 = (double)__uint_as_float(a.z), m1 = (double)__uint_as_float(a.w), m2 = (double)__uint_as_float(b.x),
-                         m3 = (double)__uint_as_float(b.y), m4 = (double)__uint_as_float(b.z), m5 = (double)__uint_as_float(b.w);
+            uint32_t lh, id;
+            double m0, m1, m2, m3, m4, m5;
+            if (COMPACT) {                                  // 8-byte entry; the triangle's f32 inverse matrix from the tap array (L2)
+                const uint2 a = static_cast<const uint2 *>(rl.ent)[e0 + i];
+                lh = a.x; id = a.y;
+                const float4 ma = *reinterpret_cast<const float4 *>(ginv + (size_t)id * kInvStride);
+                const float2 mb = *reinterpret_cast<const float2 *>(ginv + (size_t)id * kInvStride + 4);
+                m0 = (double)ma.x; m1 = (double)ma.y; m2 = (double)ma.z; m3 = (double)ma.w; m4 = (double)mb.x; m5 = (double)mb.y;
+            } else {                                        // 32-byte entry carrying the matrix
+                const uint4 a = static_cast<const uint4 *>(rl.ent)[2 * (e0 + i)], b = static_cast<const uint4 *>(rl.ent)[2 * (e0 + i) + 1];
+                lh = a.x; id = a.y;
+                m0 = (double)__uint_as_float(a.z); m1 = (double)__uint_as_float(a.w); m2 = (double)__uint_as_float(b.x);
+                m3 = (double)__uint_as_float(b.y); m4 = (double)__uint_as_float(b.z); m5 = (double)__uint_as_float(b.w);
+            }
+            const int elo = (int)(lh & 0xffffu), ehi = (int)(lh >> 16);
+            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)id << KS) | ((base + i) * 48);
             double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
             mrec[0] = make_double2(m0, m2 * y);              // {m0, m2*y, m4, m1, m3*y, m5}: m2*y and m3*y are the separately
             mrec[1] = make_double2(m4, m1);                  // rounded products of :1383-1384
@@ -637,6 +648,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
 
     // ---- phase 1: span lists -> LDS; each triangle of the group gets ONE matrix record (hash on the id: the thread that
     // claims the bucket writes the record and publishes its index; the others remember the bucket and read it later)
+    const float *__restrict__ ginv0 = fr.inv + (size_t)f * mesh.n_tris * kInvStride;     // this frame's inverse matrices (tap array)
     int my_bucket[(kPatchRows * CAPR + 255) / 256];
     int n_mine = 0;
     if (!bad0) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
@@ -644,8 +656,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
         const int cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
         int bucket = -1;
         if (i < cnt) {
-            const RowEnt *ent = rl.ent + ((size_t)f * rl.row_stride + r0 + rr) * rl.cap + i;
-            const uint4 a = reinterpret_cast<const uint4 *>(ent)[0];
+            const uint2 a = static_cast<const uint2 *>(rl.ent)[((size_t)f * rl.row_stride + r0 + rr) * rl.cap + i];      // RowEnt8 (the host pairs this kernel with compact lists)
             s_lohi[e] = a.x;
             const uint32_t id = a.y;
             if (!GLOBALREC) {
@@ -655,11 +666,12 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
                     if (old == 0u) {                                        // claimed: this thread owns the triangle's record
                         const int rec = atomicAdd(&s_nrec, 1);
                         if (rec < kPatchRecs) {
-                            const uint4 b = reinterpret_cast<const uint4 *>(ent)[1];
+                            const float4 ma = *reinterpret_cast<const float4 *>(ginv0 + (size_t)id * kInvStride);
+                            const float2 mb = *reinterpret_cast<const float2 *>(ginv0 + (size_t)id * kInvStride + 4);
                             double2 *mrec = reinterpret_cast<double2 *>(s_rec + rec * 6);
-                            mrec[0] = make_double2((double)__uint_as_float(a.z), (double)__uint_as_float(b.x));    // m0, m2
-                            mrec[1] = make_double2((double)__uint_as_float(b.z), (double)__uint_as_float(a.w));    // m4, m1
-                            mrec[2] = make_double2((double)__uint_as_float(b.y), (double)__uint_as_float(b.w));    // m3, m5
+                            mrec[0] = make_double2((double)ma.x, (double)ma.z);    // m0, m2
+                            mrec[1] = make_double2((double)mb.x, (double)ma.y);    // m4, m1
+                            mrec[2] = make_double2((double)ma.w, (double)mb.y);    // m3, m5
                             s_hash[hpos] = (id << 16) | (uint32_t)(rec + 1);
                         } else s_fail = 1;
                         bucket = (int)hpos;
@@ -1111,13 +1123,15 @@ bool pw_fast_ok(const PwMesh &mesh, int max_obj_w)
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream)
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
+    const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads == 64 ? 64 : 128);
 #ifdef HG_EXPERIMENTS
     static const int abl = getenv("HG_ABLATE_TRI") ? atoi(getenv("HG_ABLATE_TRI")) : 0;
-    if (abl == 32) { hipLaunchKernelGGL(k_tri_spans<32>, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl); return; }
-    if (abl == 64) { hipLaunchKernelGGL(k_tri_spans<64>, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl); return; }
-    if (abl == 96) { hipLaunchKernelGGL(k_tri_spans<96>, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl); return; }
+    if (abl == 32) { hipLaunchKernelGGL((k_tri_spans<32, false>), grid, block, 0, stream, mesh, fr, rl); return; }
+    if (abl == 64) { hipLaunchKernelGGL((k_tri_spans<64, false>), grid, block, 0, stream, mesh, fr, rl); return; }
+    if (abl == 96) { hipLaunchKernelGGL((k_tri_spans<96, false>), grid, block, 0, stream, mesh, fr, rl); return; }
 #endif
-    hipLaunchKernelGGL(k_tri_spans<0>, dim3(mesh.n_tris, fr.n_frames), dim3(fr.tri_threads == 64 ? 64 : 128), 0, stream, mesh, fr, rl);
+    if (rl.compact) hipLaunchKernelGGL((k_tri_spans<0, true>), grid, block, 0, stream, mesh, fr, rl);
+    else            hipLaunchKernelGGL((k_tri_spans<0, false>), grid, block, 0, stream, mesh, fr, rl);
 }
 
 void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream)
@@ -1135,12 +1149,17 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
     const int rpx = ((fr.max_obj_h + rg - 1) / rg + 7) / 8;                     // row groups per XCD band
     dim3 grid((unsigned)rpx * 8u * (unsigned)fr.n_frames);
+#define HG_ROWS(CAP, MAPF, PHV, CMP) hipLaunchKernelGGL((k_pw_rows<CAP, 0, MAPF, PHV, CMP>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
     if (rl.cap > kRowSpanCapFast) {                          // very dense meshes: 512 LDS slots per row (32 KB), one row per workgroup
-        if (map_out) hipLaunchKernelGGL((k_pw_rows<kRowSpanCapDense, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next);
-        else         hipLaunchKernelGGL((k_pw_rows<kRowSpanCapDense, 0, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next);
+        if (rl.compact) { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, true); else HG_ROWS(kRowSpanCapDense, false, 1, true); }
+        else            { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, false); else HG_ROWS(kRowSpanCapDense, false, 1, false); }
         return;
     }
-    if (map_out) { hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return; }
+    if (map_out) { if (rl.compact) HG_ROWS(kRowSpanCapFast, true, 1, true); else HG_ROWS(kRowSpanCapFast, true, 1, false); return; }
+    if (rl.compact) {                                        // dense rows: 8-byte entries
+        if (fr.phase == 2) HG_ROWS(kRowSpanCapFast, false, 2, true); else HG_ROWS(kRowSpanCapFast, false, 1, true);
+        return;
+    }
 #ifdef HG_EXPERIMENTS
     // Timing experiments of DESIGN.md §6 (ablated variants produce WRONG pixels): only in the separate experiments build
     // (`make experiments` -> lib/libhgwarp_exp.so); the shipped library has neither the instantiations nor the switch.
@@ -1156,10 +1175,11 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     }
 #endif
     switch (fr.phase) {
-    case 4:  hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false, 4>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
-    case 2:  hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false, 2>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
-    default: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 0, false, 1>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); break;
+    case 4:  HG_ROWS(kRowSpanCapFast, false, 4, false); break;
+    case 2:  HG_ROWS(kRowSpanCapFast, false, 2, false); break;
+    default: HG_ROWS(kRowSpanCapFast, false, 1, false); break;
     }
+#undef HG_ROWS
 }
 
 void launch_map_build(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, int32_t *map32, hipStream_t stream)
