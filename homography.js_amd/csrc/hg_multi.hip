@@ -188,7 +188,20 @@ extern "C" int hg_multi_piecewise_set_mesh(hg_multi *m, const float *src_points,
 // The caller loop for F frames over all devices: device i warps the contiguous block hg_multi_partition gives it, all
 // devices at once.  Frames stay resident (hg_multi_frame) unless out_host is given: then out_host[f] receives frame f
 // (4*obj_w*obj_h bytes; pinned memory from hg_host_alloc makes the copies of different devices overlap).
+static int multi_batch_impl(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host);
+
 extern "C" int hg_multi_warp_piecewise_batch(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
+{
+    const int rc = multi_batch_impl(m, dst_points, geoms, n_frames, out_host);
+    if (rc != HG_OK && m) {                                  // nothing may still be writing into the caller's buffers when an error is reported
+        const std::string why = m->err;
+        for (auto &d : m->devs) if (d.ctx) (void)hg_sync(d.ctx);
+        m->err = why; g_merr = why;
+    }
+    return rc;
+}
+
+static int multi_batch_impl(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
 {
     if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
     if (!dst_points || !geoms || n_frames <= 0) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_piecewise_batch: bad arguments");
