@@ -67,7 +67,7 @@ struct hg_ctx {
     bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
     long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
-    int opt_min_row_groups = 1536, opt_patch = -1, opt_phase = -1;   // hg_set_option()
+    int opt_min_row_groups = 1536, opt_patch = -1, opt_phase = -1, opt_geo_nw = 4;   // hg_set_option()
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
     struct Pending { uint8_t *out; int slot; };
@@ -275,6 +275,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     if (!std::strcmp(key, "min_row_groups")) c->opt_min_row_groups = value;
     else if (!std::strcmp(key, "patch")) c->opt_patch = value;
     else if (!std::strcmp(key, "phase")) c->opt_phase = value;
+    else if (!std::strcmp(key, "geo_windows")) c->opt_geo_nw = value;
     else return fail(c, HG_ERR_INVALID, std::string("hg_set_option: unknown key ") + key);
     return HG_OK;
 }
@@ -559,7 +560,7 @@ extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
     HG_TRY(time_begin(c));
     launch_geo(c->geo_kind, c->geo_f32_exact, c->d_geo_frames, c->d_mats, (int)c->geo_frames.size(), mw, mh, c->d_img, c->W, c->H,
                c->n_imgs, (uint64_t)c->img_stride, static_cast<uint8_t *>(d_out),
-               (c->geo_from_points && c->geo_kind == HG_PROJECTIVE) ? c->d_geo_plain : nullptr, c->stream);
+               (c->geo_from_points && c->geo_kind == HG_PROJECTIVE) ? c->d_geo_plain : nullptr, c->opt_geo_nw, c->stream);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
     return HG_OK;

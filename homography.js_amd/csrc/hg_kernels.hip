@@ -964,7 +964,7 @@ __global__ void k_selftest_division(uint64_t seed, uint64_t n_per_thread, unsign
 //     choice from the flag the device-side solve wrote (k_solve_frames);
 //   * Math.round + bounds :1001 via two round-toward-minus-infinity adds per coordinate (round_x8), source through a
 //     range-checked buffer load (0 outside the array), stores through a per-row buffer descriptor (no tail guards).
-template <int KIND>
+template <int KIND, int NW>
 __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ frames, const double *__restrict__ mats,
                                                   const uint8_t *__restrict__ img0, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *__restrict__ out,
                                                   const int32_t *__restrict__ plain)
@@ -973,9 +973,9 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
     const uint8_t *__restrict__ img = n_imgs > 1 ? img0 + (uint64_t)(blockIdx.z % n_imgs) * img_stride : img0;
     const int r = blockIdx.y * 4 + threadIdx.y;            // one wave per row of the block
     const int lane = threadIdx.x;
-    const int c0 = blockIdx.x << 8;
+    const int cb = blockIdx.x * (256 * NW);                // this wave's NW consecutive 256-pixel windows of the row
     const int OW = fd.obj_w;
-    if (r >= fd.obj_h || c0 >= OW) return;
+    if (r >= fd.obj_h || cb >= OW) return;
     const double *__restrict__ mp = mats + (size_t)blockIdx.z * 8;
     double m[8];
 #pragma unroll
@@ -985,43 +985,48 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
     const double y = (double)(r + fd.y_off);
     const double bx_hi = (double)W + 0.5, by_hi = (double)H + 0.5;
     const int pitch4 = W * 4;
-    double h[8], rd[8];
-    if (KIND == 0 || KIND == 2) {
-        const double cx = m[2] * y, cy = m[3] * y;                         // :1383-1384
+    // row constants, once per wave: fl(m2*y), fl(m3*y) (affine) / fl(m1*y), fl(m4*y), fl(m7*y) (projective)   :1383-1384 / :1402-1403
+    const double cx = (KIND == 0 || KIND == 2) ? m[2] * y : m[1] * y, cy = (KIND == 0 || KIND == 2) ? m[3] * y : m[4] * y, ad = m[7] * y;
+    // KIND 4: matrices solved on the device (k_solve_frames), which also proved (or not) the plain range per frame
+    const bool use_plain = KIND == 4 && __builtin_amdgcn_readfirstlane(plain[blockIdx.z]) != 0;
+    // NW windows per wave, gathers of all of them issued before the first store (see k_pw_rows: loads and stores share vmcnt)
+    uint32_t px[NW][4];
+#pragma unroll
+    for (int p = 0; p < NW; p++) {
+        const int c0 = cb + p * 256;
+        if (c0 >= OW) break;                               // wave-uniform
+        double h[8], rd[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const double x = (double)(c0 + lane + k * 64 + fd.x_off);
-            if (KIND == 0) {                                               // f32-valued matrix: exact product, fma == mul then add
+            if (KIND == 0) {                               // f32-valued matrix: exact product, fma == mul then add
                 h[2 * k] = fma(m[0], x, cx) + m[4];
                 h[2 * k + 1] = fma(m[1], x, cy) + m[5];
-            } else {                                                       // arbitrary doubles: keep both roundings
+            } else if (KIND == 2) {                        // arbitrary doubles: keep both roundings
                 h[2 * k] = ((m[0] * x) + cx) + m[4];
                 h[2 * k + 1] = ((m[1] * x) + cy) + m[5];
+            } else {
+                const double den = ((m[6] * x) + ad) + 1.0;
+                const double nx = ((m[0] * x) + cx) + m[2], ny = ((m[3] * x) + cy) + m[5];
+                if (KIND == 3 || (KIND == 4 && use_plain)) div2_plain(nx, ny, den, h[2 * k], h[2 * k + 1]);     // same bits, one reciprocal (proved range)
+                else { h[2 * k] = nx / den; h[2 * k + 1] = ny / den; }
             }
         }
-    } else {
-        const double ax = m[1] * y, ay = m[4] * y, ad = m[7] * y;          // :1402-1403
-        // KIND 4: matrices solved on the device (k_solve_frames), which also proved (or not) the plain range per frame
-        const bool use_plain = KIND == 4 && __builtin_amdgcn_readfirstlane(plain[blockIdx.z]) != 0;
+        round_x8(h, rd);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const double x = (double)(c0 + lane + k * 64 + fd.x_off);
-            const double den = ((m[6] * x) + ad) + 1.0;
-            const double nx = ((m[0] * x) + ax) + m[2], ny = ((m[3] * x) + ay) + m[5];
-            if (KIND == 3 || (KIND == 4 && use_plain)) div2_plain(nx, ny, den, h[2 * k], h[2 * k + 1]);     // same bits, one reciprocal (proved range)
-            else { h[2 * k] = nx / den; h[2 * k + 1] = ny / den; }
+            const bool inb = (int)(h[2 * k] >= 0.5) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= 0.5) & (int)(h[2 * k + 1] < by_hi);     // :1001 (NaN fails)
+            const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2)); // :1005
+            px[p][k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
         }
     }
-    round_x8(h, rd);
-    uint32_t px[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const bool inb = (int)(h[2 * k] >= 0.5) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= 0.5) & (int)(h[2 * k + 1] < by_hi);     // :1001 (NaN fails)
-        const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2)); // :1005
-        px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
+    for (int p = 0; p < NW; p++) {
+        const int c0 = cb + p * 256;
+        if (c0 >= OW) break;
+#pragma unroll
+        for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[p][k], dst, (c0 + lane + k * 64) * 4, 0, kStoreNT);
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[k], dst, (c0 + lane + k * 64) * 4, 0, kStoreNT);
 }
 
 // ------------------------------------------------------------------------------------------------ forward (scatter) paths
@@ -1209,19 +1214,25 @@ void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream
 }
 
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
-                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, hipStream_t stream)
+                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, hipStream_t stream)
 {
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
-    dim3 grid((max_w + 255) / 256, (max_h + 3) / 4, n_frames);
     const bool fast = ((int64_t)H + 2) * W * 4 < ((int64_t)1 << 31) && W < (1 << 21) && H < (1 << 22) && max_w < (1 << 28);
     if (fast) {
-        if (kind == 1 && plain) hipLaunchKernelGGL(k_geo_fast<4>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
-        else if (kind == 1 && f32_exact) hipLaunchKernelGGL(k_geo_fast<3>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
-        else if (kind == 1) hipLaunchKernelGGL(k_geo_fast<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
-        else if (f32_exact) hipLaunchKernelGGL(k_geo_fast<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
-        else                hipLaunchKernelGGL(k_geo_fast<2>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain);
+        const int NW = nw == 1 ? 1 : (nw == 2 ? 2 : 4);        // windows per wave (measured on C2, 1 -> 2 -> 4: 0.198 -> 0.177 -> 0.171 ms)
+        dim3 grid((max_w + 256 * NW - 1) / (256 * NW), (max_h + 3) / 4, n_frames);
+#define HG_GEO(K) do { if (NW == 1) hipLaunchKernelGGL((k_geo_fast<K, 1>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); \
+                       else if (NW == 4) hipLaunchKernelGGL((k_geo_fast<K, 4>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); \
+                       else hipLaunchKernelGGL((k_geo_fast<K, 2>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); } while (0)
+        if (kind == 1 && plain) HG_GEO(4);
+        else if (kind == 1 && f32_exact) HG_GEO(3);
+        else if (kind == 1) HG_GEO(1);
+        else if (f32_exact) HG_GEO(0);
+        else                HG_GEO(2);
+#undef HG_GEO
         return;
     }
+    dim3 grid((max_w + 255) / 256, (max_h + 3) / 4, n_frames);
     if (kind == 0) hipLaunchKernelGGL(k_geo<0>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
     else           hipLaunchKernelGGL(k_geo<1>, grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out);
 }

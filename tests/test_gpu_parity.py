@@ -19,7 +19,7 @@ GOLD = G.load()
 # results must not depend on it, so every test that takes `ctx` runs under each layout policy.
 LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0}, "rows1": {"min_row_groups": 1 << 30, "patch": 0},
            "patch": {"min_row_groups": 0, "patch": 1}, "patch_global": {"min_row_groups": 0, "patch": 2},
-           "phase1": {"phase": 1, "patch": 0}, "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0}}
+           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1}, "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))

@@ -25,14 +25,20 @@ def main():
         F = Fopt or {"C5": 8, "C5flat": 8}.get(config, 64)
         img = torch.from_numpy(wl.lcg_image(W, H, 1)).to(dev)
         srcs = None
-        if cfg["kind"] == "face":
+        proj = cfg["kind"] == "projective"
+        if proj:
+            s4 = wl.corners(W, H)
+            d4s = [wl.projective_dst(W, H, 0.0125 * (f % 10)) for f in range(F)]
+            geoms = [tuple(int(v) for v in hg.transform_limits(1, hg.solve_projective(s4, d4), W, H)) for d4 in d4s]
+        elif cfg["kind"] == "face":
             sp = wl.face_mesh(W, H, cfg["landmarks"]); tris = hg.triangulate(sp); seq = wl.face_frames(sp, W, cfg["total_frames"])
             frames = [seq[f] for f in range(F)]
         else:
             sp, tris = wl.grid_points(W, H, cfg["nx"], cfg["ny"]), wl.grid_triangles(cfg["nx"], cfg["ny"])
             frames = [wl.sin_grid_dst(W, H, cfg["nx"], cfg["ny"], cfg["A"], 8 + f % 4) for f in range(F)]
-        geoms = [wl.piecewise_geom(d) for d in frames]
-        msx, msy = wl.src_min(sp)
+        if not proj:
+            geoms = [wl.piecewise_geom(d) for d in frames]
+            msx, msy = wl.src_min(sp)
         offs, total = hg.pack_offsets(geoms)
         out = torch.empty(total, dtype=torch.uint8, device=dev)
         ref = None
@@ -46,16 +52,21 @@ def main():
                     ctx.set_images_device(srcs.data_ptr(), W, H, F, W * H * 4)
                 else:
                     ctx.set_image_device(img.data_ptr(), W, H)
-                ctx.piecewise_set_mesh(sp, tris, msx, msy)
-                ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                if proj:
+                    ctx.geometric_set_frames_points(1, np.concatenate(d4s), np.tile(s4, F), geoms, offs)
+                    run = ctx.warp_inverse_geometric_frames_device
+                else:
+                    ctx.piecewise_set_mesh(sp, tris, msx, msy)
+                    ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                    run = ctx.warp_inverse_piecewise_frames_device
                 out.zero_(); torch.cuda.synchronize()
-                for _ in range(60): ctx.warp_inverse_piecewise_frames_device(out.data_ptr())
+                for _ in range(60): run(out.data_ptr())
                 ctx.sync()
                 if ref is None: ref = out.clone()
                 same = bool(torch.equal(ref, out))
                 ctx.set_timing(True)
                 t0 = time.perf_counter()
-                for _ in range(100): ctx.warp_inverse_piecewise_frames_device(out.data_ptr())
+                for _ in range(100): run(out.data_ptr())
                 ctx.sync()
                 dt = (time.perf_counter() - t0) / 100 * 1e3
                 tot, n = ctx.kernel_ms_stats()
