@@ -19,6 +19,12 @@ for t in range(trials):
     W, H = int(rng.integers(8, 700)), int(rng.integers(8, 400))
     img = G.lcg_image(W, H, 9000 + t)
     mode = t % 8
+    # a random kernel-layout policy per trial (results must not depend on it): k_pw_rows phases, row groups, k_pw_patch variants,
+    # windows per wave of the geometric kernel
+    ctx.set_option("phase", int(rng.choice([-1, 1, 2, 4])))
+    ctx.set_option("patch", int(rng.choice([-1, -1, 0, 1, 2])))
+    ctx.set_option("min_row_groups", int(rng.choice([1536, 0, 1 << 30])))
+    ctx.set_option("geo_windows", int(rng.choice([1, 2, 4])))
     nx, ny = int(rng.integers(1, 24)), int(rng.integers(1, 16))
     if mode == 6:
         nx, ny = int(rng.integers(30, 140)), int(rng.integers(1, 6))                      # dense rows: 1 row per workgroup, > 63 spans per row
@@ -70,6 +76,19 @@ for t in range(trials):
             for f, g in enumerate(geoms):
                 gotf = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
                 ok = ok and np.array_equal(gotf, O.warp_inverse_piecewise(sp32, frames[f], tris, img, int(ms[0]), int(ms[1]), *g))
+            # ... and with one source per frame (hg_set_images_device)
+            imgs = [img, G.lcg_image(W, H, 5000 + t), G.lcg_image(W, H, 7000 + t)]
+            d_src = ctx.alloc(W * H * 4 * 3)
+            for k3 in range(3):
+                ctx.to_device(d_src, imgs[k3], k3 * W * H * 4)
+            ctx.set_images_device(d_src, W, H, 3, W * H * 4)
+            ctx.warp_inverse_piecewise_frames_device(d_out)
+            ctx.sync()
+            for f, g in enumerate(geoms):
+                gotf = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                ok = ok and np.array_equal(gotf, O.warp_inverse_piecewise(sp32, frames[f], tris, imgs[f], int(ms[0]), int(ms[1]), *g))
+            ctx.set_image(img)
+            ctx.free(d_src)
             ctx.free(d_out)
     # geometric kernels on the same image
     d4 = (WL.corners(W, H).reshape(4, 2) * rng.uniform(0.4, 2.0, 2) + rng.uniform(-0.2, 0.2, (4, 2)) * [W, H] + rng.uniform(-50, 50, 2)).astype(np.float32).ravel()
@@ -79,7 +98,16 @@ for t in range(trials):
     if np.all(np.isfinite(lim)) and 0 < lim[2] * lim[3] < 6_000_000:
         lim = [int(v) for v in lim]
         inv = O.projective_from_squares(d4, s4)
-        ok = ok and np.array_equal(ctx.warp_inverse_geometric(1, HG.solve_projective(d4, s4), lim), O.warp_inverse_geometric(1, inv, img, *lim))
+        wantg = O.warp_inverse_geometric(1, inv, img, *lim)
+        ok = ok and np.array_equal(ctx.warp_inverse_geometric(1, HG.solve_projective(d4, s4), lim), wantg)
+        if t % 3 == 0:                                                                      # the same frame with the matrix solved on the device
+            d_g = ctx.alloc(lim[2] * lim[3] * 4)
+            ctx.geometric_set_frames_points(1, d4, s4, [lim])
+            ctx.warp_inverse_geometric_frames_device(d_g)
+            ctx.sync()
+            ok = ok and np.array_equal(ctx.to_host(d_g, lim[2] * lim[3] * 4).reshape(lim[3], lim[2], 4), wantg)
+            ok = ok and np.array_equal(ctx.get_geometric_matrices(1)[0].view(np.uint64), inv.view(np.uint64))
+            ctx.free(d_g)
     fa = O.affine_from_triangles(s4[:6], d4[:6]).astype(np.float64)
     lim = O.transform_limits(0, fa, W, H)
     if np.all(np.isfinite(lim)) and 0 < lim[2] * lim[3] < 6_000_000:
