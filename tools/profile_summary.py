@@ -31,5 +31,9 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for kn, cn, n, v in con.execute(q):
             print(f"  {kn[:44]:44s} {cn:24s} n={n:3d} avg={v:.6g}")
 for log in sorted(glob.glob(os.path.join(out, "*.log"))):
-    tail = open(log, errors="replace").read().strip().splitlines()[-1:]
-    print(f"-- {os.path.basename(log)}: {tail[0][:300] if tail else ''}")
+    lines = open(log, errors="replace").read().strip().splitlines()
+    js = [ln for ln in lines if ln.startswith("{")]
+    if js:
+        print(f"-- {os.path.basename(log)}: bench line printed by this run: {js[-1]}")
+    else:
+        print(f"-- {os.path.basename(log)}: {lines[-1][:300] if lines else ''}")
