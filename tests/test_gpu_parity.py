@@ -794,6 +794,11 @@ def test_multi_device_batch(devices):
         m.warp_piecewise_batch(np.concatenate(frames), geoms, [o.ctypes.data for o in outs])
         for f in range(F):
             assert np.array_equal(outs[f], want[f]), ("pageable", f)
+        # fewer frames than devices (some devices idle) and an empty window among them
+        few = [frames[0], frames[1]]
+        fgeoms = [geoms[0], (geoms[1][0], geoms[1][1], 0, geoms[1][3])]
+        m.warp_piecewise_batch(np.concatenate(few), fgeoms)
+        assert np.array_equal(m.frame_to_host(0), want[0]) and m.frame(1)[2] == 0
         # a second image of another size through the same object (buffers regrow, aliases are re-attached)
         img2 = G.lcg_image(W + 64, H + 32, 322)
         m.set_image(img2)
