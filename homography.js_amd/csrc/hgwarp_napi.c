@@ -654,6 +654,54 @@ static napi_value fn_warp_inverse_piecewise_batch(napi_env env, napi_callback_in
     return arr;
 }
 
+/* The caller loop `setDestinyPoints(dst_f); warp()` for an affine / projective transform as one device pass: from / to = F point
+ * sets each (3 or 4 points x,y float32; the matrix of frame f maps from[f] -> to[f]: pass dst, src for the inverse warp, the
+ * solves run on the GPU like the reference's :994 runs per warp), geoms = Int32Array F x 4; returns an Array of F frames. */
+static napi_value fn_warp_inverse_geometric_batch(napi_env env, napi_callback_info info)
+{
+    napi_value a[5];
+    if (!get_args(env, info, 5, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    int kind; size_t nf, nt, ng;
+    if (!get_i32(env, a[1], &kind)) return NULL;
+    if (kind != HG_AFFINE && kind != HG_PROJECTIVE) return throw_str(env, "hgwarp: kind must be 0 (affine) or 1 (projective)");
+    float *from = (float *)get_typed(env, a[2], napi_float32_array, &nf, "fromPoints"); if (!from) return NULL;
+    float *to = (float *)get_typed(env, a[3], napi_float32_array, &nt, "toPoints"); if (!to) return NULL;
+    int32_t *gv = (int32_t *)get_typed(env, a[4], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
+    const int F = (int)(ng / 4);
+    const size_t per = kind == HG_AFFINE ? 6 : 8;
+    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
+    if (nf < (size_t)F * per || nt < (size_t)F * per) return throw_str(env, "hgwarp: point sets must hold frames x points x,y pairs");
+    size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
+    size_t total = 0;
+    hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
+    int rc = HG_OK;
+    if (total > h->d_batch_cap) {
+        if (h->d_batch) hg_device_free(h->ctx, h->d_batch);
+        h->d_batch = NULL; h->d_batch_cap = 0;
+        rc = hg_device_alloc(h->ctx, total, &h->d_batch);
+        if (rc == HG_OK) h->d_batch_cap = total;
+    }
+    if (rc == HG_OK) rc = hg_geometric_set_frames_points(h->ctx, kind, from, to, (const hg_geom *)gv, offs, F);
+    if (rc == HG_OK) rc = hg_warp_inverse_geometric_frames_device(h->ctx, h->d_batch);
+    napi_value arr = NULL;
+    if (rc == HG_OK && napi_create_array_with_length(env, F, &arr) == napi_ok) {
+        for (int f = 0; f < F && rc == HG_OK; f++) {
+            const hg_geom *g = (const hg_geom *)gv + f;
+            const size_t px = (g->obj_w > 0 && g->obj_h > 0) ? (size_t)g->obj_w * g->obj_h : 0;
+            void *out; napi_value ta = make_pixels(env, px * 4, NULL, 0, &out);
+            if (!ta) { rc = HG_ERR_NOMEM; break; }
+            if (px) rc = hg_copy_to_host_async(h->ctx, out, (const uint8_t *)h->d_batch + offs[f], px * 4);
+            napi_set_element(env, arr, f, ta);
+        }
+        const int rc2 = hg_sync(h->ctx);
+        if (rc == HG_OK) rc = rc2;
+    }
+    free(offs);
+    if (rc != HG_OK) return throw_hg(env, h->ctx, "warpInverseGeometricBatch", rc);
+    return arr;
+}
+
 /* ---------------------------------------------------------------- several GPUs (hg_multi_*) */
 typedef struct { hg_multi *m; size_t n_pts; } mhandle_t;
 
@@ -772,7 +820,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "setImage", fn_set_image }, { "warpInverseGeometric", fn_warp_inverse_geometric },
         { "piecewiseSetMesh", fn_piecewise_set_mesh }, { "piecewisePrepare", fn_piecewise_prepare },
         { "warpInversePiecewise", fn_warp_inverse_piecewise }, { "getTriMap", fn_get_tri_map }, { "getMatrices", fn_get_matrices },
-        { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch },
+        { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch }, { "warpInverseGeometricBatch", fn_warp_inverse_geometric_batch },
         { "warpForwardGeometric", fn_warp_forward_geometric }, { "warpForwardPiecewise", fn_warp_forward_piecewise },
         { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },
         { "multiCreate", fn_multi_create }, { "multiDestroy", fn_multi_destroy }, { "multiSetImage", fn_multi_set_image },

@@ -238,7 +238,8 @@ class Homography {
      * ImageData-shaped frames, each identical to what the loop would return with applyAlwaysInverse = true.
      */
     warpBatch(dstPointSets, options = {}) {
-        if (this.transform !== 'piecewiseaffine') throw ("hgwarp: warpBatch() is for the piecewise affine transform");
+        if (this.transform === 'affine' || this.transform === 'projective') return this._warpBatchGeometric(dstPointSets);
+        if (this.transform !== 'piecewiseaffine') throw ("hgwarp: warpBatch() needs a transform (set the source points first)");
         if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
         const F = dstPointSets.length, n = this._srcPoints.length;
         const all = new Float32Array(F * n), geoms = new Int32Array(F * 4);
@@ -270,6 +271,35 @@ class Homography {
             datas = this._native.warpInversePiecewiseBatch(this._ctx, all, geoms);
         }
         return datas.map((d, f) => makeImageData(d, geoms[4 * f + 2], geoms[4 * f + 3]));
+    }
+
+    /**
+     * warpBatch() for affine / projective: every `setDestinyPoints(dst_f)` of the loop runs on the host exactly as in the loop
+     * (normalisation auto-detect, in-place range alignment, forward matrix, output window); the inverse matrices the reference
+     * re-solves inside every warp (:994) are solved on the GPU, one lane per frame, and all frames are warped in one launch.
+     * Frames equal `warp(null, false, true)` of the loop; the instance ends in the state the loop would leave it in.
+     */
+    _warpBatchGeometric(dstPointSets) {
+        if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
+        const F = dstPointSets.length, per = this.transform === 'affine' ? 6 : 8;
+        const from = new Float32Array(F * per), to = new Float32Array(F * per), geoms = new Int32Array(F * 4);
+        const blank = [];
+        let largest = 0;
+        for (let f = 0; f < F; f++) {
+            this.setDestinyPoints(dstPointSets[f]);
+            this._alignRanges();                                                                         // :993
+            from.set(asF32(this._dstPoints).subarray(0, per), f * per);                                  // inverse: dst -> src (:994)
+            to.set(asF32(this._srcPoints).subarray(0, per), f * per);
+            const [xo, yo, ow, oh] = this._window();
+            if (!(ow * oh >= 1)) { blank.push(f); geoms.set([0, 0, 0, 0], f * 4); continue; }
+            largest = Math.max(largest, checkedLength(ow * oh * 4));
+            geoms.set([xo, yo, ow, oh], f * 4);
+        }
+        this._lastPath = '_inverseGeometricWarp';
+        this._uploadImage();
+        makeRoomFor(this._native, largest, F);
+        const datas = this._native.warpInverseGeometricBatch(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, from, to, geoms);
+        return datas.map((d, f) => (blank.includes(f) ? makeImageData(new Uint8ClampedArray(4), 1, 1) : makeImageData(d, geoms[4 * f + 2], geoms[4 * f + 3])));
     }
 
     /** hg_multi handle for a device list (kept while the list stays the same). */

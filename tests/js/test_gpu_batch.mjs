@@ -69,6 +69,33 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     ok(q.warp(null, false, true).data.every((v) => v === 9 || v === 0), 'staticImage: setImage() must upload the new content');
     q.close();
 }
+{   // warpBatch for projective and affine: the setDestinyPoints + warp loop with the per-frame solves on the GPU
+    const im = lcgImage(480, 270, 33);
+    const pj = new Homography('projective');
+    pj.setSourcePoints([[0, 0], [0, 270], [480, 0], [480, 270]], im, 480, 270, false);
+    const psets = [];
+    for (let f = 0; f < 6; f++) psets.push([[48 + 3 * f, 0], [48, 270 - 2 * f], [480, 67 - 5 * f], [480 + 7 * f, 202]]);
+    const loop = psets.map((d) => { pj.setDestinyPoints(d, false); return pj.warp(null, false, true); });
+    const bat = pj.warpBatch(psets);
+    ok(bat.length === 6, 'projective batch length');
+    bat.forEach((b, f) => ok(b.width === loop[f].width && b.height === loop[f].height && sha(b.data) === sha(loop[f].data), `projective batch frame ${f} differs from the loop`));
+    const af = new Homography('affine');
+    af.setSourcePoints([[0, 0], [0, 270], [480, 0]], im, 480, 270, false);
+    const asets = [];
+    for (let f = 0; f < 5; f++) asets.push([[10 * f, 135], [240, 216 + 9 * f], [240 + 4 * f, 0]]);
+    const aloop = asets.map((d) => { af.setDestinyPoints(d, false); return af.warp(null, false, true); });
+    const abat = af.warpBatch(asets);
+    abat.forEach((b, f) => ok(b.width === aloop[f].width && b.height === aloop[f].height && sha(b.data) === sha(aloop[f].data), `affine batch frame ${f} differs from the loop`));
+    // normalised points go through the same auto-detect as the loop
+    const nj = new Homography('projective');
+    nj.setSourcePoints([[0, 0], [0, 1], [1, 0], [1, 1]], im);
+    const nsets = [[[0.1, 0], [0.1, 1], [1, 0.25], [1, 0.75]], [[0.2, 0.1], [0.1, 0.9], [0.9, 0.2], [1, 0.8]]];
+    const nloop = nsets.map((d) => { nj.setDestinyPoints(d); return nj.warp(null, false, true); });
+    const nj2 = new Homography('projective');
+    nj2.setSourcePoints([[0, 0], [0, 1], [1, 0], [1, 1]], im);
+    nj2.warpBatch(nsets).forEach((b, f) => ok(b.width === nloop[f].width && sha(b.data) === sha(nloop[f].data), `normalised projective batch frame ${f} differs`));
+    pj.close(); af.close(); nj.close(); nj2.close();
+}
 {   // several GPUs behind one host thread: warpBatch(sets, {devices}).  This box has one GPU; listing it more than once puts
     // several contexts on it, which runs the real partition + peer-copy fan-out + per-device launch path of hg_multi_*.
     const ref = lcgImage(W, H, 21);
