@@ -35,15 +35,17 @@ static napi_value throw_hg(napi_env env, hg_ctx *ctx, const char *what, int code
 
 /* d_batch: device buffer the frames of warpInversePiecewiseBatch are produced in (kept between calls, grown as needed) */
 /* n_pts / n_tris: the mesh last set, so that point-set and matrix buffers can be checked before the C ABI reads / fills them */
-typedef struct { hg_ctx *ctx; int obj_w, obj_h; void *d_batch; size_t d_batch_cap; size_t n_pts, n_tris; } handle_t;
+/* d_imgs: device buffer of the per-frame sources of setImages() (kept, grown as needed) */
+typedef struct { hg_ctx *ctx; int obj_w, obj_h; void *d_batch; size_t d_batch_cap; size_t n_pts, n_tris; void *d_imgs; size_t d_imgs_cap; } handle_t;
 
 static void release_ctx(handle_t *h)
 {
     if (h->ctx) {
         if (h->d_batch) hg_device_free(h->ctx, h->d_batch);
+        if (h->d_imgs) hg_device_free(h->ctx, h->d_imgs);      /* (waits for the stream; the context that aliases it goes next) */
         hg_destroy(h->ctx);
     }
-    h->ctx = NULL; h->d_batch = NULL; h->d_batch_cap = 0;
+    h->ctx = NULL; h->d_batch = NULL; h->d_batch_cap = 0; h->d_imgs = NULL; h->d_imgs_cap = 0;
 }
 
 static void handle_finalize(napi_env env, void *data, void *hint)
@@ -483,6 +485,37 @@ static napi_value fn_set_image(napi_env env, napi_callback_info info)
     return NULL;
 }
 
+/* setImages(ctx, [Uint8ClampedArray, ...], w, h): one source per frame of the next batch (`warp(image_f)` per frame in the
+ * reference: setImage :290 on every call).  The images are copied into one device buffer; frame f reads image f % n. */
+static napi_value fn_set_images(napi_env env, napi_callback_info info)
+{
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    bool is_arr = false; uint32_t n = 0; int w, hh;
+    if (napi_is_array(env, a[1], &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, a[1], &n) != napi_ok || n == 0)
+        return throw_str(env, "hgwarp: setImages needs a non-empty array of image data arrays");
+    if (!get_i32(env, a[2], &w) || !get_i32(env, a[3], &hh)) return NULL;
+    if (w <= 0 || hh <= 0) return throw_str(env, "hgwarp: bad image size");
+    const size_t bytes = (size_t)w * (size_t)hh * 4, stride = (bytes + 255) & ~(size_t)255;
+    if (stride * n > h->d_imgs_cap) {
+        /* the context may still alias the old buffer: detach it first by attaching nothing harmful -- a new alias follows below */
+        if (h->d_imgs) hg_device_free(h->ctx, h->d_imgs);
+        h->d_imgs = NULL; h->d_imgs_cap = 0;
+        HG_CALL(h->ctx, "hg_device_alloc", hg_device_alloc(h->ctx, stride * n, &h->d_imgs));
+        h->d_imgs_cap = stride * n;
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        napi_value el; size_t len;
+        NAPI_OK(napi_get_element(env, a[1], k, &el));
+        uint8_t *px = (uint8_t *)get_typed(env, el, napi_uint8_clamped_array, &len, "images[k]"); if (!px) return NULL;
+        if (len < bytes) return throw_str(env, "hgwarp: an image is smaller than width*height*4");
+        HG_CALL(h->ctx, "hg_copy_to_device", hg_copy_to_device(h->ctx, (uint8_t *)h->d_imgs + stride * k, px, bytes));
+    }
+    HG_CALL(h->ctx, "hg_set_images_device", hg_set_images_device(h->ctx, h->d_imgs, w, hh, (int)n, stride));
+    return NULL;
+}
+
 static int get_geom(napi_env env, napi_value *a, hg_geom *g)
 {
     int v[4];
@@ -817,7 +850,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "create", fn_create }, { "destroy", fn_destroy }, { "deviceCount", fn_device_count },
         { "solveAffine", fn_solve_affine }, { "invertAffine", fn_invert_affine }, { "solveProjective", fn_solve_projective },
         { "transformLimits", fn_transform_limits }, { "minmaxXY", fn_minmax_xy }, { "triangulate", fn_triangulate },
-        { "setImage", fn_set_image }, { "warpInverseGeometric", fn_warp_inverse_geometric },
+        { "setImage", fn_set_image }, { "setImages", fn_set_images }, { "warpInverseGeometric", fn_warp_inverse_geometric },
         { "piecewiseSetMesh", fn_piecewise_set_mesh }, { "piecewisePrepare", fn_piecewise_prepare },
         { "warpInversePiecewise", fn_warp_inverse_piecewise }, { "getTriMap", fn_get_tri_map }, { "getMatrices", fn_get_matrices },
         { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch }, { "warpInverseGeometricBatch", fn_warp_inverse_geometric_batch },

@@ -238,7 +238,7 @@ class Homography {
      * ImageData-shaped frames, each identical to what the loop would return with applyAlwaysInverse = true.
      */
     warpBatch(dstPointSets, options = {}) {
-        if (this.transform === 'affine' || this.transform === 'projective') return this._warpBatchGeometric(dstPointSets);
+        if (this.transform === 'affine' || this.transform === 'projective') return this._warpBatchGeometric(dstPointSets, options);
         if (this.transform !== 'piecewiseaffine') throw ("hgwarp: warpBatch() needs a transform (set the source points first)");
         if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
         const F = dstPointSets.length, n = this._srcPoints.length;
@@ -255,6 +255,7 @@ class Homography {
         makeRoomFor(this._native, largest, F);
         let datas;
         if (options.devices !== undefined && options.devices !== null) {
+            if (options.images) throw ("hgwarp: warpBatch({devices, images}) is not supported: per-frame sources run on one device");
             // several GPUs of this node: device i of G warps a contiguous block of the frames (hg_multi_*: no collective on the
             // data path; the shared source is fanned out once over xGMI peer copies)
             const multi = this._multiFor(options.devices);
@@ -266,7 +267,7 @@ class Homography {
             this._native.multiSetMesh(multi, asF32(this._srcPoints), tris, this._minSrcX, this._minSrcY);
             datas = this._native.multiWarpBatch(multi, all, geoms);
         } else {
-            this._uploadImage();
+            this._uploadSources(options.images);
             this._uploadMesh();
             datas = this._native.warpInversePiecewiseBatch(this._ctx, all, geoms);
         }
@@ -279,7 +280,7 @@ class Homography {
      * re-solves inside every warp (:994) are solved on the GPU, one lane per frame, and all frames are warped in one launch.
      * Frames equal `warp(null, false, true)` of the loop; the instance ends in the state the loop would leave it in.
      */
-    _warpBatchGeometric(dstPointSets) {
+    _warpBatchGeometric(dstPointSets, options = {}) {
         if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
         const F = dstPointSets.length, per = this.transform === 'affine' ? 6 : 8;
         const from = new Float32Array(F * per), to = new Float32Array(F * per), geoms = new Int32Array(F * 4);
@@ -296,7 +297,7 @@ class Homography {
             geoms.set([xo, yo, ow, oh], f * 4);
         }
         this._lastPath = '_inverseGeometricWarp';
-        this._uploadImage();
+        this._uploadSources(options.images);
         makeRoomFor(this._native, largest, F);
         const datas = this._native.warpInverseGeometricBatch(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, from, to, geoms);
         return datas.map((d, f) => (blank.includes(f) ? makeImageData(new Uint8ClampedArray(4), 1, 1) : makeImageData(d, geoms[4 * f + 2], geoms[4 * f + 3])));
@@ -440,6 +441,19 @@ class Homography {
         if (this.staticImage && this._uploadedImage === this._image && this._uploadedCtx === ctx) return;
         this._native.setImage(ctx, this._image, this._width, this._height);
         this._uploadedImage = this._image; this._uploadedCtx = ctx;
+    }
+
+    /** Source(s) of a batch: the instance's image, or `images` (one ImageData-shaped source per frame, all of the instance's size:
+     *  the loop `warp(image_f)`; frame f reads images[f % images.length]). */
+    _uploadSources(images) {
+        if (images === undefined || images === null) return this._uploadImage();
+        if (!Array.isArray(images) || images.length === 0) throw ("hgwarp: warpBatch({images}) needs a non-empty array of ImageData-shaped sources");
+        for (const im of images) {
+            if (!im || !ArrayBuffer.isView(im.data) || im.width !== this._width || im.height !== this._height)
+                throw ("hgwarp: every image of warpBatch({images}) must be ImageData-shaped and of the size the instance was set up with");
+        }
+        this._native.setImages(this._ctx, images.map((im) => im.data), this._width, this._height);
+        this._uploadedImage = null;                              // the next single-image warp uploads again
     }
 
     _uploadMesh() {

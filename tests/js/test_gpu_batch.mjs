@@ -96,6 +96,25 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     nj2.warpBatch(nsets).forEach((b, f) => ok(b.width === nloop[f].width && sha(b.data) === sha(nloop[f].data), `normalised projective batch frame ${f} differs`));
     pj.close(); af.close(); nj.close(); nj2.close();
 }
+{   // one source per frame: warpBatch(sets, {images}) == the loop warp(image_f)
+    const ims = [lcgImage(W, H, 71), lcgImage(W, H, 72), lcgImage(W, H, 73)];
+    const vh = new Homography('piecewiseaffine');
+    vh.setSourcePoints(src, ims[0], W, H, false);
+    const loop = sets.map((d, f) => { vh.setDestinyPoints(d, false); return vh.warp(ims[f % 3], false, true); });
+    const bat = vh.warpBatch(sets, { images: ims });
+    bat.forEach((b, f) => ok(sha(b.data) === sha(loop[f].data), `per-frame sources: frame ${f} differs from warp(image_f)`));
+    vh.setDestinyPoints(sets[0], false);
+    ok(sha(vh.warp(ims[0], false, true).data) === sha(loop[0].data), 'single-image warp after an images batch uploads its image again');
+    const pv = new Homography('projective');
+    pv.setSourcePoints([[0, 0], [0, H], [W, 0], [W, H]], ims[0], W, H, false);
+    const ps = [[[20, 0], [20, H], [W, 40], [W, H - 40]], [[0, 10], [30, H], [W - 20, 0], [W, H - 10]]];
+    const pl = ps.map((d, f) => { pv.setDestinyPoints(d, false); return pv.warp(ims[f + 1], false, true); });
+    pv.warpBatch(ps, { images: [ims[1], ims[2]] }).forEach((b, f) => ok(sha(b.data) === sha(pl[f].data), `projective per-frame sources: frame ${f} differs`));
+    let bad = false;
+    try { vh.warpBatch(sets, { images: [lcgImage(W + 1, H, 1)] }); } catch (e) { bad = typeof e === 'string'; }
+    ok(bad, 'an image of another size must be refused');
+    vh.close(); pv.close();
+}
 {   // several GPUs behind one host thread: warpBatch(sets, {devices}).  This box has one GPU; listing it more than once puts
     // several contexts on it, which runs the real partition + peer-copy fan-out + per-device launch path of hg_multi_*.
     const ref = lcgImage(W, H, 21);
