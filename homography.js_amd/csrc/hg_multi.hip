@@ -133,9 +133,16 @@ extern "C" int hg_multi_set_image(hg_multi *m, const uint8_t *rgba, int w, int h
     const int G = (int)m->devs.size();
     for (auto &d : m->devs) {
         MHG(m, d.ctx, hg_sync(d.ctx));                       // queued warps still read the old image
-        if (bytes > d.img_cap) {                             // the ctx aliases d_img: detach before the buffer is replaced
-            if (d.d_img) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipFree(d.d_img)); d.d_img = nullptr; d.img_cap = 0; }
-            MHG(m, d.ctx, ensure_dev(m, d, d.d_img, d.img_cap, bytes));
+        if (bytes > d.img_cap) {
+            // grow: new buffer first, the context's alias moves to it, only then the old one goes (never a dangling alias,
+            // whatever fails on the way)
+            MHIP(m, hipSetDevice(d.id));
+            void *q = nullptr;
+            if (hipMalloc(&q, bytes) != hipSuccess) return mfail(m, HG_ERR_NOMEM, "hg_multi_set_image: hipMalloc failed");
+            const int rc = hg_set_image_device(d.ctx, q, w, h);
+            if (rc != HG_OK) { (void)hipFree(q); return mfail(m, rc, hg_last_error(d.ctx)); }
+            if (d.d_img) MHIP(m, hipFree(d.d_img));
+            d.d_img = static_cast<uint8_t *>(q); d.img_cap = bytes;
         }
     }
     auto &root = m->devs[0];

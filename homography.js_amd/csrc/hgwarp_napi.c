@@ -499,11 +499,13 @@ static napi_value fn_set_images(napi_env env, napi_callback_info info)
     if (w <= 0 || hh <= 0) return throw_str(env, "hgwarp: bad image size");
     const size_t bytes = (size_t)w * (size_t)hh * 4, stride = (bytes + 255) & ~(size_t)255;
     if (stride * n > h->d_imgs_cap) {
-        /* the context may still alias the old buffer: detach it first by attaching nothing harmful -- a new alias follows below */
+        /* grow: new buffer first, the context's alias moves to it, only then the old one is freed (never a dangling alias) */
+        void *q = NULL;
+        HG_CALL(h->ctx, "hg_device_alloc", hg_device_alloc(h->ctx, stride * n, &q));
+        int rc = hg_set_images_device(h->ctx, q, w, hh, (int)n, stride);
+        if (rc != HG_OK) { hg_device_free(h->ctx, q); return throw_hg(env, h->ctx, "hg_set_images_device", rc); }
         if (h->d_imgs) hg_device_free(h->ctx, h->d_imgs);
-        h->d_imgs = NULL; h->d_imgs_cap = 0;
-        HG_CALL(h->ctx, "hg_device_alloc", hg_device_alloc(h->ctx, stride * n, &h->d_imgs));
-        h->d_imgs_cap = stride * n;
+        h->d_imgs = q; h->d_imgs_cap = stride * n;
     }
     for (uint32_t k = 0; k < n; k++) {
         napi_value el; size_t len;
