@@ -243,6 +243,52 @@ static int multi_batch_impl(hg_multi *m, const float *dst_points, const hg_geom 
     return HG_OK;
 }
 
+// The same for affine / projective frames given as point sets (hg_geometric_set_frames_points: the per-frame solves run on each
+// device for its own block of frames).
+static int multi_geo_impl(hg_multi *m, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
+{
+    if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
+    if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !from || !to || !geoms || n_frames <= 0) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_geometric_batch: bad arguments");
+    if (m->W <= 0) return mfail(m, HG_ERR_STATE, "no source image: call hg_multi_set_image first");
+    const int G = (int)m->devs.size();
+    const size_t per = kind == HG_AFFINE ? 6 : 8;
+    m->geoms.assign(geoms, geoms + n_frames);
+    for (int i = 0; i < G; i++) {
+        auto &d = m->devs[i];
+        hg_multi_partition(n_frames, G, i, &d.first, &d.count);
+        d.offs.assign((size_t)std::max(d.count, 1), 0);
+        if (d.count == 0) continue;
+        size_t total = 0;
+        MHG(m, nullptr, hg_pack_offsets(geoms + d.first, d.count, d.offs.data(), &total));
+        MHG(m, d.ctx, ensure_dev(m, d, d.d_out, d.out_cap, std::max<size_t>(total, 256)));
+        MHG(m, d.ctx, hg_geometric_set_frames_points(d.ctx, kind, from + (size_t)d.first * per, to + (size_t)d.first * per, geoms + d.first, d.offs.data(), d.count));
+        MHG(m, d.ctx, hg_warp_inverse_geometric_frames_device(d.ctx, d.d_out));
+    }
+    if (out_host) {
+        for (auto &d : m->devs)
+            for (int k = 0; k < d.count; k++) {
+                const hg_geom &g = geoms[d.first + k];
+                const size_t bytes = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h * 4 : 0;
+                if (!bytes) continue;
+                if (!out_host[d.first + k]) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_geometric_batch: out_host[f] is NULL");
+                MHG(m, d.ctx, hg_copy_to_host_async(d.ctx, out_host[d.first + k], d.d_out + d.offs[k], bytes));
+            }
+    }
+    for (auto &d : m->devs) if (d.count) MHG(m, d.ctx, hg_sync(d.ctx));
+    return HG_OK;
+}
+
+extern "C" int hg_multi_warp_geometric_batch(hg_multi *m, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
+{
+    const int rc = multi_geo_impl(m, kind, from, to, geoms, n_frames, out_host);
+    if (rc != HG_OK && m) {
+        const std::string why = m->err;
+        for (auto &d : m->devs) if (d.ctx) (void)hg_sync(d.ctx);
+        m->err = why; g_merr = why;
+    }
+    return rc;
+}
+
 extern "C" int hg_multi_frame(hg_multi *m, int frame, int *device_index, void **d_ptr, size_t *bytes)
 {
     if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");

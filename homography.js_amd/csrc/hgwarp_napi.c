@@ -845,6 +845,39 @@ static napi_value fn_multi_warp_batch(napi_env env, napi_callback_info info)
     return arr;
 }
 
+static napi_value fn_multi_warp_geometric_batch(napi_env env, napi_callback_info info)
+{
+    napi_value a[5];
+    if (!get_args(env, info, 5, a)) return NULL;
+    mhandle_t *h = get_mhandle(env, a[0]); if (!h) return NULL;
+    int kind; size_t nf, nt, ng;
+    if (!get_i32(env, a[1], &kind)) return NULL;
+    if (kind != HG_AFFINE && kind != HG_PROJECTIVE) return throw_str(env, "hgwarp: kind must be 0 (affine) or 1 (projective)");
+    float *from = (float *)get_typed(env, a[2], napi_float32_array, &nf, "fromPoints"); if (!from) return NULL;
+    float *to = (float *)get_typed(env, a[3], napi_float32_array, &nt, "toPoints"); if (!to) return NULL;
+    int32_t *gv = (int32_t *)get_typed(env, a[4], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
+    const int F = (int)(ng / 4);
+    const size_t per = kind == HG_AFFINE ? 6 : 8;
+    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
+    if (nf < (size_t)F * per || nt < (size_t)F * per) return throw_str(env, "hgwarp: point sets must hold frames x points x,y pairs");
+    napi_value arr;
+    NAPI_OK(napi_create_array_with_length(env, F, &arr));
+    uint8_t **outs = (uint8_t **)calloc((size_t)F, sizeof *outs);
+    uint8_t dummy = 0;
+    for (int f = 0; f < F; f++) {
+        const hg_geom *g = (const hg_geom *)gv + f;
+        const size_t px = (g->obj_w > 0 && g->obj_h > 0) ? (size_t)g->obj_w * g->obj_h : 0;
+        void *out = NULL; napi_value ta = make_pixels(env, px * 4, NULL, 0, &out);
+        if (!ta) { free(outs); return NULL; }
+        outs[f] = px ? (uint8_t *)out : &dummy;
+        napi_set_element(env, arr, f, ta);
+    }
+    int rc = hg_multi_warp_geometric_batch(h->m, kind, from, to, (const hg_geom *)gv, F, outs);
+    free(outs);
+    if (rc != HG_OK) return throw_multi(env, h->m, "hg_multi_warp_geometric_batch", rc);
+    return arr;
+}
+
 /* ---------------------------------------------------------------- module */
 static napi_value init(napi_env env, napi_value exports)
 {
@@ -859,7 +892,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "warpForwardGeometric", fn_warp_forward_geometric }, { "warpForwardPiecewise", fn_warp_forward_piecewise },
         { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },
         { "multiCreate", fn_multi_create }, { "multiDestroy", fn_multi_destroy }, { "multiSetImage", fn_multi_set_image },
-        { "multiSetMesh", fn_multi_set_mesh }, { "multiWarpBatch", fn_multi_warp_batch },
+        { "multiSetMesh", fn_multi_set_mesh }, { "multiWarpBatch", fn_multi_warp_batch }, { "multiWarpGeometricBatch", fn_multi_warp_geometric_batch },
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -297,9 +297,21 @@ class Homography {
             geoms.set([xo, yo, ow, oh], f * 4);
         }
         this._lastPath = '_inverseGeometricWarp';
-        this._uploadSources(options.images);
         makeRoomFor(this._native, largest, F);
-        const datas = this._native.warpInverseGeometricBatch(this._ctx, this.transform === 'affine' ? AFFINE : PROJECTIVE, from, to, geoms);
+        const kind = this.transform === 'affine' ? AFFINE : PROJECTIVE;
+        let datas;
+        if (options.devices !== undefined && options.devices !== null) {                              // frames spread over several GPUs
+            if (options.images) throw ("hgwarp: warpBatch({devices, images}) is not supported: per-frame sources run on one device");
+            const multi = this._multiFor(options.devices);
+            if (!(this.staticImage && this._multiImage === this._image)) {
+                this._native.multiSetImage(multi, this._image, this._width, this._height);
+                this._multiImage = this._image;
+            }
+            datas = this._native.multiWarpGeometricBatch(multi, kind, from, to, geoms);
+        } else {
+            this._uploadSources(options.images);
+            datas = this._native.warpInverseGeometricBatch(this._ctx, kind, from, to, geoms);
+        }
         return datas.map((d, f) => (blank.includes(f) ? makeImageData(new Uint8ClampedArray(4), 1, 1) : makeImageData(d, geoms[4 * f + 2], geoms[4 * f + 3])));
     }
 

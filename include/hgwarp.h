@@ -221,6 +221,10 @@ int hg_multi_piecewise_set_mesh(hg_multi *multi, const float *src_points, int n_
 /* dst_points = n_frames x n_points x,y; out_host = NULL (frames stay on their devices: hg_multi_frame) or n_frames host
  * pointers of 4*obj_w*obj_h bytes each (pinned memory from hg_host_alloc lets the devices' copies overlap).  Synchronous. */
 int hg_multi_warp_piecewise_batch(hg_multi *multi, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host);
+/* The same for affine / projective frames given as point sets (see hg_geometric_set_frames_points): the matrix of frame f maps
+ * from[f] -> to[f] (3 or 4 points each) and is solved on the device that warps the frame. */
+int hg_multi_warp_geometric_batch(hg_multi *multi, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames,
+                                  uint8_t *const *out_host);
 /* Where frame f of the last batch lives: index into the device list, device pointer, byte size (any of them may be NULL). */
 int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, size_t *bytes);
 

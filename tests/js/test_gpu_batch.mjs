@@ -79,6 +79,7 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     const bat = pj.warpBatch(psets);
     ok(bat.length === 6, 'projective batch length');
     bat.forEach((b, f) => ok(b.width === loop[f].width && b.height === loop[f].height && sha(b.data) === sha(loop[f].data), `projective batch frame ${f} differs from the loop`));
+    for (const devices of [[0], [0, 0, 0]]) pj.warpBatch(psets, { devices }).forEach((b, f) => ok(sha(b.data) === sha(loop[f].data), `projective multi [${devices}] frame ${f} differs`));
     const af = new Homography('affine');
     af.setSourcePoints([[0, 0], [0, 270], [480, 0]], im, 480, 270, false);
     const asets = [];

@@ -794,6 +794,13 @@ def test_multi_device_batch(devices):
         m.warp_piecewise_batch(np.concatenate(frames), geoms, [o.ctypes.data for o in outs])
         for f in range(F):
             assert np.array_equal(outs[f], want[f]), ("pageable", f)
+        # projective frames over the same device list, solved per device
+        s4 = WL.corners(W, H)
+        d4s = [WL.projective_dst(W, H, 0.03 * k) for k in range(5)]
+        pg = [tuple(int(v) for v in O.transform_limits(1, O.projective_from_squares(s4, d4), W, H)) for d4 in d4s]
+        m.warp_geometric_batch(1, np.concatenate(d4s), np.tile(s4, 5), pg)
+        for k in range(5):
+            assert np.array_equal(m.frame_to_host(k), O.warp_inverse_geometric(1, HG.solve_projective(d4s[k], s4), img, *pg[k])), ("projective", k)
         # fewer frames than devices (some devices idle) and an empty window among them
         few = [frames[0], frames[1]]
         fgeoms = [geoms[0], (geoms[1][0], geoms[1][1], 0, geoms[1][3])]
