@@ -20,9 +20,14 @@ def broadcast_source(img_t, rank, world, dist, src=0, verify=False):
     Nothing but the two collectives runs here (this is what bench.py times as `broadcast_ms`): when the byte count divides
     by `world` (every RGBA image whose pixel count does) the root scatters views of its own tensor and the all-gather
     lands directly in the result; `verify` (off by default) adds verify_replicas()."""
-    import torch
     if world == 1:
         return img_t
+    return scatter_allgather(img_t, rank, world, dist, src, verify)
+
+
+def scatter_allgather(img_t, rank, world, dist, src=0, verify=False):
+    """The two collectives of broadcast_source(), for any world size (world 1 included: the RCCL smoke test on a 1-GPU box)."""
+    import torch
     flat = img_t.reshape(-1)
     n = flat.numel()
     chunk = (n + world - 1) // world
