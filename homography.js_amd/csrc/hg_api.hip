@@ -88,6 +88,9 @@ struct hg_ctx {
     int32_t *d_fmap = nullptr; size_t fmap_cap = 0;            // forward (source-side) triangle map of the current mesh, kept across warps
     bool fmap_valid = false; int fmap_w = 0, fmap_h = 0;
     int32_t *d_win32 = nullptr; size_t win32_cap = 0;
+    uint8_t *d_fwd_par = nullptr; size_t fwd_par_cap = 0;      // k_fwd_tiles: FwdParam[n] then FrameDesc[n]
+    int opt_fwd_tiles = -1;                                    // forward geometric path: -1 auto, 0 scatter + gather, 1 tiles whenever admissible
+    int fwd_last_kernel = 0;                                   // 1 scatter + gather, 2 k_fwd_tiles (hg_last_kernel-style tap for the tests)
     int16_t *d_map16 = nullptr; size_t map16_cap = 0;
     uint8_t *d_out_tmp = nullptr; size_t out_tmp_cap = 0;
 
@@ -187,7 +190,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
     void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent,
-                     c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_map16, c->d_out_tmp };
+                     c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -265,6 +268,7 @@ extern "C" int hg_copy_to_device(hg_ctx *c, void *dst, const void *src, size_t b
 }
 
 extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kernel : 0; }
+extern "C" int hg_last_forward_kernel(hg_ctx *c) { return c ? c->fwd_last_kernel : 0; }
 
 extern "C" long hg_redone_frames(hg_ctx *c) { return c ? c->pw_redone : 0; }
 
@@ -276,6 +280,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "patch")) c->opt_patch = value;
     else if (!std::strcmp(key, "phase")) c->opt_phase = value;
     else if (!std::strcmp(key, "geo_windows")) c->opt_geo_nw = value;
+    else if (!std::strcmp(key, "fwd_tiles")) c->opt_fwd_tiles = value;
     else return fail(c, HG_ERR_INVALID, std::string("hg_set_option: unknown key ") + key);
     return HG_OK;
 }
@@ -1086,6 +1091,62 @@ static int forward_limits(hg_ctx *c, int64_t w, int64_t h, const char *what)
     return HG_OK;
 }
 
+// Is k_fwd_tiles admissible for this frame (see the kernel: every bound below keeps the rounding error of its candidate
+// constraints under the 1/64-pixel widening, and no source pixel further than kFwdWrap columns outside the window)?
+// Fills P (matrix, inverse = adjugate / det of the 3x3 form, use_inv only when the inverse reproduces the source corners).
+static bool fwd_tile_param(int kind, const double *m, int W, int H, const FrameDesc &fd, FwdParam &P)
+{
+    if (fd.obj_w < 2 * kFwdWrap || fd.obj_h <= 0 || W <= 0 || H <= 0 || W > 65535 || H > 65535) return false;
+    const bool proj = kind == HG_PROJECTIVE;
+    for (int k = 0; k < (proj ? 8 : 6); k++) if (!std::isfinite(m[k])) return false;
+    const double lim = proj ? 1.0e4 : 1.0e6, flim = proj ? 1.0e5 : 1.0e7;
+    for (int k = 0; k < 6; k++) if (std::fabs(m[k]) > lim) return false;
+    if (proj && (std::fabs(m[6]) > 0.1 || std::fabs(m[7]) > 0.1)) return false;
+    double Hm[9];
+    if (proj) { for (int k = 0; k < 8; k++) Hm[k] = m[k]; Hm[8] = 1.0; }
+    else { Hm[0] = m[0]; Hm[1] = m[2]; Hm[2] = m[4]; Hm[3] = m[1]; Hm[4] = m[3]; Hm[5] = m[5]; Hm[6] = 0.0; Hm[7] = 0.0; Hm[8] = 1.0; }
+    double umin = INFINITY, umax = -INFINITY, cfx[4], cfy[4];
+    for (int c = 0; c < 4; c++) {
+        const double x = (c & 1) ? W - 1 : 0, y = (c & 2) ? H - 1 : 0;
+        const double den = Hm[6] * x + Hm[7] * y + Hm[8];
+        if (!(den >= 1.0e-2)) return false;                  // (linear: positive at the corners = positive on the whole image)
+        const double fx = (Hm[0] * x + Hm[1] * y + Hm[2]) / den, fy = (Hm[3] * x + Hm[4] * y + Hm[5]) / den;
+        if (!(std::fabs(fx) < flim && std::fabs(fy) < flim)) return false;
+        cfx[c] = fx; cfy[c] = fy;
+        umin = std::min(umin, fx - fd.x_off); umax = std::max(umax, fx - fd.x_off);
+    }
+    // the image of the source rectangle is the convex hull of its corner images: no rounded x further out than kFwdWrap - 2
+    if (umin < -(double)(kFwdWrap - 2) || umax > (double)fd.obj_w + (kFwdWrap - 2)) return false;
+    for (int k = 0; k < 8; k++) P.m[k] = k < (proj ? 8 : 6) ? m[k] : 0.0;
+    P.use_inv = 0; P.pad = 0;
+    const double det = Hm[0] * (Hm[4] * Hm[8] - Hm[5] * Hm[7]) - Hm[1] * (Hm[3] * Hm[8] - Hm[5] * Hm[6]) + Hm[2] * (Hm[3] * Hm[7] - Hm[4] * Hm[6]);
+    const double adj[9] = { Hm[4] * Hm[8] - Hm[5] * Hm[7], Hm[2] * Hm[7] - Hm[1] * Hm[8], Hm[1] * Hm[5] - Hm[2] * Hm[4],
+                            Hm[5] * Hm[6] - Hm[3] * Hm[8], Hm[0] * Hm[8] - Hm[2] * Hm[6], Hm[2] * Hm[3] - Hm[0] * Hm[5],
+                            Hm[3] * Hm[7] - Hm[4] * Hm[6], Hm[1] * Hm[6] - Hm[0] * Hm[7], Hm[0] * Hm[4] - Hm[1] * Hm[3] };
+    for (int k = 0; k < 9; k++) P.inv[k] = 0.0;
+    if (std::isfinite(det) && std::fabs(det) > 1.0e-12) {
+        bool ok = true;
+        for (int k = 0; k < 9; k++) { P.inv[k] = adj[k] / det; if (!std::isfinite(P.inv[k])) ok = false; }
+        for (int c = 0; c < 4 && ok; c++) {                  // the inverse has to bring the corner images back (1e-3 px), with w > 0
+            const double x = (c & 1) ? W - 1 : 0, y = (c & 2) ? H - 1 : 0;
+            const double X = P.inv[0] * cfx[c] + P.inv[1] * cfy[c] + P.inv[2], Y = P.inv[3] * cfx[c] + P.inv[4] * cfy[c] + P.inv[5];
+            const double Wd = P.inv[6] * cfx[c] + P.inv[7] * cfy[c] + P.inv[8];
+            if (!(Wd > 0.0) || !(std::fabs(X / Wd - x) < 1.0e-3) || !(std::fabs(Y / Wd - y) < 1.0e-3)) ok = false;
+        }
+        P.use_inv = ok ? 1 : 0;
+    }
+    return true;
+}
+
+extern "C" int hg_forward_tiles_admissible(int kind, const double *m, int W, int H, hg_geom geom)
+{
+    if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m) return 0;
+    FrameDesc fd; fd.x_off = geom.x_off; fd.y_off = geom.y_off; fd.obj_w = geom.obj_w; fd.obj_h = geom.obj_h; fd.out_off = 0; fd.map_off = 0;
+    FwdParam P;
+    if (!fwd_tile_param(kind, m, W, H, fd, P)) return 0;
+    return P.use_inv ? 2 : 1;
+}
+
 extern "C" int hg_warp_forward_geometric_batch_device(hg_ctx *c, int kind, const double *m, const hg_geom *geoms, const size_t *offs, int n, void *d_out)
 {
     HG_TRY(bind(c));
@@ -1098,6 +1159,43 @@ extern "C" int hg_warp_forward_geometric_batch_device(hg_ctx *c, int kind, const
     for (const FrameDesc &fd : fds) if (fd.obj_w > 0 && fd.obj_h > 0) max_px = std::max(max_px, (size_t)fd.obj_w * fd.obj_h);
     if (max_px == 0) return HG_OK;
     HG_TRY(hg_sync(c));
+    // Tile-binned gather (k_fwd_tiles, all frames in one launch) when every frame is admissible and the windows are large
+    // enough to fill the chip with tiles of a bounded candidate count; otherwise scatter + gather frame after frame.
+    if (c->opt_fwd_tiles != 0) {
+        std::vector<FwdParam> par((size_t)n);
+        bool all = true;
+        int64_t tiles = 0;
+        int mw = 0, mh = 0;
+        for (int f = 0; f < n && all; f++) {
+            if (fds[f].obj_w <= 0 || fds[f].obj_h <= 0) { std::memset(&par[f], 0, sizeof(FwdParam)); continue; }
+            all = fwd_tile_param(kind, m + 8 * (size_t)f, c->W, c->H, fds[f], par[f]);
+            const int64_t t = (int64_t)((fds[f].obj_w + kFwdTileW - 1) / kFwdTileW) * ((fds[f].obj_h + kFwdTileH - 1) / kFwdTileH);
+            if (c->opt_fwd_tiles < 0 && (int64_t)c->W * c->H > t * 32768) all = false;   // (few tiles for many source pixels: long serial candidate loops)
+            tiles += t; mw = std::max(mw, fds[f].obj_w); mh = std::max(mh, fds[f].obj_h);
+        }
+        if (all && c->opt_fwd_tiles < 0 && tiles < 160) all = false;     // (measured break-even against the three small scatter-path kernels)
+        if (all) {
+            FwdBatch batch;
+            std::memset(&batch, 0, sizeof batch);
+            if (n == 1) { batch.p0 = par[0]; batch.f0 = fds[0]; }
+            else {
+                const size_t bytes = sizeof(FwdParam) * n + sizeof(FrameDesc) * n;
+                HG_TRY(ensure(c, c->d_fwd_par, c->fwd_par_cap, bytes));
+                std::vector<uint8_t> blob(bytes);
+                std::memcpy(blob.data(), par.data(), sizeof(FwdParam) * n);
+                std::memcpy(blob.data() + sizeof(FwdParam) * n, fds.data(), sizeof(FrameDesc) * n);
+                HIP_TRY(c, hipMemcpyAsync(c->d_fwd_par, blob.data(), bytes, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream)); // caller / local memory is not retained
+                batch.params = reinterpret_cast<const FwdParam *>(c->d_fwd_par);
+                batch.frames = reinterpret_cast<const FrameDesc *>(c->d_fwd_par + sizeof(FwdParam) * n);
+            }
+            launch_fwd_tiles(kind, batch, n, mw, mh, c->d_img, c->W, c->H, static_cast<uint8_t *>(d_out), c->stream);
+            HIP_TRY(c, hipGetLastError());
+            c->fwd_last_kernel = 2;
+            return HG_OK;
+        }
+    }
+    c->fwd_last_kernel = 1;
     HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)8 * n));
     HG_TRY(ensure(c, c->d_win32, c->win32_cap, max_px));
     HIP_TRY(c, hipMemcpyAsync(c->d_mats, m, sizeof(double) * 8 * n, hipMemcpyHostToDevice, c->stream));

@@ -126,6 +126,14 @@ void launch_solve_frames(int kind, const float *from, const float *to, const Fra
 unsigned long long run_selftest_division(uint64_t seed, uint64_t samples, unsigned long long *d_counter, hipStream_t stream);
 
 // Forward (scatter) paths, SURVEY.md §8f-1: winner buffer `win` = obj_w*obj_h int32 scratch.
+// Tile-binned forward warp (k_fwd_tiles): per frame the forward matrix (8 doubles, affine in m[0..5]), the adjugate of its 3x3
+// form (any positive multiple of the inverse; use_inv = 0 when it is not trustworthy: tiles then scan every source row).
+struct FwdParam { double m[8]; double inv[9]; int32_t use_inv, pad; };
+constexpr int kFwdTileW = 64, kFwdTileH = 64, kFwdWrap = 32;
+// params == nullptr: one frame, carried by value (p0, f0) in the kernel arguments
+struct FwdBatch { const FwdParam *params; const FrameDesc *frames; FwdParam p0; FrameDesc f0; };
+void launch_fwd_tiles(int kind, const FwdBatch &batch, int n_frames, int max_w, int max_h,
+                      const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
 void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, int H, const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);
 void launch_fwd_pw(const int32_t *fmap, const float *fwd, const uint8_t *img, int W, int H, int min_src_x, int min_src_y, int map_w, int map_h,
                    const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);

@@ -1100,6 +1100,153 @@ __global__ __launch_bounds__(256) void k_fwd_gather(const int32_t *__restrict__ 
     reinterpret_cast<uint32_t *>(out + fd.out_off)[i] = px;
 }
 
+// ------------------------------------------------------------------------------------------------ k_fwd_tiles
+// The forward warps without global atomics and without the winner buffer: one workgroup per 64 x 64 tile of OUTPUT pixels
+// gathers the source pixels that land in its tile.  The candidates are enumerated conservatively -- per source row the x
+// interval in which the transformed point can round into the tile (four constraints, each linear in x for a fixed row; the
+// tile rectangle widened by 1/64 pixel and the interval by one pixel each side), rows bounded through the inverse map of the
+// rectangle's corners -- and every candidate then runs the EXACT arithmetic of the scatter kernel (same transform order,
+// Math.round, `<< 2`, array-bounds drop) to get its flat destination index; only if that index falls in the tile does its
+// raster rank enter an atomicMax on the tile's 4096 winner words in LDS.  Last writer in raster order == largest rank, as in
+// k_fwd_scatter_geo.  Destination x just outside the window aliases into the neighbouring row of the flat array (the
+// reference does not check x): tiles near the left / right edge also enumerate those aliased rectangles (kFwdWrap columns;
+// the host only takes this path when no source pixel can land further out).  Then each cell copies its winner's pixel.
+// Traffic per frame: source once + output once (scatter path: + 4 x the winner buffer).
+template <int KIND, bool ONE>      // ONE: a single frame whose parameters travel in the kernel arguments (no upload, no sync)
+__global__ __launch_bounds__(256) void k_fwd_tiles(FwdBatch batch, const uint8_t *__restrict__ img, int W, int H, uint8_t *__restrict__ out)
+{
+    __shared__ int s_win[kFwdTileW * kFwdTileH];
+    __shared__ int s_xa[256], s_pre[256], s_wsum[4];
+    const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FrameDesc fd = ONE ? batch.f0 : batch.frames[f];
+    const int tx0 = blockIdx.x * kFwdTileW, ty0 = blockIdx.y * kFwdTileH;
+    if (tx0 >= fd.obj_w || ty0 >= fd.obj_h) return;
+    const int tx1 = min(tx0 + kFwdTileW, fd.obj_w), ty1 = min(ty0 + kFwdTileH, fd.obj_h);
+    for (int i = tid; i < kFwdTileW * kFwdTileH; i += 256) s_win[i] = -1;
+    double m[8], iv[9];
+#pragma unroll
+    for (int k = 0; k < 8; k++) m[k] = ONE ? batch.p0.m[k] : batch.params[f].m[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) iv[k] = ONE ? batch.p0.inv[k] : batch.params[f].inv[k];
+    const int use_inv = ONE ? batch.p0.use_inv : batch.params[f].use_inv;
+    const double eps = 1.0 / 64.0;
+
+#pragma unroll 1
+    for (int region = 0; region < 3; region++) {
+        // rounded, un-aliased destination coordinates (u, v) (offsets subtracted) of this region, and where they land: (u - ush, v + vsh)
+        int u0, u1, v0, v1, ush = 0, vsh = 0;
+        if (region == 0) { u0 = tx0; u1 = tx1; v0 = ty0; v1 = ty1; }
+        else if (region == 1) {                                        // u in [objW, objW + wrap) of the row above lands in columns [0, wrap)
+            if (tx0 >= kFwdWrap) continue;
+            u0 = fd.obj_w + tx0; u1 = fd.obj_w + min(tx1, kFwdWrap); v0 = ty0 - 1; v1 = ty1 - 1; ush = fd.obj_w; vsh = 1;
+        } else {                                                       // u in [-wrap, 0) of the row below lands in columns [objW - wrap, objW)
+            const int lo = max(tx0, fd.obj_w - kFwdWrap);
+            if (lo >= tx1) continue;
+            u0 = lo - fd.obj_w; u1 = tx1 - fd.obj_w; v0 = ty0 + 1; v1 = ty1 + 1; ush = -fd.obj_w; vsh = -1;
+        }
+        const double fx_lo = (double)u0 + fd.x_off - 0.5 - eps, fx_hi = (double)(u1 - 1) + fd.x_off + 0.5 + eps;
+        const double fy_lo = (double)v0 + fd.y_off - 0.5 - eps, fy_hi = (double)(v1 - 1) + fd.y_off + 0.5 + eps;
+        int ylo = 0, yhi = H - 1;
+        if (use_inv) {                                                 // source rows of the rectangle's pre-image (a convex quad)
+            double mn = INFINITY, mx = -INFINITY;
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const double fx = (c & 1) ? fx_hi : fx_lo, fy = (c & 2) ? fy_hi : fy_lo;
+                const double t3 = iv[3] * fx, t4 = iv[4] * fy, t6 = iv[6] * fx, t7 = iv[7] * fy;
+                const double Y = t3 + t4 + iv[5], Wd = t6 + t7 + iv[8];
+                const double sw = fabs(t6) + fabs(t7) + fabs(iv[8]);
+                if (!(Wd > 1e-9 * sw) || !(Wd > 1e-300)) ok = false;   // at or beyond the horizon of the inverse map (or cancelled to noise)
+                const double sy = Y / Wd;
+                // evaluation error of sy (products and sums rounded once each): must stay well inside the 2-row padding
+                if (!(4.0e-16 * (fabs(t3) + fabs(t4) + fabs(iv[5]) + fabs(sy) * sw) < 0.5 * Wd)) ok = false;
+                mn = fmin(mn, sy); mx = fmax(mx, sy);
+            }
+            if (ok && mn == mn && mx == mx) {
+                mn = floor(mn) - 2.0; mx = ceil(mx) + 2.0;
+                if (mn > (double)(H - 1) || mx < 0.0) continue;
+                ylo = mn < 0.0 ? 0 : (int)mn;
+                yhi = mx > (double)(H - 1) ? H - 1 : (int)mx;
+            }
+        }
+        // the four constraints are a_k x + b_k(y) >= 0 with a_k the same for every row: one reciprocal each (the +-1 pixel
+        // padding of the interval absorbs its last-bit difference from a division)
+        double a[4], ra[4];
+        if (KIND == 0) { a[0] = m[0]; a[1] = -m[0]; a[2] = m[1]; a[3] = -m[1]; }
+        else { a[0] = m[0] - fx_lo * m[6]; a[1] = fx_hi * m[6] - m[0]; a[2] = m[3] - fy_lo * m[6]; a[3] = fy_hi * m[6] - m[3]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) ra[k] = fabs(a[k]) < 1e-9 ? 0.0 : -1.0 / a[k];
+#pragma unroll 1
+        for (int ybase = ylo; ybase <= yhi; ybase += 256) {
+            // (A) one lane per source row: the x interval that can reach the rectangle
+            int xa = 0, len = 0;
+            const int y = ybase + tid;
+            if (y <= yhi) {
+                const double yd = (double)y;
+                double xlo = 0.0, xhi = (double)(W - 1);
+                bool empty = false;
+                double b[4];
+                if (KIND == 0) {
+                    const double cx = m[2] * yd + m[4], cy = m[3] * yd + m[5];
+                    b[0] = cx - fx_lo; b[1] = fx_hi - cx; b[2] = cy - fy_lo; b[3] = fy_hi - cy;
+                } else {                                               // num - L * den >= 0 (den > 0 on the whole source: host-checked)
+                    b[0] = (m[1] - fx_lo * m[7]) * yd + (m[2] - fx_lo);
+                    b[1] = (fx_hi * m[7] - m[1]) * yd + (fx_hi - m[2]);
+                    b[2] = (m[4] - fy_lo * m[7]) * yd + (m[5] - fy_lo);
+                    b[3] = (fy_hi * m[7] - m[4]) * yd + (fy_hi - m[5]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (ra[k] == 0.0) { if (b[k] + 1e-3 < 0.0) empty = true; }            // |a| < 1e-9: |a| x < 1e-4 over any source row
+                    else {
+                        const double x0 = b[k] * ra[k];
+                        if (a[k] > 0.0) xlo = fmax(xlo, floor(x0) - 1.0); else xhi = fmin(xhi, ceil(x0) + 1.0);
+                    }
+                }
+                if (!empty && xlo <= xhi) { xa = (int)xlo; len = (int)xhi - xa + 1; }
+            }
+            // inclusive prefix sum of the interval lengths over the 256 rows of this pass
+            int incl = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            __syncthreads();                                           // (previous pass done with s_xa / s_pre; s_win initialised)
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            int base = 0;
+#pragma unroll
+            for (int w = 0; w < 3; w++) if (w < wave) base += s_wsum[w];
+            s_xa[tid] = xa; s_pre[tid] = base + incl;
+            __syncthreads();
+            const int total = s_pre[255];
+            // (B) candidates laid out back to back over the 256 lanes; each lane walks its row pointer forward
+            int r = 0;
+#pragma unroll 1
+            for (int k = tid; k < total; k += 256) {
+                while (s_pre[r] <= k) r++;
+                const int x = s_xa[r] + (k - (r ? s_pre[r - 1] : 0));
+                const double yd = (double)(ybase + r);
+                double nx, ny;
+                if (KIND == 0) apply_affine(m, (double)x, yd, nx, ny); else apply_projective(m, (double)x, yd, nx, ny);      // :923
+                // :924-926 in the admissible range (|rounded coordinate| < 2^24: `<< 2` and the flat index are exact integers):
+                // flat = v * objW + u, i.e. cell (u - ush, v + vsh) for this region's aliasing
+                const double ur = js_round(nx - (double)fd.x_off), vr = js_round(ny - (double)fd.y_off);
+                if (!(fabs(ur) < 16777216.0 && fabs(vr) < 16777216.0)) continue;
+                const int col = (int)ur - ush, row = (int)vr + vsh;
+                if (row >= ty0 && row < ty1 && col >= tx0 && col < tx1) atomicMax(&s_win[(row - ty0) * kFwdTileW + (col - tx0)], (ybase + r) * W + x);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(img);
+    uint32_t *__restrict__ o32 = reinterpret_cast<uint32_t *>(out + fd.out_off);
+    const int cx = tid & (kFwdTileW - 1);
+    for (int cy = tid >> 6; cy < ty1 - ty0; cy += 4) {
+        if (tx0 + cx >= tx1) continue;
+        const int w = s_win[cy * kFwdTileW + cx];
+        o32[(size_t)(ty0 + cy) * fd.obj_w + tx0 + cx] = w >= 0 ? img32[w] : 0u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 
 void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream)
@@ -1296,6 +1443,20 @@ void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, in
     if (kind == 0) hipLaunchKernelGGL(k_fwd_scatter_geo<0>, grid, dim3(256), 0, stream, d_mat, W, H, fd, win);
     else           hipLaunchKernelGGL(k_fwd_scatter_geo<1>, grid, dim3(256), 0, stream, d_mat, W, H, fd, win);
     hipLaunchKernelGGL(k_fwd_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, win, img, W, H, 0, 0, 0, 1, fd, out);
+}
+
+void launch_fwd_tiles(int kind, const FwdBatch &batch, int n_frames, int max_w, int max_h,
+                      const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream)
+{
+    if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
+    const dim3 grid((max_w + kFwdTileW - 1) / kFwdTileW, (max_h + kFwdTileH - 1) / kFwdTileH, n_frames);
+    if (batch.params) {
+        if (kind == 0) hipLaunchKernelGGL((k_fwd_tiles<0, false>), grid, dim3(256), 0, stream, batch, img, W, H, out);
+        else           hipLaunchKernelGGL((k_fwd_tiles<1, false>), grid, dim3(256), 0, stream, batch, img, W, H, out);
+    } else {
+        if (kind == 0) hipLaunchKernelGGL((k_fwd_tiles<0, true>), grid, dim3(256), 0, stream, batch, img, W, H, out);
+        else           hipLaunchKernelGGL((k_fwd_tiles<1, true>), grid, dim3(256), 0, stream, batch, img, W, H, out);
+    }
 }
 
 void launch_fwd_pw(const int32_t *fmap, const float *fwd, const uint8_t *img, int W, int H, int min_src_x, int min_src_y, int map_w, int map_h,

@@ -35,7 +35,7 @@ EXPORTS = [
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
     "hg_warp_forward_geometric", "hg_warp_forward_piecewise", "hg_warp_forward_geometric_device", "hg_warp_forward_geometric_batch_device",
     "hg_warp_forward_piecewise_device", "hg_warp_forward_piecewise_batch_device",
-    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_redone_frames", "hg_set_option", "hg_selftest_division", "hg_projective_plain_range",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_set_option", "hg_selftest_division", "hg_projective_plain_range",
 ]
 
 
@@ -95,9 +95,9 @@ def lib():
         "hg_warp_inverse_piecewise_batch_device": (i, [vp, f32p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
         "hg_get_tri_map": (i, [vp, C.POINTER(C.c_int16), sz]), "hg_get_tri_map_fused": (i, [vp, C.POINTER(C.c_int16), sz]),
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
-        "hg_last_piecewise_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]),
+        "hg_last_piecewise_kernel": (i, [vp]), "hg_last_forward_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]),
         "hg_selftest_division": (i, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
-        "hg_projective_plain_range": (i, [f64p, Geom]),
+        "hg_projective_plain_range": (i, [f64p, Geom]), "hg_forward_tiles_admissible": (i, [i, f64p, i, i, Geom]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
         "hg_kernel_ms_stats": (i, [vp, f64p, C.POINTER(i)]),
         "hg_warp_forward_geometric": (i, [vp, i, f64p, Geom, u8p]),
@@ -176,6 +176,14 @@ def projective_plain_range(m, geom):
     """True if the projective kernel may use its shared-reciprocal division for this frame (host-side range proof)."""
     a = np.ascontiguousarray(m, np.float64)
     return bool(lib().hg_projective_plain_range(a.ctypes.data_as(C.POINTER(C.c_double)), Geom(*[int(v) for v in geom])))
+
+
+def forward_tiles_admissible(kind, m, w, h, geom):
+    """0 = scatter + gather, 1 = k_fwd_tiles admissible, 2 = admissible with a trusted inverse (include/hgwarp.h)."""
+    a = np.zeros(8, np.float64)
+    mm = np.ascontiguousarray(m, np.float64).ravel()
+    a[:mm.size] = mm
+    return int(lib().hg_forward_tiles_admissible(int(kind), a.ctypes.data_as(C.POINTER(C.c_double)), int(w), int(h), Geom(*[int(v) for v in geom])))
 
 
 def js_round(x):
@@ -271,6 +279,10 @@ class Context:
         ms = C.c_float(0)
         self._c(lib().hg_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def last_forward_kernel(self):
+        """1 = scatter + gather, 2 = k_fwd_tiles (see include/hgwarp.h)"""
+        return lib().hg_last_forward_kernel(self._h)
 
     def last_piecewise_kernel(self):
         """0 none, 1 k_pw_rows (4-row groups), 2 k_pw_rows (1 row), 3 k_pw_patch, 4 k_pw_fused."""

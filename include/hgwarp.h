@@ -231,6 +231,16 @@ int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, 
 /* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
  * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general). */
 int hg_last_piecewise_kernel(hg_ctx *ctx);
+/* Which kernels ran the last forward geometric warp: 0 = none yet, 1 = scatter (atomicMax on a winner buffer) + gather,
+ * 2 = k_fwd_tiles (one launch for the whole batch: output tiles gather their source pixels, winners resolved in LDS; taken
+ * when every frame's matrix passes the admissibility bounds and the windows have enough tiles; option "fwd_tiles":
+ * -1 auto (default), 0 never, 1 whenever admissible). */
+int hg_last_forward_kernel(hg_ctx *ctx);
+/* Host-side admission test of k_fwd_tiles (no GPU needed): 0 = this forward matrix (6 or 8 doubles) / source size / window
+ * goes through scatter + gather; 1 = admissible; 2 = admissible and the inverse is trusted for the per-tile source row range.
+ * Bounds: DESIGN.md §4.6 (matrix magnitudes, projective denominator >= 1e-2 at the source corners, no source pixel more than
+ * 30 columns outside the window, window at least 64 wide). */
+int hg_forward_tiles_admissible(int kind, const double *m, int W, int H, hg_geom geom);
 /* Frames the fused kernels only flagged (row lists / kernel limits exceeded, irregular spans) and hg_sync redid through the
  * materialised map, since the ctx was created (tests / profiling: a steady-state workload should show 0). */
 long hg_redone_frames(hg_ctx *ctx);

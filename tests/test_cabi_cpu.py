@@ -198,3 +198,38 @@ def test_projective_plain_range_classification():
     assert not HG.projective_plain_range([1e150, 0, 0, 0, 1, 0, 0, 0], g)
     assert not HG.projective_plain_range(ident, (1 << 28, 0, 100, 100))
     assert HG.projective_plain_range(ident, (0, 0, 0, 0))                                          # empty window: nothing to divide
+
+
+def test_forward_tile_admission_bounds():
+    """Host-side admission of the tile-binned forward kernel (hg_forward_tiles_admissible): ordinary matrices pass with a trusted
+    inverse; anything that could put a source pixel far outside the window, a projective denominator near zero, huge or
+    non-finite entries, narrow windows -> the scatter path; a singular matrix is admissible but without inverse."""
+    W, H = 640, 480
+    rot = lambda a, s=1.0, tx=0.0, ty=0.0: np.array([np.cos(a) * s, np.sin(a) * s, -np.sin(a) * s, np.cos(a) * s, tx, ty], np.float64)
+    for a, s in ((0.0, 1.0), (0.3, 0.5), (-2.0, 2.5), (np.pi / 4, 1.0)):
+        m = rot(a, s, 12.0, -7.0)
+        lim = [int(v) for v in HG.transform_limits(0, m, W, H)]
+        assert HG.forward_tiles_admissible(0, m, W, H, lim) == 2, (a, s)
+        # the window moved 100 columns to the right: source pixels land 100 columns outside on the left
+        assert HG.forward_tiles_admissible(0, m, W, H, (lim[0] + 100, lim[1], lim[2], lim[3])) == 0
+        # ... moved by 20: inside the 30-column aliasing margin
+        assert HG.forward_tiles_admissible(0, m, W, H, (lim[0] + 20, lim[1], lim[2] - 40, lim[3])) == 2
+    m = rot(0.2)
+    lim = [int(v) for v in HG.transform_limits(0, m, W, H)]
+    assert HG.forward_tiles_admissible(0, m, W, H, (lim[0], lim[1], 40, lim[3])) == 0                     # narrower than two aliasing margins
+    bad = m.copy(); bad[4] = np.nan
+    assert HG.forward_tiles_admissible(0, bad, W, H, lim) == 0
+    bad = m.copy(); bad[0] = 1e7
+    assert HG.forward_tiles_admissible(0, bad, W, H, lim) == 0
+    sing = np.array([1.0, 0.5, 2.0, 1.0, 0.0, 0.0])                                                      # rank 1: every pixel lands on one line
+    lim = [int(v) for v in HG.transform_limits(0, sing, W, H)]
+    if lim[2] >= 64 and lim[3] > 0:
+        assert HG.forward_tiles_admissible(0, sing, W, H, lim) == 1
+    p = np.array([1.0, 0.02, 3.0, -0.01, 0.9, 5.0, 1e-4, -5e-5])
+    lim = [int(v) for v in HG.transform_limits(1, p, W, H)]
+    assert HG.forward_tiles_admissible(1, p, W, H, lim) == 2
+    p2 = p.copy(); p2[6] = -1.0 / 300.0                                                                   # denominator crosses zero inside the image
+    assert HG.forward_tiles_admissible(1, p2, W, H, lim) == 0
+    p3 = p.copy(); p3[6] = 0.5
+    assert HG.forward_tiles_admissible(1, p3, W, H, lim) == 0
+    assert HG.forward_tiles_admissible(0, m, 70000, H, lim) == 0                                           # beyond the 65 535 source limit

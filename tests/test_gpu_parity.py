@@ -19,7 +19,8 @@ GOLD = G.load()
 # results must not depend on it, so every test that takes `ctx` runs under each layout policy.
 LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0}, "rows1": {"min_row_groups": 1 << 30, "patch": 0},
            "patch": {"min_row_groups": 0, "patch": 1}, "patch_global": {"min_row_groups": 0, "patch": 2},
-           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1}, "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2}}
+           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1},
+           "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))
@@ -161,6 +162,79 @@ def test_forward_scatter_matches_oracle(ctx):
         want = O.warp_forward_piecewise(fmap, fwd, img, int(ms[0]), int(ms[1]), int(ms[2]), int(ms[3]), *geom)
         ctx.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
         assert np.array_equal(ctx.warp_forward_piecewise(dp, int(ms[2]), int(ms[3]), geom), want), ("piecewise", trial)
+
+
+def test_forward_tiles_match_scatter_and_oracle():
+    """k_fwd_tiles (output tiles gather their source pixels, winners in LDS) == scatter + gather == the oracle's sequential
+    loops, over rotations, up/down scaling, shear, perspective, windows that cut the image, negative offsets and windows
+    shifted so that destination x lands just outside them (the flat-index aliasing into the neighbouring row)."""
+    rng = np.random.default_rng(2024)
+    c = HG.Context(0)
+    try:
+        took_tiles = 0
+        for trial in range(60):
+            W, H = int(rng.integers(100, 900)), int(rng.integers(80, 600))
+            img = G.lcg_image(W, H, 4000 + trial)
+            c.set_image(img)
+            kind = trial % 2
+            ang = rng.uniform(-3.2, 3.2) if trial % 3 else rng.choice([0.0, np.pi / 4, np.pi / 2, np.pi])
+            sx, sy = rng.uniform(0.25, 3.0, 2) if trial % 5 else (1.0, 1.0)
+            sh = rng.uniform(-0.6, 0.6) if trial % 4 == 0 else 0.0
+            A = np.array([[np.cos(ang) * sx, -np.sin(ang) * sy + sh], [np.sin(ang) * sx, np.cos(ang) * sy]])
+            t = rng.uniform(-300, 300, 2)
+            if kind == 0:
+                m = np.array([A[0, 0], A[1, 0], A[0, 1], A[1, 1], t[0], t[1]], np.float32).astype(np.float64)      # :1382 layout
+            else:
+                g = rng.uniform(-4e-4, 4e-4, 2) if trial % 7 else np.zeros(2)
+                m = np.array([A[0, 0], A[0, 1], t[0], A[1, 0], A[1, 1], t[1], g[0], g[1]], np.float64)
+            lim = O.transform_limits(kind, m, W, H)
+            if not np.all(np.isfinite(lim)) or not (0 < lim[2] * lim[3] < 4_000_000):
+                continue
+            lim = [int(v) for v in lim]
+            variants = [tuple(lim)]
+            if lim[2] > 140 and lim[3] > 40:
+                variants.append((lim[0] + 9, lim[1] - 3, lim[2] - 20, lim[3] + 5))         # x just outside on both sides: aliasing into neighbouring rows
+                variants.append((lim[0] + lim[2] // 4, lim[1] + lim[3] // 3, lim[2] // 2, lim[3] // 2))   # window cuts the image: falls back to scatter
+            for geom in variants:
+                want = O.warp_forward_geometric(kind, m, img, *geom)
+                c.set_option("fwd_tiles", 0)
+                a = c.warp_forward_geometric(kind, m, geom)
+                assert c.last_forward_kernel() == 1
+                c.set_option("fwd_tiles", 1)
+                b = c.warp_forward_geometric(kind, m, geom)
+                took_tiles += c.last_forward_kernel() == 2
+                assert np.array_equal(a, want), ("scatter", trial, geom)
+                assert np.array_equal(b, want), ("tiles", trial, geom, c.last_forward_kernel())
+        assert took_tiles >= 40, took_tiles
+        # full size: 4K source, the policy picks the tile kernel by itself; batch of 3 frames in one launch == scatter path
+        W, H = 3840, 2160
+        img = G.lcg_image(W, H, 1)
+        c.set_image(img)
+        mats, geoms = [], []
+        for f, (ang, s) in enumerate([(0.05, 1.0), (0.6, 0.7), (-0.3, 1.4)]):
+            m6 = np.array([np.cos(ang) * s, np.sin(ang) * s, -np.sin(ang) * s, np.cos(ang) * s, 40.0 * f, -25.0], np.float32).astype(np.float64)
+            mats.append(np.concatenate([m6, [0, 0]]))
+            geoms.append(tuple(int(v) for v in O.transform_limits(0, m6, W, H)))
+        offs, total = HG.pack_offsets(geoms)
+        d_a, d_b = c.alloc(total), c.alloc(total)
+        try:
+            c.set_option("fwd_tiles", 0)
+            c.warp_forward_geometric_batch_device(0, np.concatenate(mats), geoms, offs, d_a)
+            c.sync()
+            c.set_option("fwd_tiles", -1)
+            c.warp_forward_geometric_batch_device(0, np.concatenate(mats), geoms, offs, d_b)
+            c.sync()
+            assert c.last_forward_kernel() == 2
+            for f, g in enumerate(geoms):
+                n = g[2] * g[3] * 4
+                assert np.array_equal(c.to_host(d_a, n, offs[f]), c.to_host(d_b, n, offs[f])), f
+            g = geoms[0]
+            assert np.array_equal(c.to_host(d_b, g[2] * g[3] * 4, offs[0]).reshape(g[3], g[2], 4), O.warp_forward_geometric(0, mats[0][:6], img, *g))
+        finally:
+            c.free(d_a)
+            c.free(d_b)
+    finally:
+        c.close()
 
 
 def test_forward_scatter_batches_stay_on_the_device(ctx):
