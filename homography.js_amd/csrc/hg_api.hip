@@ -89,7 +89,17 @@ struct hg_ctx {
     bool fmap_valid = false; int fmap_w = 0, fmap_h = 0;
     int32_t *d_win32 = nullptr; size_t win32_cap = 0;
     uint8_t *d_fwd_par = nullptr; size_t fwd_par_cap = 0;      // k_fwd_tiles: FwdParam[n] then FrameDesc[n]
-    int opt_fwd_tiles = -1;                                    // forward geometric path: -1 auto, 0 scatter + gather, 1 tiles whenever admissible
+    int32_t *d_fbbox = nullptr; size_t fbbox_cap = 0;          // forward piecewise tiles: per-matrix cell bbox of the forward map (valid with it)
+    uint32_t *d_frowoff = nullptr; size_t frowoff_cap = 0;     // ... offset of its per-row extents
+    int32_t *d_frowext = nullptr; size_t frowext_cap = 0;      // ... {min mx, max mx} per (matrix index, map row of its bbox)
+    bool fwd_rowext_ok = false;
+    int32_t *d_ftile_cnt = nullptr; size_t ftile_cnt_cap = 0;  // F x tiles counters, then F status words
+    int32_t *d_ftile_ent = nullptr; size_t ftile_ent_cap = 0;  // F x tiles x fwd_pw_cap entries
+    bool pw_quick_layout = false;                              // set around the forward paths' hg_piecewise_set_frames calls
+    int fwd_pw_cap = 64;                                       // entries per tile (doubles after an overflow, up to kFwdPwCapMax)
+    bool fwd_pw_tiles_disabled = false;                        // overflowed at the largest capacity once: stay with the scatter path for this mesh
+    struct FwdPending { uint8_t *out = nullptr; int n = 0; int32_t *status = nullptr; int max_src_x = 0, max_src_y = 0; } fwd_pending;
+    int opt_fwd_tiles = -1;                                    // forward paths: -1 auto, 0 scatter + gather, 1 tiles whenever admissible
     int fwd_last_kernel = 0;                                   // 1 scatter + gather, 2 k_fwd_tiles (hg_last_kernel-style tap for the tests)
     int16_t *d_map16 = nullptr; size_t map16_cap = 0;
     uint8_t *d_out_tmp = nullptr; size_t out_tmp_cap = 0;
@@ -190,7 +200,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
     void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent,
-                     c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_map16, c->d_out_tmp };
+                     c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -280,7 +290,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "patch")) c->opt_patch = value;
     else if (!std::strcmp(key, "phase")) c->opt_phase = value;
     else if (!std::strcmp(key, "geo_windows")) c->opt_geo_nw = value;
-    else if (!std::strcmp(key, "fwd_tiles")) c->opt_fwd_tiles = value;
+    else if (!std::strcmp(key, "fwd_tiles")) { c->opt_fwd_tiles = value; c->fwd_pw_tiles_disabled = false; }
     else return fail(c, HG_ERR_INVALID, std::string("hg_set_option: unknown key ") + key);
     return HG_OK;
 }
@@ -632,6 +642,7 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
     c->h_src.assign(src, src + (size_t)2 * n_pts);
     c->fmap_valid = false;
     c->have_mesh = true;
+    c->fwd_pw_tiles_disabled = false; c->fwd_pw_cap = 64;     // (learned on the previous mesh)
     c->pw_frames.clear(); c->pw_setup_done = false;
     return HG_OK;
 }
@@ -749,9 +760,9 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     int group_tris = 0, max_w = 0, cover = 0;
     int64_t total_px = 0;
     for (const FrameDesc &d : c->pw_frames) { max_w = std::max(max_w, d.obj_w); if (d.obj_w > 0 && d.obj_h > 0) total_px += (int64_t)d.obj_w * d.obj_h; }
-    if (total_px < ((int64_t)4 << 20) && (int64_t)F * c->n_tris > 4096) {
+    if (c->pw_quick_layout || (total_px < ((int64_t)4 << 20) && (int64_t)F * c->n_tris > 4096)) {
         // small frames of a dense mesh (the README's 400x400 / 23 000-triangle benchmark): walking every triangle on the host
-        // would cost more than the frame; guess the row density from the triangle count (the span lists grow if it was low)
+        // would cost more than the frame (and the forward paths, which only need the per-triangle solves, skip the walk); guess the row density from the triangle count (the span lists grow if it was low)
         cover = (int)(2.5 * std::sqrt((double)c->n_tris));
         group_tris = 1 << 30;                               // (no k_pw_patch without the real estimate)
         tri_rows = 64.0;
@@ -964,6 +975,36 @@ extern "C" int hg_sync(hg_ctx *c)
             if (c->pw_fast && c->row_cap < kRowSpanCapDense)      // denser mesh than assumed: larger lists next time
                 c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
         }
+    }
+    if (c->fwd_pending.n > 0) {
+        // tile-binned forward piecewise frames the device flagged (a triangle it could not bound, an overfull tile list):
+        // redone through scatter + gather into the same output, from the state the call left in the context
+        const hg_ctx::FwdPending fp = c->fwd_pending;
+        c->fwd_pending.n = 0;
+        std::vector<int32_t> st((size_t)fp.n);
+        HIP_TRY(c, hipMemcpy(st.data(), fp.status, sizeof(int32_t) * fp.n, hipMemcpyDeviceToHost));
+        bool overflow = false, unbounded = false, any = false;
+        const int map_w = fp.max_src_x - c->min_src_x, map_h = fp.max_src_y - c->min_src_y;
+        size_t max_px = 0;
+        for (int f = 0; f < fp.n && f < (int)c->pw_frames.size(); f++)
+            if (st[f] != 0 && c->pw_frames[f].obj_w > 0 && c->pw_frames[f].obj_h > 0) max_px = std::max(max_px, (size_t)c->pw_frames[f].obj_w * c->pw_frames[f].obj_h);
+        if (max_px) HG_TRY(ensure(c, c->d_win32, c->win32_cap, max_px));
+        for (int f = 0; f < fp.n && f < (int)c->pw_frames.size(); f++) {
+            if (st[f] == 0) continue;
+            any = true; c->pw_redone++;
+            if (st[f] & FWD_OVERFLOW) overflow = true;
+            if (st[f] & FWD_FALLBACK) unbounded = true;
+            const FrameDesc &fd = c->pw_frames[f];
+            if (fd.obj_w <= 0 || fd.obj_h <= 0) continue;
+            launch_fwd_pw(c->d_fmap, c->d_fwd + (size_t)f * c->n_tris * 6, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, map_w, map_h,
+                          fd, c->d_win32, fp.out, c->stream);
+        }
+        if (any) { HIP_TRY(c, hipGetLastError()); HIP_TRY(c, hipStreamSynchronize(c->stream)); }
+        if (overflow) {
+            if (c->fwd_pw_cap < kFwdPwCapMax) c->fwd_pw_cap = std::min(kFwdPwCapMax, c->fwd_pw_cap * 2);
+            else c->fwd_pw_tiles_disabled = true;
+        }
+        if (unbounded) c->fwd_pw_tiles_disabled = true;      // (a degenerate triangle in this mesh: do not pay for both paths again)
     }
     const int d = c->deferred;
     c->deferred = HG_OK;
@@ -1229,6 +1270,31 @@ extern "C" int hg_warp_forward_geometric(hg_ctx *c, int kind, const double *m, h
     return HG_OK;
 }
 
+// Per-row extents of every matrix index inside its bbox (k_fwd_pw_tiles' candidate bound), built once per forward map when the
+// tile path first wants them: offsets are a prefix sum of the bbox heights (host).
+static int ensure_fwd_rowext(hg_ctx *c, int map_w, int map_h)
+{
+    if (c->fwd_rowext_ok || c->n_tris <= 0) return HG_OK;
+    std::vector<int32_t> bb((size_t)4 * c->n_tris);
+    HIP_TRY(c, hipMemcpyAsync(bb.data(), c->d_fbbox, sizeof(int32_t) * bb.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> off((size_t)c->n_tris);
+    uint64_t total = 0;
+    for (int t = 0; t < c->n_tris; t++) {
+        off[t] = (uint32_t)total;
+        if (bb[4 * (size_t)t + 3] >= bb[4 * (size_t)t + 1]) total += (uint64_t)(bb[4 * (size_t)t + 3] - bb[4 * (size_t)t + 1] + 1);
+        if (total > ((uint64_t)1 << 27)) { c->fwd_pw_tiles_disabled = true; return HG_OK; }   // fill() wrap-around quirks made the boxes absurdly tall: scatter path
+    }
+    HG_TRY(ensure(c, c->d_frowoff, c->frowoff_cap, (size_t)c->n_tris));
+    HG_TRY(ensure(c, c->d_frowext, c->frowext_cap, (size_t)2 * std::max<uint64_t>(total, 1)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_frowoff, off.data(), sizeof(uint32_t) * off.size(), hipMemcpyHostToDevice, c->stream));
+    launch_fmap_rowext(c->d_fmap, map_w, map_h, c->d_fbbox, c->d_frowoff, c->d_frowext, (size_t)total, c->n_tris, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));             // (`off` is local)
+    c->fwd_rowext_ok = true;
+    return HG_OK;
+}
+
 // _piecewiseAffineWarp :948-972 for n destination point sets on the current mesh (the caller loop `setDestinyPoints(d_f); warp()`
 // when warp() takes the forward path, :421), asynchronous, frames in GPU memory.
 extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *dst_points, int max_src_x, int max_src_y, const hg_geom *geoms,
@@ -1253,11 +1319,17 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
         launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
         HG_TRY(ensure(c, c->d_fmap, c->fmap_cap, n_map));
         launch_map_build(mesh_of(c), frames_of(c), 0, c->pw_frames[0], c->d_fmap, c->stream);
+        HG_TRY(ensure(c, c->d_fbbox, c->fbbox_cap, (size_t)4 * std::max(c->n_tris, 1)));
+        launch_fmap_bbox(c->d_fmap, (int)map_w, (int)map_h, c->d_fbbox, c->n_tris, c->stream);     // (for the tile-binned frames below)
         HIP_TRY(c, hipGetLastError());
         c->fmap_valid = true; c->fmap_w = (int)map_w; c->fmap_h = (int)map_h;
+        c->fwd_rowext_ok = false;
     }
     // (B) forward matrices of every frame (:785-804) in one launch, then scatter + gather frame after frame
-    HG_TRY(hg_piecewise_set_frames(c, dst_points, geoms, offs, n));
+    c->pw_quick_layout = true;                               // (the inverse kernels' layout estimate is not needed here: no host walk over the triangles)
+    const int rc_frames = hg_piecewise_set_frames(c, dst_points, geoms, offs, n);
+    c->pw_quick_layout = false;
+    HG_TRY(rc_frames);
     c->status_ptr = c->d_status;
     HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * n, c->stream));
     launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
@@ -1265,6 +1337,37 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
     size_t max_px = 0;
     for (const FrameDesc &fd : c->pw_frames) if (fd.obj_w > 0 && fd.obj_h > 0) max_px = std::max(max_px, (size_t)fd.obj_w * fd.obj_h);
     if (max_px) {
+        // Tile-binned gather (k_fwd_pw_bins + k_fwd_pw_tiles, all frames in two launches) when the batch has enough tiles;
+        // frames the device cannot bound (flagged in their status word) are redone through scatter + gather by hg_sync.
+        int mw = 0, mh = 0;
+        int64_t tiles = 0;
+        for (const FrameDesc &fd : c->pw_frames) if (fd.obj_w > 0 && fd.obj_h > 0) {
+            mw = std::max(mw, fd.obj_w); mh = std::max(mh, fd.obj_h);
+            tiles += (int64_t)((fd.obj_w + kFwdTileW - 1) / kFwdTileW) * ((fd.obj_h + kFwdTileH - 1) / kFwdTileH);
+        }
+        const int tsx = (mw + kFwdTileW - 1) / kFwdTileW, tsy = (mh + kFwdTileH - 1) / kFwdTileH;
+        bool use_tiles = n_map > 0 && c->n_tris > 0 && !c->fwd_pw_tiles_disabled && tsy <= 65535 &&
+                         (c->opt_fwd_tiles > 0 || (c->opt_fwd_tiles < 0 && tiles >= 160 && (int64_t)n_map <= tiles * 32768 &&
+                                                   (int64_t)c->n_tris * n <= 4 * tiles));   // (dense meshes, > 4 triangles per tile: no gain measured)
+        if (use_tiles) { HG_TRY(ensure_fwd_rowext(c, (int)map_w, (int)map_h)); use_tiles = c->fwd_rowext_ok; }
+        if (use_tiles) {
+            const size_t per = (size_t)n * tsx * tsy;
+            HG_TRY(ensure(c, c->d_ftile_cnt, c->ftile_cnt_cap, per + (size_t)n));
+            HG_TRY(ensure(c, c->d_ftile_ent, c->ftile_ent_cap, per * (size_t)c->fwd_pw_cap));
+            HIP_TRY(c, hipMemsetAsync(c->d_ftile_cnt, 0, sizeof(int32_t) * (per + (size_t)n), c->stream));
+            FwdPwTiles p;
+            p.fmap = c->d_fmap; p.fwd = c->d_fwd; p.bbox = c->d_fbbox; p.frames = c->d_pw_frames; p.rowext = c->d_frowext; p.rowoff = c->d_frowoff;
+            p.tile_cnt = c->d_ftile_cnt; p.tile_ent = c->d_ftile_ent; p.status = c->d_ftile_cnt + per;
+            p.T = c->n_tris; p.min_src_x = c->min_src_x; p.min_src_y = c->min_src_y; p.map_w = (int)map_w; p.map_h = (int)map_h;
+            p.tsx = tsx; p.tsy = tsy; p.cap = c->fwd_pw_cap;
+            launch_fwd_pw_tiles(p, n, mw, mh, c->d_img, c->W, c->H, static_cast<uint8_t *>(d_out), c->stream);
+            HIP_TRY(c, hipGetLastError());
+            c->fwd_pending.out = static_cast<uint8_t *>(d_out); c->fwd_pending.n = n; c->fwd_pending.status = p.status;
+            c->fwd_pending.max_src_x = max_src_x; c->fwd_pending.max_src_y = max_src_y;
+            c->fwd_last_kernel = 2;
+            return HG_OK;
+        }
+        c->fwd_last_kernel = 1;
         HG_TRY(ensure(c, c->d_win32, c->win32_cap, max_px));
         for (int f = 0; f < n; f++)
             launch_fwd_pw(c->d_fmap, c->d_fwd + (size_t)f * c->n_tris * 6, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, (int)map_w, (int)map_h,
@@ -1288,6 +1391,7 @@ extern "C" int hg_warp_forward_piecewise(hg_ctx *c, const float *dst_points, int
     const size_t n = (size_t)geom.obj_w * geom.obj_h;
     HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, n * 4));
     HG_TRY(hg_warp_forward_piecewise_device(c, dst_points, max_src_x, max_src_y, geom, c->d_out_tmp));
+    HG_TRY(hg_sync(c));                                      // (settles a frame the tile kernels handed to the scatter path)
     HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HG_OK;

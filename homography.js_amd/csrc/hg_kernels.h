@@ -134,6 +134,22 @@ constexpr int kFwdTileW = 64, kFwdTileH = 64, kFwdWrap = 32;
 struct FwdBatch { const FwdParam *params; const FrameDesc *frames; FwdParam p0; FrameDesc f0; };
 void launch_fwd_tiles(int kind, const FwdBatch &batch, int n_frames, int max_w, int max_h,
                       const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
+// Tile-binned forward PIECEWISE warp: k_fmap_bbox (once per mesh: bounding box, in map cells, of the cells the forward
+// triangle map assigns to each matrix index), k_fwd_pw_bins (per frame and triangle: which output tiles its pixels can reach,
+// per aliasing shift k of the flat index; frames it cannot bound are flagged for the scatter path), k_fwd_pw_tiles (per tile:
+// gather the candidates of the filed (triangle, k) entries, winners in LDS).
+enum : int32_t { FWD_FALLBACK = 1, FWD_OVERFLOW = 2 };
+constexpr int kFwdPwCapMax = 256;
+struct FwdPwTiles {
+    const int32_t *fmap; const float *fwd; const int32_t *bbox; const FrameDesc *frames;
+    const int32_t *rowext;      // per (matrix index t, row of its bbox): {min mx, max mx} of its cells in that map row, at rowoff[t] + (my - bbox.cy0)
+    const uint32_t *rowoff;
+    int32_t *tile_cnt, *tile_ent, *status;
+    int32_t T, min_src_x, min_src_y, map_w, map_h, tsx, tsy, cap;
+};
+void launch_fmap_bbox(const int32_t *fmap, int map_w, int map_h, int32_t *bbox, int T, hipStream_t stream);
+void launch_fmap_rowext(const int32_t *fmap, int map_w, int map_h, const int32_t *bbox, const uint32_t *rowoff, int32_t *rowext, size_t total_rows, int T, hipStream_t stream);
+void launch_fwd_pw_tiles(const FwdPwTiles &p, int n_frames, int max_w, int max_h, const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
 void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, int H, const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);
 void launch_fwd_pw(const int32_t *fmap, const float *fwd, const uint8_t *img, int W, int H, int min_src_x, int min_src_y, int map_w, int map_h,
                    const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);

@@ -195,7 +195,8 @@ int hg_warp_forward_geometric_batch_device(hg_ctx *ctx, int kind, const double *
  * max_src_x/y = rounded source-point bbox maximum (:758); the forward triangle map :817-832 is rebuilt on the device. */
 int hg_warp_forward_piecewise(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host);
 /* Same, asynchronous into GPU memory; batch = the caller loop `setDestinyPoints(d_f); warp()` for n destination point sets
- * (dst_points = n_frames x n_points x,y) when warp() takes the forward path (:421). */
+ * (dst_points = n_frames x n_points x,y) when warp() takes the forward path (:421).  Like the inverse `_device` entry points
+ * the frames are final after hg_sync (or any hg_copy_to_host): a frame the tile-binned kernels flagged is redone there. */
 int hg_warp_forward_piecewise_device(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, void *d_out);
 int hg_warp_forward_piecewise_batch_device(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, const hg_geom *geoms,
                                            const size_t *out_offsets, int n_frames, void *d_out);
@@ -231,10 +232,11 @@ int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, 
 /* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
  * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general). */
 int hg_last_piecewise_kernel(hg_ctx *ctx);
-/* Which kernels ran the last forward geometric warp: 0 = none yet, 1 = scatter (atomicMax on a winner buffer) + gather,
- * 2 = k_fwd_tiles (one launch for the whole batch: output tiles gather their source pixels, winners resolved in LDS; taken
- * when every frame's matrix passes the admissibility bounds and the windows have enough tiles; option "fwd_tiles":
- * -1 auto (default), 0 never, 1 whenever admissible). */
+/* Which kernels ran the last forward warp: 0 = none yet, 1 = scatter (atomicMax on a winner buffer) + gather, 2 = the
+ * tile-binned gather (output tiles gather their source pixels, winners resolved in LDS, one or two launches for the whole
+ * batch): k_fwd_tiles for affine / projective matrices that pass the admissibility bounds, k_fwd_pw_bins + k_fwd_pw_tiles
+ * for piecewise meshes (frames the device cannot bound are flagged and redone through 1 by hg_sync; hg_redone_frames counts
+ * them).  Option "fwd_tiles": -1 by size and mesh density (default), 0 never, 1 whenever admissible. */
 int hg_last_forward_kernel(hg_ctx *ctx);
 /* Host-side admission test of k_fwd_tiles (no GPU needed): 0 = this forward matrix (6 or 8 doubles) / source size / window
  * goes through scatter + gather; 1 = admissible; 2 = admissible and the inverse is trusted for the per-tile source row range.

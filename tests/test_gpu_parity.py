@@ -237,6 +237,114 @@ def test_forward_tiles_match_scatter_and_oracle():
         c.close()
 
 
+def _fwd_pw_oracle(sp, dp, tris, img, geom):
+    ms = O.minmax_xy(sp)
+    mw, mh = int(ms[2] - ms[0]), int(ms[3] - ms[1])
+    fwd = O.piecewise_matrices(sp, dp, tris)
+    fmap = O.build_tri_map(sp, tris, mw, int(ms[1]), mw * mh)
+    return O.warp_forward_piecewise(fmap, fwd, img, int(ms[0]), int(ms[1]), int(ms[2]), int(ms[3]), *geom)
+
+
+def test_forward_piecewise_tiles_match_scatter_and_oracle():
+    """The tile-binned forward piecewise warp (k_fwd_pw_bins + k_fwd_pw_tiles) == scatter + gather == the oracle's sequential
+    loop: jittered / folded / shuffled meshes, source bbox off the image corner, degenerate source triangles (Inf / NaN matrices:
+    the frame is flagged on the device and redone by hg_sync), tile lists that overflow (capacity grows), 4K frames and batches."""
+    rng = np.random.default_rng(31337)
+    c = HG.Context(0)
+    try:
+        tiles_taken = 0
+        for trial in range(36):
+            W, H = int(rng.integers(120, 700)), int(rng.integers(90, 500))
+            img = G.lcg_image(W, H, 8000 + trial)
+            c.set_image(img)
+            nx, ny = int(rng.integers(1, 14)), int(rng.integers(1, 10))
+            sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+            if trial % 3 == 0:
+                sp = (sp.reshape(-1, 2) * 0.8 + [W * 0.1 - 4, H * 0.1 + 3]).astype(np.float32).ravel()      # min source x / y > 0
+            jit = rng.uniform(0, 0.45)
+            dp = ((sp.reshape(-1, 2) + rng.uniform(-jit, jit, (sp.size // 2, 2)) * [W / nx, H / ny]) * rng.uniform(0.5, 1.6, 2) + rng.uniform(-30, 40, 2))
+            if trial % 4 == 1:
+                dp[:, 1] += np.sin(dp[:, 0] * 0.21) * rng.uniform(1, 25)                                     # shear
+            if trial % 5 == 2:
+                perm = rng.permutation(tris.size // 3)
+                tris = tris.reshape(-1, 3)[perm].ravel()
+                dp[rng.integers(0, dp.shape[0])] += rng.uniform(-40, 40, 2)                                   # a fold
+            if trial % 9 == 4:                                                                                # a degenerate source triangle: Inf / NaN matrices
+                sp = sp.copy(); t0 = tris.reshape(-1, 3)[0]
+                sp[2 * t0[1]:2 * t0[1] + 2] = sp[2 * t0[0]:2 * t0[0] + 2]
+            dp = dp.astype(np.float32).ravel()
+            md = O.minmax_xy(dp)
+            geom = (int(md[0]), int(md[1]), int(md[2] - md[0]), int(md[3] - md[1]))
+            if geom[2] <= 0 or geom[3] <= 0:
+                continue
+            ms = O.minmax_xy(sp)
+            want = _fwd_pw_oracle(sp, dp, tris, img, geom)
+            c.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
+            c.set_option("fwd_tiles", 0)
+            a = c.warp_forward_piecewise(dp, int(ms[2]), int(ms[3]), geom)
+            assert c.last_forward_kernel() == 1
+            c.set_option("fwd_tiles", 1)
+            b = c.warp_forward_piecewise(dp, int(ms[2]), int(ms[3]), geom)
+            tiles_taken += c.last_forward_kernel() == 2
+            assert np.array_equal(a, want), ("scatter", trial)
+            assert np.array_equal(b, want), ("tiles", trial, nx, ny, geom)
+        assert tiles_taken >= 30, tiles_taken
+        # tile lists that overflow their capacity: 12 800 triangles on 512 x 512 (about 200 entries per tile, first capacity 64)
+        W = H = 512
+        img = G.lcg_image(W, H, 77)
+        c.set_image(img)
+        sp, tris = WL.grid_points(W, H, 80, 80), WL.grid_triangles(80, 80)
+        dp = (sp.reshape(-1, 2) * 0.9 + rng.uniform(-1.5, 1.5, (sp.size // 2, 2)) + 7).astype(np.float32).ravel()
+        md, ms = O.minmax_xy(dp), O.minmax_xy(sp)
+        geom = (int(md[0]), int(md[1]), int(md[2] - md[0]), int(md[3] - md[1]))
+        want = _fwd_pw_oracle(sp, dp, tris, img, geom)
+        c.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
+        c.set_option("fwd_tiles", 1)
+        redone0 = c.redone_frames()
+        for rep in range(4):                                     # capacity 64 -> 128 -> 256: flagged + redone until the lists fit
+            assert np.array_equal(c.warp_forward_piecewise(dp, int(ms[2]), int(ms[3]), geom), want), rep
+        assert c.redone_frames() > redone0
+        # 4K, the BASELINE mesh (200 triangles) shrunk to fit the source size (what warp() sends down the forward path): the policy
+        # picks the tile kernels by itself; a batch of 3 frames == the scatter path, frame 0 == the oracle
+        W, H = 3840, 2160
+        img = G.lcg_image(W, H, 1)
+        c.set_image(img)
+        for (gx, gy) in ((10, 10), (96, 54)):
+            sp, tris = WL.grid_points(W, H, gx, gy), WL.grid_triangles(gx, gy)
+            ms = O.minmax_xy(sp)
+            frames = [(WL.sin_grid_dst(W, H, gx, gy, 40.0 if gx == 10 else 6.0, 8 + k).reshape(-1, 2) * np.float32(0.9) + np.float32(20)).astype(np.float32).ravel() for k in range(3)]
+            geoms = [WL.piecewise_geom(d) for d in frames]
+            offs, total = HG.pack_offsets(geoms)
+            c.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
+            d_a, d_b = c.alloc(total), c.alloc(total)
+            try:
+                c.set_option("fwd_tiles", 0)
+                c.warp_forward_piecewise_batch_device(np.concatenate(frames), int(ms[2]), int(ms[3]), geoms, offs, d_a)
+                c.sync()
+                c.set_option("fwd_tiles", -1)
+                redone0 = c.redone_frames()
+                c.warp_forward_piecewise_batch_device(np.concatenate(frames), int(ms[2]), int(ms[3]), geoms, offs, d_b)
+                c.sync()
+                # (the policy keeps meshes with more than ~4 triangles per output tile on the scatter path)
+                assert c.last_forward_kernel() == (2 if gx == 10 else 1) and c.redone_frames() == redone0, (gx, c.last_forward_kernel(), c.redone_frames() - redone0)
+                if gx != 10:
+                    c.set_option("fwd_tiles", 1)
+                    c.warp_forward_piecewise_batch_device(np.concatenate(frames), int(ms[2]), int(ms[3]), geoms, offs, d_b)
+                    c.sync()
+                    assert c.last_forward_kernel() == 2 and c.redone_frames() == redone0
+                for f, g in enumerate(geoms):
+                    nb = g[2] * g[3] * 4
+                    assert np.array_equal(c.to_host(d_a, nb, offs[f]), c.to_host(d_b, nb, offs[f])), (gx, f)
+                if gx == 10:
+                    g = geoms[0]
+                    assert np.array_equal(c.to_host(d_b, g[2] * g[3] * 4, offs[0]).reshape(g[3], g[2], 4), _fwd_pw_oracle(sp, frames[0], tris, img, g))
+            finally:
+                c.free(d_a)
+                c.free(d_b)
+    finally:
+        c.close()
+
+
 def test_forward_scatter_batches_stay_on_the_device(ctx):
     """The forward (scatter) paths as asynchronous batches into GPU memory: F frames back to back == the synchronous
     single-frame calls == the oracle's sequential loops (last writer in raster order)."""

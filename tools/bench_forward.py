@@ -49,3 +49,37 @@ for name, (kind, ang, s, g) in cases.items():
         else: res["same_bytes"] = bool(np.array_equal(ref, out))
     ctx.free(d)
     print(json.dumps(res), flush=True)
+
+# piecewise forward: the BASELINE C3 mesh (10 x 10 cells) and a dense one, shrunk to fit the source size
+for name, (gx, gy, A) in {"piecewise 10x10 grid": (10, 10, 40.0), "piecewise 32x18 grid": (32, 18, 16.0), "piecewise 48x27 grid": (48, 27, 10.0),
+                          "piecewise 96x54 grid": (96, 54, 6.0)}.items():
+    sp, tris = wl.grid_points(W, H, gx, gy), wl.grid_triangles(gx, gy)
+    msx, msy = wl.src_min(sp)
+    mm = hg.minmax_xy(sp)
+    frames = [(wl.sin_grid_dst(W, H, gx, gy, A, 8 + k % 4).reshape(-1, 2) * np.float32(0.9) + np.float32(20)).astype(np.float32).ravel() for k in range(F)]
+    geoms = [wl.piecewise_geom(d) for d in frames]
+    offs, total = hg.pack_offsets(geoms)
+    ctx.piecewise_set_mesh(sp, tris, msx, msy)
+    d = ctx.alloc(total)
+    px = sum(gm[2] * gm[3] for gm in geoms)
+    res = {"case": name, "frames": F, "source": f"{W}x{H}", "out_Mpx_per_frame": round(px / F / 1e6, 2)}
+    ref = None
+    for mode, label in ((0, "scatter_gather"), (1, "tiles")):
+        ctx.set_option("fwd_tiles", mode)
+        for _ in range(3):
+            ctx.warp_forward_piecewise_batch_device(np.concatenate(frames), int(mm[2]), int(mm[3]), geoms, offs, d)
+        ctx.sync()
+        r0 = ctx.redone_frames()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.warp_forward_piecewise_batch_device(np.concatenate(frames), int(mm[2]), int(mm[3]), geoms, offs, d)
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        res[label + "_us_per_frame"] = round(dt / F * 1e6, 1)
+        res[label + "_kernel"] = ctx.last_forward_kernel()
+        res[label + "_redone"] = ctx.redone_frames() - r0
+        out = ctx.to_host(d, total)
+        if ref is None: ref = out
+        else: res["same_bytes"] = bool(np.array_equal(ref, out))
+    ctx.free(d)
+    print(json.dumps(res), flush=True)
