@@ -454,7 +454,10 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     // triangle point at); threads t0, t0 + step, ... of the caller's thread set do the copying
     auto load_row = [&](int row, int cnt, int base, int nan_slot, int t0, int step) {
         const double y = (double)(r0 + row + fd.y_off);
-        const size_t e0 = ((size_t)f * rl.row_stride + r0 + row) * rl.cap;
+        // (ABL & 1, timing experiment only: the entries of one of 8 fixed groups of this XCD's band in frame 0 -- always L2-resident --
+        //  with this row's own count: what the prologue would cost if the lists were cache hits)
+        const size_t e0 = (ABL & 1) ? ((size_t)(xcd * groups_per_xcd + ((bi - f * groups_per_xcd) & 7)) * rows_per_group + row) * rl.cap
+                                    : ((size_t)f * rl.row_stride + r0 + row) * rl.cap;
         for (int i = t0; i < cnt; i += step) {
             uint32_t lh, id;
             double m0, m1, m2, m3, m4, m5;
@@ -1571,6 +1574,7 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     // (`make experiments` -> lib/libhgwarp_exp.so); the shipped library has neither the instantiations nor the switch.
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;
     switch (abl) {
+    case 1: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 1, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
     case 2: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 2, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
     case 4: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 4, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;
     case 6: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, 6, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return;

@@ -48,6 +48,6 @@ if __name__ == "__main__":
     else:
         config = sys.argv[1] if len(sys.argv) > 1 else "C3"; sources = sys.argv[2] if len(sys.argv) > 2 else "distinct"
         F = {"C5": 8}.get(config, 64)
-        for abl in (0, 2, 4, 6, 8, 14):
+        for abl in ([int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else (0, 2, 4, 6, 8, 14)):
             p = subprocess.run([sys.executable, __file__, config, sources, "--one", str(F)], env=dict(os.environ, HG_ABLATE=str(abl)), capture_output=True, text=True, timeout=300)
             print(config, sources, p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:])
