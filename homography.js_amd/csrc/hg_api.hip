@@ -244,7 +244,7 @@ extern "C" int hg_copy_to_host_async(hg_ctx *c, void *dst, const void *src, size
 {
     HG_TRY(bind(c));
     if (!dst || !src) return fail(c, HG_ERR_INVALID, "NULL pointer");
-    if (!c->pw_pending_out.empty()) HG_TRY(hg_sync(c));
+    if (!c->pw_pending_out.empty() || c->fwd_pending.n > 0) HG_TRY(hg_sync(c));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     return HG_OK;
 }
