@@ -327,6 +327,22 @@ if (FULL) {
     add({ name: 'C4_orbit_4k', images: { a: { w: c4.W, h: c4.H, seed: 1 } }, triangles: c4.triangles, shaOnly: true, orbitFrames: c4.frames, script });
 }
 
+// ================================================================= 5c. full-size FORWARD cases: what warp() dispatches to when the output is not larger
+// than the source (:421 piecewise, :427 affine with an output of exactly the source size).  Appended after 5b (no blobs: shaOnly).
+if (FULL) {
+    // affine, half turn about the image centre: the corners map onto the same w x h box -> _geometricWarp
+    for (const [name, W, Hh] of [['fwd_affine_1080p', 1920, 1080], ['fwd_affine_4k', 3840, 2160]])
+        add({ name, images: { a: { w: W, h: Hh, seed: 21 } }, shaOnly: true,
+              script: [['new', 'affine'], ['setSourcePoints', [[0, 0], [0, Hh], [W, 0]], 'a', W, Hh, false], ['setDestinyPoints', [[W, Hh], [W, 0], [0, Hh]], false], ['warp']] });
+    // piecewise: the sinusoidal grid shrunk so that its bounding box stays inside the source size and above 1 / 1.2 of it -> _piecewiseAffineWarp
+    for (const [name, W, Hh, nx, ny, A] of [['fwd_piecewise_1080p', 1920, 1080, 10, 10, 20], ['fwd_piecewise_4k', 3840, 2160, 10, 10, 40], ['fwd_piecewise_4k_dense', 3840, 2160, 32, 18, 16]]) {
+        const c = cfgSinGrid(W, Hh, nx, ny, A, 8);
+        const dst = c.dst.map(([x, y]) => [x * 0.95 + 7, y * 0.9 + 5]);
+        add({ name, images: { a: { w: W, h: Hh, seed: 22 } }, triangles: c.tri, shaOnly: true,
+              script: [['new', 'piecewiseaffine'], ['setSourcePoints', c.src, 'a', W, Hh, false], ['setDestinyPoints', dst, false], ['warp']] });
+    }
+}
+
 // ================================================================= 6. per-function vectors
 const func = { affine: [], inv_affine: [], projective: [], round: [], fill: [], limits: [], minmax: [] };
 {

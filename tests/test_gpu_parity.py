@@ -94,6 +94,23 @@ def test_hip_matches_reference_golden(ctx, name, k):
             assert G.sha256(inv) == w["invSha"]
 
 
+@pytest.mark.parametrize("name", [c["name"] for c in GOLD["cases"] if c["name"].startswith("fwd_")])
+def test_full_size_forward_goldens_take_the_tile_kernels(name):
+    """The reference's own forward warps at 1080p / 4K (tests/golden 5c): under the default policy they run the tile-binned
+    kernels, forced off they run scatter + gather -- both give the reference's SHA-256."""
+    case = next(c for c in GOLD["cases"] if c["name"] == name)
+    c = HG.Context(0)
+    try:
+        for opt, kernel in ((-1, 2), (0, 1)):
+            c.set_option("fwd_tiles", opt)
+            r0 = c.redone_frames()
+            out = hip_run_warp(c, case, 0)
+            assert c.last_forward_kernel() == kernel and c.redone_frames() == r0, (name, opt, c.last_forward_kernel())
+            assert G.sha256(out) == case["warps"][0]["out"]["sha"], (name, opt)
+    finally:
+        c.close()
+
+
 def test_hip_matches_oracle_on_fresh_seeds(ctx):
     """Same seeded inputs through oracle and HIP at sizes the oracle finishes in well under a second."""
     rng = np.random.default_rng(1234)
