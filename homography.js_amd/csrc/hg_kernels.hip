@@ -974,7 +974,10 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
 {
     const FrameDesc fd = frames[blockIdx.z];
     const uint8_t *__restrict__ img = n_imgs > 1 ? img0 + (uint64_t)(blockIdx.z % n_imgs) * img_stride : img0;
-    const int r = blockIdx.y * 4 + threadIdx.y;            // one wave per row of the block
+    // one wave per row of the block.  threadIdx.y is the same in all 64 lanes of a wave, but the compiler cannot know: made scalar
+    // explicitly, or the row's output descriptor counts as divergent and every buffer_store below is wrapped in a waterfall
+    // loop (v_readfirstlane x 4, two 64-bit compares, exec save / restore per store: a sixth of the kernel's instructions)
+    const int r = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
     const int lane = threadIdx.x;
     const int cb = blockIdx.x * (256 * NW);                // this wave's NW consecutive 256-pixel windows of the row
     const int OW = fd.obj_w;
