@@ -357,6 +357,21 @@ __device__ __forceinline__ void round_x8(double h[8], double r[8])
         : "s"(M));
 }
 
+// The same for two doubles (the forward tile kernels): a, b become RTN(v + 0.5); ia, ib = Math.round(v) as int32, valid while |v| < 2^31.
+__device__ __forceinline__ void round_x2(double &a, double &b, int &ia, int &ib)
+{
+    const double M = 6755399441055744.0;
+    double ra, rb;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %0, 0.5\n\t" "v_add_f64 %1, %1, 0.5\n\t"
+        "v_add_f64 %2, %0, %4\n\t"  "v_add_f64 %3, %1, %4\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "+v"(a), "+v"(b), "=&v"(ra), "=&v"(rb)
+        : "s"(M));
+    ia = __double2loint(ra); ib = __double2loint(rb);
+}
+
 // best[k] = max(best[k], key) for the pixels k = 0..3 (at d + 64k relative to the span start) that lie inside the span,
 // i.e. (unsigned)(d + 64k) < len.  Two VALU instructions per pixel: the compare writes EXEC directly (v_cmpx) and the
 // max runs under it; a compare + select + max sequence (what the compiler emits) needs three.  All 64 lanes are active
@@ -1235,9 +1250,11 @@ __global__ __launch_bounds__(256) void k_fwd_tiles(FwdBatch batch, const uint8_t
                 if (KIND == 0) apply_affine(m, (double)x, yd, nx, ny); else apply_projective(m, (double)x, yd, nx, ny);      // :923
                 // :924-926 in the admissible range (|rounded coordinate| < 2^24: `<< 2` and the flat index are exact integers):
                 // flat = v * objW + u, i.e. cell (u - ush, v + vsh) for this region's aliasing
-                const double ur = js_round(nx - (double)fd.x_off), vr = js_round(ny - (double)fd.y_off);
-                if (!(fabs(ur) < 16777216.0 && fabs(vr) < 16777216.0)) continue;
-                const int col = (int)ur - ush, row = (int)vr + vsh;
+                double uh = nx - (double)fd.x_off, vh = ny - (double)fd.y_off;                    // :924: Math.round(newX - xOffset) ...
+                int ui, vi;
+                round_x2(uh, vh, ui, vi);                                                         // ... exactly, through two round-down adds each
+                if (!(fabs(uh) < 16777216.0 && fabs(vh) < 16777216.0)) continue;
+                const int col = ui - ush, row = vi + vsh;
                 if (row >= ty0 && row < ty1 && col >= tx0 && col < tx1) atomicMax(&s_win[(row - ty0) * kFwdTileW + (col - tx0)], (ybase + r) * W + x);
             }
         }
@@ -1484,9 +1501,11 @@ __global__ __launch_bounds__(256) void k_fwd_pw_tiles(FwdPwTiles p, const uint8_
             const double m[6] = { s_m[e][0], s_m[e][1], s_m[e][2], s_m[e][3], s_m[e][4], s_m[e][5] };
             double nx, ny;
             apply_affine(m, (double)x, (double)y, nx, ny);                                  // :961
-            const double ur = js_round(nx - (double)fd.x_off), vr = js_round(ny - (double)fd.y_off);       // :962
-            if (!(fabs(ur) < 1.0e9 && fabs(vr) < 1.0e9)) continue;
-            const int col = (int)ur - k * fd.obj_w, row = (int)vr + k;
+            double uh = nx - (double)fd.x_off, vh = ny - (double)fd.y_off;                               // :962
+            int ui, vi;
+            round_x2(uh, vh, ui, vi);
+            if (!(fabs(uh) < 1.0e9 && fabs(vh) < 1.0e9)) continue;
+            const int col = ui - k * fd.obj_w, row = vi + k;
             if (row >= ty0 && row < ty1 && col >= tx0 && col < tx1) atomicMax(&s_win[(row - ty0) * kFwdTileW + (col - tx0)], (int)cell);
         }
     }
