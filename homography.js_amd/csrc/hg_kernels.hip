@@ -357,6 +357,19 @@ __device__ __forceinline__ void round_x8(double h[8], double r[8])
         : "s"(M));
 }
 
+// The same for four doubles (two pixels): see STEP in k_pw_rows.
+__device__ __forceinline__ void round_x4(double h[4], double r[4])
+{
+    const double M = 6755399441055744.0;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %0, 0.5\n\t" "v_add_f64 %1, %1, 0.5\n\t" "v_add_f64 %2, %2, 0.5\n\t" "v_add_f64 %3, %3, 0.5\n\t"
+        "v_add_f64 %4, %0, %8\n\t"  "v_add_f64 %5, %1, %8\n\t"  "v_add_f64 %6, %2, %8\n\t"  "v_add_f64 %7, %3, %8\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "s"(M));
+}
+
 // The same for two doubles (the forward tile kernels): a, b become RTN(v + 0.5); ia, ib = Math.round(v) as int32, valid while |v| < 2^31.
 __device__ __forceinline__ void round_x2(double &a, double &b, int &ia, int &ib)
 {
@@ -546,27 +559,36 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
                 empty[p] = any == 0;                         // no span of this row reaches the window
                 if (empty[p]) px[p][0] = px[p][1] = px[p][2] = px[p][3] = 0u;
                 else {
-                    double h[8], rd[8];
                     const double xd0 = (double)(cq + fd.x_off);     // exact: integers far below 2^53
+                    // Pixels are transformed and rounded STEP at a time.  With 2 or 4 windows per phase two at a time: only 8 + 8
+                    // instead of 16 + 16 registers of coordinates are live at once, which brings the 2-window instantiation
+                    // from 66 to 58 VGPRs (8 waves/SIMD instead of 7; C3 -1.4 %, and the 4-window one from 78 to 66).  With one
+                    // window per phase (one source per frame) all four at once measured 2 % faster.
+                    constexpr int STEP = PH == 1 ? 4 : 2;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KMASK));
-                        const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                        // (ABL & 16, timing experiment only: the access pattern of a 16 px x 4 row lane patch instead of 64 px x 1 row)
-                        const double xd = (ABL & 16) ? (double)(c0 + (lane & 15) + 16 * k + fd.x_off) : xd0 + (double)(k * 64);
-                        // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
-                        // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
-                        h[2 * k]     = fma(m0.x, xd, m0.y) + m1.x;
-                        h[2 * k + 1] = fma(m1.y, xd, m2.x) + m2.y;
-                        if (ABL & 16) h[2 * k + 1] += (double)(lane >> 4);
-                    }
-                    round_x8(h, rd);
+                    for (int kk = 0; kk < 4; kk += STEP) {
+                        double h[2 * STEP], rd[2 * STEP];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool inb = (int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi);   // NaN fails
-                        const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
-                        const uint32_t off = inb ? o : 0xffffffffu;
-                        px[p][k] = (ABL & 2) ? off : __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0);       // outside the array -> 0
+                        for (int k = kk; k < kk + STEP; k++) {
+                            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KMASK));
+                            const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+                            // (ABL & 16, timing experiment only: the access pattern of a 16 px x 4 row lane patch instead of 64 px x 1 row)
+                            const double xd = (ABL & 16) ? (double)(c0 + (lane & 15) + 16 * k + fd.x_off) : xd0 + (double)(k * 64);
+                            // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
+                            // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
+                            h[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
+                            h[2 * (k - kk) + 1] = fma(m1.y, xd, m2.x) + m2.y;
+                            if (ABL & 16) h[2 * (k - kk) + 1] += (double)(lane >> 4);
+                        }
+                        if constexpr (STEP == 4) round_x8(h, rd); else round_x4(h, rd);
+#pragma unroll
+                        for (int k = kk; k < kk + STEP; k++) {
+                            const int q = 2 * (k - kk);
+                            const bool inb = (int)(h[q] >= bx_lo) & (int)(h[q] < bx_hi) & (int)(h[q + 1] >= by_lo) & (int)(h[q + 1] < by_hi);   // NaN fails
+                            const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[q + 1]), pitch4) + ((int)dlo(rd[q]) << 2));     // :1048-1049
+                            const uint32_t off = inb ? o : 0xffffffffu;
+                            px[p][k] = (ABL & 2) ? off : __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0);       // outside the array -> 0
+                        }
                     }
                 }
                 if (MAP) {                                  // parity tap (hg_get_tri_map_fused): a separate instantiation
@@ -1588,7 +1610,7 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     }
     if (map_out) { if (rl.compact) HG_ROWS(kRowSpanCapFast, true, 1, true); else HG_ROWS(kRowSpanCapFast, true, 1, false); return; }
     if (rl.compact) {                                        // dense rows: 8-byte entries
-        if (fr.phase == 2) HG_ROWS(kRowSpanCapFast, false, 2, true); else HG_ROWS(kRowSpanCapFast, false, 1, true);
+        if (fr.phase >= 2) HG_ROWS(kRowSpanCapFast, false, 2, true); else HG_ROWS(kRowSpanCapFast, false, 1, true);     // (no 4-window instantiation here)
         return;
     }
 #ifdef HG_EXPERIMENTS

@@ -251,7 +251,8 @@ long hg_redone_frames(hg_ctx *ctx);
  *   "min_row_groups" (default 1536): frame sets with fewer 4-row groups run one row per workgroup;
  *   "patch" (default -1 = by estimate): 0 never use k_pw_patch, 1 use it whenever the frame width allows, 2 the same in its
  *           global-record variant;
- *   "phase" (default -1 = 2 for a shared source, 1 with one source per frame): windows per k_pw_rows gather/store phase, 1, 2 or 4;
+ *   "phase" (default -1 = 2 for a shared source -- 4 when the rows carry 3 or more spans per window --, 1 with one source per frame):
+ *           windows per k_pw_rows gather/store phase, 1, 2 or 4;
  *   "geo_windows" (default 4): 256-pixel windows per wave of the affine / projective kernel, 1, 2 or 4. */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);
 /* Host-side proof obligation of that division (no GPU needed): 1 if every pixel of the window `geom` under the inverse
