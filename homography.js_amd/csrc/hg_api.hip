@@ -62,12 +62,18 @@ struct hg_ctx {
     int pw_row_group = kRowGroup;                              // output rows per k_pw_rows workgroup (4, or 1 for dense meshes)
     int pw_tri_threads = 128;                                  // k_tri_spans workgroup size
     bool pw_patch = false;                                     // dense mesh that fits k_pw_patch (4-row groups, 2-D gather patches)
+    bool pw_patch_fits = false;                                // ... the frame set is within k_pw_patch's limits (it may be preferred later: one source per frame)
+    double pw_shear = 0.0;                                     // mean |d(source row) / d(output x)| of the uploaded frames (layout heuristic)
     bool pw_patch_dense = false;                               // ... only in its global-record variant (up to 511 spans per row)
     bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
     bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
     long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
     int opt_min_row_groups = 1536, opt_patch = -1, opt_phase = -1, opt_geo_nw = 4;   // hg_set_option()
+    int xcc_log2 = 3;                                          // log2(XCCs of the device): hipDeviceAttributeNumberOfXccs at hg_create, option "xcc"
+    int opt_lds_pad = -1;                                       // KB of dynamic LDS padding per k_pw_rows workgroup (occupancy experiments)
+    int opt_sgpr_cap = -1;                                     // -1 auto (shared source), 0 never, 1 always: k_pw_rows_s80
+    int opt_hi_bounds = 1;                                     // 0: fp64 bounds compares instead of the high-dword form (hg_dev.h)
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
     struct Pending { uint8_t *out; int slot; };
@@ -180,6 +186,13 @@ static int create_common(int device_id, void *stream, bool own, hg_ctx **out)
         return fail(nullptr, HG_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + "; libhgwarp is built for gfx950 (MI355X) only");
     hg_ctx *c = new hg_ctx();
     c->device = device_id;
+    {   // XCC count of this device / partition (8 on an unpartitioned MI355X): the warp kernels map block ids to per-XCD row bands
+        // with it (speed only -- any value gives the same pixels).  Not a power of two or unknown: no banding.
+        int nx = 0;
+        if (hipDeviceGetAttribute(&nx, hipDeviceAttributeNumberOfXccs, device_id) != hipSuccess) nx = 1;
+        c->xcc_log2 = 0;
+        if (nx > 0 && (nx & (nx - 1)) == 0) while ((1 << c->xcc_log2) < nx && c->xcc_log2 < 6) c->xcc_log2++;
+    }
     if (hipSetDevice(device_id) != hipSuccess) { delete c; return fail(nullptr, HG_ERR_HIP, "hipSetDevice failed"); }
     if (own) {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, HG_ERR_HIP, "hipStreamCreate failed"); }
@@ -291,10 +304,20 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "patch")) c->opt_patch = value;
     else if (!std::strcmp(key, "phase")) c->opt_phase = value;
     else if (!std::strcmp(key, "geo_windows")) c->opt_geo_nw = value;
+    else if (!std::strcmp(key, "hi_bounds")) c->opt_hi_bounds = value != 0;
+    else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
+    else if (!std::strcmp(key, "lds_pad")) c->opt_lds_pad = std::min(std::max(value, -1), 40);
+    else if (!std::strcmp(key, "xcc")) {                      // block id -> XCD band mapping for `value` XCCs (a power of two <= 64); speed only
+        if (value < 1 || value > 64 || (value & (value - 1))) return fail(c, HG_ERR_INVALID, "hg_set_option: xcc must be a power of two in 1..64");
+        c->xcc_log2 = 0;
+        while ((1 << c->xcc_log2) < value) c->xcc_log2++;
+    }
     else if (!std::strcmp(key, "fwd_tiles")) { c->opt_fwd_tiles = value; c->fwd_pw_tiles_disabled = false; }
     else return fail(c, HG_ERR_INVALID, std::string("hg_set_option: unknown key ") + key);
     return HG_OK;
 }
+
+extern "C" int hg_xcc_count(const hg_ctx *c) { return c ? 1 << c->xcc_log2 : 0; }
 
 extern "C" int hg_set_timing(hg_ctx *c, int enabled)
 {
@@ -788,6 +811,14 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     c->pw_patch = cover > 56 && cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW &&
                   (int64_t)cover * 64 <= (int64_t)8 * max_w &&          // spans per 64-pixel bin ~ cover * 64 / width: overfull bins are slow
                   (shear >= 0.1 || (int64_t)cover * 256 >= (int64_t)6 * max_w) && !c->pw_patch_disabled;
+    // one source per frame (decided at run time, hg_set_images_device may follow): k_pw_patch whenever the frame set fits it, see patch_preferred()
+    {
+        int64_t groups = 0;
+        for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + kRowGroup - 1) / kRowGroup;
+        c->pw_patch_fits = cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW && max_w >= 256 &&
+                           (int64_t)cover * 64 <= (int64_t)8 * max_w && groups >= c->opt_min_row_groups && !c->pw_patch_disabled;
+    }
+    c->pw_shear = shear;
     // beyond that budget, up to ~480 spans per row: the same kernel without matrix records in LDS (pixels read them from global)
     c->pw_patch_dense = !c->pw_patch && cover > kPatchMaxRowSpans && cover <= kPatchMaxRowSpansDense && max_w <= kPatchMaxW &&
                         (int64_t)cover * 64 <= (int64_t)8 * max_w && !c->pw_patch_disabled;
@@ -826,11 +857,15 @@ static PwFrames frames_of(const hg_ctx *c)
     f.max_obj_h = mh;
     f.row_group = c->pw_row_group;
     f.tri_threads = c->pw_tri_threads;
-    // measured (C3 / C4, 64 frames): 2 windows per phase -4..5 % when the source is shared (cache-resident), +2..7 % when
-    // every frame streams its own source from HBM
-    // ... and 4 windows per phase when a window holds several spans (C4's face mesh: ~4.5; C3: 1.5): the longer span walk of each
-    // window then overlaps four windows' gathers instead of two (C4 0.245 -> 0.229 ms; C3 unchanged at 2)
-    f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 ? 1 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
+    // Windows per phase, measured (C3 / C4, 64 frames): shared (cache-resident) source: 2, or 4 when a window holds
+    // several spans (C4's face mesh ~4.5, C3 1.5: the longer span walk then overlaps four windows' gathers); one source per
+    // frame (HBM-bound): 4 windows per phase AND fewer, deeper waves -- 12-16 KB of idle LDS per workgroup leave 5 of them on a
+    // CU instead of 7 (round 3, same box: C3 0.934 -> 0.910 ms, C4 0.406 -> 0.371), where k_pw_patch does not take the frame set anyway.
+    f.xcc_log2 = c->xcc_log2; f.no_hi_bounds = c->opt_hi_bounds ? 0 : 1;
+    f.sgpr_cap = c->opt_sgpr_cap >= 0 ? (c->opt_sgpr_cap != 0) : (c->n_imgs <= 1);
+    f.lds_pad_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : (c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0);
+    f.lds_pad_patch_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : 0;
+    f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
     return f;
 }
 
@@ -856,7 +891,10 @@ static bool patch_preferred(const hg_ctx *c, bool *global_records)
     int mw = 0;
     for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
     if (global_records) *global_records = force == 2 ? true : (force == 1 ? false : c->pw_patch_dense);
-    return c->pw_fast && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force >= 1 : c->pw_patch);
+    // by estimate (dense, sheared rows), and -- measured round 3 -- whenever every frame streams its own source from HBM and the
+    // set fits the kernel: its 16 x 4 gather patches and 8-byte lists beat k_pw_rows there even on sparse meshes (same box, one
+    // source per frame: C4 0.371 -> 0.330 ms, C3 step 0.973 -> 0.947)
+    return c->pw_fast && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force >= 1 : (c->pw_patch || (c->n_imgs > 1 && c->pw_patch_fits)));
 }
 
 // per-frame solves; status words are reset first.  Fast path: k_tri_spans (solves + per-row span lists);

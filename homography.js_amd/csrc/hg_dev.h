@@ -1,0 +1,211 @@
+// hg_dev.h -- device-side helpers shared by the kernel translation units (hg_k_*.hip): rounding blocks, span updates,
+// the slow-path pixel body, buffer policies, and the experiment hooks' product policy.  gfx950 only.
+// Citations are file:line into the reference's Homography.js (v1.8.0).  Design notes: DESIGN.md §4.
+#pragma once
+#include "hg_kernels.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace hg {
+
+// ------------------------------------------------------------------------------------------------ experiment hooks
+// The warp kernels call these hooks at the few places the timing ablations of DESIGN.md §6 alter.  The product translation
+// units only ever instantiate NoExperiment, whose hooks are identities; the ablation policies (which write WRONG pixels by
+// design) live in csrc/experiments/hg_ablate.h and are compiled only into lib/libhgwarp_exp.so (`make experiments`).
+struct NoExperiment {
+    // k_pw_rows
+    __device__ static __forceinline__ size_t list_base(size_t own, int, int, int, int, int, int, int) { return own; }
+    __device__ static __forceinline__ bool fake_search(int *, unsigned long long &, int, int, int) { return false; }
+    __device__ static __forceinline__ double pixel_x(double xd, int, int, int, int) { return xd; }
+    __device__ static __forceinline__ double pixel_hy(double hy, int) { return hy; }
+    __device__ static __forceinline__ uint32_t gather(__amdgpu_buffer_rsrc_t src, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0); }
+    __device__ static __forceinline__ bool skip_store(const uint32_t *) { return false; }
+    // k_tri_spans
+    __device__ static __forceinline__ int slot(int32_t *cnt, int, int64_t) { return atomicAdd(cnt, 1); }
+    static constexpr bool store_entries = true;
+};
+
+// ------------------------------------------------------------------------------------------------ bounds on the high dwords
+// The bounds tests :1047 / :1001 are made on h = RTN(s + 0.5):  a <= s < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).
+// When 0 <= a and b < 2^20, both limits are doubles >= 0.5 whose LOW dword is zero (at most 21 significant bits), and then
+// for EVERY bit pattern of h
+//        lo <= h < hi   <=>   (uint32)(hi32(h) - hi32(lo)) < hi32(hi) - hi32(lo)
+// -- non-negative doubles order like their bit patterns, and with a zero low dword of the limit the 64-bit comparison is
+// decided by the high dwords alone; patterns with the sign bit set (negative, -0, negative NaNs) have hi32(h) >= 2^31 >
+// hi32(hi) and positive NaNs / +Inf have hi32(h) >= 0x7ff00000 > hi32(hi): both fail, as the fp64 compares do.  One 32-bit
+// subtract and one 32-bit compare per coordinate instead of two fp64 compares (fp64 instructions issue at half the rate).
+struct HiBounds { uint32_t lox, rx, loy, ry; };
+__host__ __device__ __forceinline__ bool hi_bounds_ok(int64_t ax, int64_t bx, int64_t ay, int64_t by)      // limits a + 0.5, b + 0.5
+{
+    return ax >= 0 && ay >= 0 && bx < (1 << 20) && by < (1 << 20) && ax <= bx && ay <= by;
+}
+__device__ __forceinline__ HiBounds make_hi_bounds(double lox, double hix, double loy, double hiy)       // wave-uniform: kept in SGPRs
+{
+    HiBounds b;
+    b.lox = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(lox)); b.rx = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(hix)) - b.lox;
+    b.loy = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(loy)); b.ry = (uint32_t)__builtin_amdgcn_readfirstlane(__double2hiint(hiy)) - b.loy;
+    return b;
+}
+__device__ __forceinline__ bool hi_inb(const HiBounds &b, double hx, double hy)
+{
+    return (int)(((uint32_t)__double2hiint(hx) - b.lox) < b.rx) & (int)(((uint32_t)__double2hiint(hy) - b.loy) < b.ry);
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+// Math.round for a value already known to be finite and far below 2^52 (it passed the source bounds test).
+__device__ __forceinline__ int round_inbounds(double x)
+{
+    double r = floor(x);
+    if (x - r >= 0.5) r += 1.0;
+    return (int)r;
+}
+
+__device__ __forceinline__ int64_t floordiv64(int64_t n, int64_t d)   // d > 0
+{
+    int64_t q = n / d;
+    if ((n % d) < 0) --q;
+    return q;
+}
+
+// Source fetch of the pixel loops (:1005-1007 / :1049-1052): flat index ry*W + rx into the RGBA8 array; anything
+// outside the array reads `undefined` in JS and is stored as 0 in the Uint8ClampedArray.
+__device__ __forceinline__ uint32_t fetch_src(const uint32_t *__restrict__ img32, int64_t n_src_px, int W, int rx, int ry)
+{
+    const int64_t idx = (int64_t)ry * W + rx;
+    return (idx >= 0 && idx < n_src_px) ? img32[idx] : 0u;
+}
+
+// Store 4 consecutive output pixels of one row (16-byte store when the row pitch allows it).
+__device__ __forceinline__ void store_quad(uint32_t *__restrict__ orow, int cq, int W, bool vec_ok, const uint32_t px[4])
+{
+    if (vec_ok && cq + 3 < W) {
+        *reinterpret_cast<uint4 *>(orow + cq) = make_uint4(px[0], px[1], px[2], px[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (cq + k < W) orow[cq + k] = px[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ per-pixel piecewise body
+// One output pixel of _inversePiecewiseAffineWarp :1044-1053 given its resolved triangle id.
+struct MatCache { int id; double m[6]; };
+
+__device__ __forceinline__ uint32_t pw_pixel(int tid_raw, int x, double y, MatCache &mc, const float *__restrict__ invm,
+                                             const uint32_t *__restrict__ img32, int64_t n_src_px, int W, int H,
+                                             double bx0, double bx1, double by0, double by1)
+{
+    const int t16 = (int)(int16_t)tid_raw;          // Int16Array element conversion (ids >= 32768 wrap, Appendix A-Q9)
+    if (t16 < 0) return 0u;                         // :1045
+    if (t16 != mc.id) {
+        const float4 lo = *reinterpret_cast<const float4 *>(invm + (size_t)t16 * kInvStride);
+        const float2 hi = *reinterpret_cast<const float2 *>(invm + (size_t)t16 * kInvStride + 4);
+        mc.m[0] = lo.x; mc.m[1] = lo.y; mc.m[2] = lo.z; mc.m[3] = lo.w; mc.m[4] = hi.x; mc.m[5] = hi.y;
+        mc.id = t16;
+    }
+    const double xd = (double)x;
+    const double sx = (mc.m[0] * xd) + (mc.m[2] * y) + mc.m[4];      // :1383
+    const double sy = (mc.m[1] * xd) + (mc.m[3] * y) + mc.m[5];      // :1384
+    if (sx >= bx0 && sx < bx1 && sy >= by0 && sy < by1)              // :1047 (unrounded; NaN fails)
+        return fetch_src(img32, n_src_px, W, round_inbounds(sx), round_inbounds(sy));   // :1048-1052
+    return 0u;
+}
+
+__device__ __forceinline__ uint32_t dlo(double v) { return (uint32_t)__double2loint(v); }
+// a wave-uniform double moved to scalar registers (v_cmp_f64 takes it as its scalar operand): frees two VGPRs each
+__device__ __forceinline__ double sgpr_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// Output pixels are written once and never re-read by these kernels: non-temporal stores (aux bit 1 = nt) keep the
+// 34 MB-per-frame output stream from displacing the shared source image in L2 / Infinity Cache (measured -13 % kernel
+// time on C3 versus default-policy stores).
+constexpr int kStoreNT = 2;
+// k_pw_rows span key: triangle id << 14 | LDS byte offset of the span's matrix record (256 records x 48 B < 2^14), so that
+// one signed max picks the last writer AND carries the address of its matrix; ids are < 2^15 (pw_fast_ok)
+constexpr int kKeyShift = 14, kKeyOffMask = (1 << kKeyShift) - 1;
+
+// For 8 doubles, in place: h[i] = RTN(h[i] + 0.5), then r[i] = RTN(h[i] + M), M = 1.5 * 2^52, with the fp64 rounding mode
+// switched to round-toward-minus-infinity for exactly these 16 adds.  floor(h) == floor(v + 0.5 exactly) == Math.round(v)
+// for every finite double (RTN never crosses an integer upward; this also gets 0.49999999999999994 right), and it appears
+// as the low dword of r.  h itself serves the bounds test:  a <= v < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).
+// (h is an in/out operand so that the 8 inputs and the 8 h share registers: 32 VGPRs for the block instead of 48.)
+__device__ __forceinline__ void round_x8(double h[8], double r[8])
+{
+    const double M = 6755399441055744.0;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %0, 0.5\n\t"  "v_add_f64 %1, %1, 0.5\n\t"  "v_add_f64 %2, %2, 0.5\n\t"  "v_add_f64 %3, %3, 0.5\n\t"
+        "v_add_f64 %4, %4, 0.5\n\t"  "v_add_f64 %5, %5, 0.5\n\t"  "v_add_f64 %6, %6, 0.5\n\t"  "v_add_f64 %7, %7, 0.5\n\t"
+        "v_add_f64 %8, %0, %16\n\t"  "v_add_f64 %9, %1, %16\n\t"  "v_add_f64 %10, %2, %16\n\t" "v_add_f64 %11, %3, %16\n\t"
+        "v_add_f64 %12, %4, %16\n\t" "v_add_f64 %13, %5, %16\n\t" "v_add_f64 %14, %6, %16\n\t" "v_add_f64 %15, %7, %16\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]),
+          "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "s"(M));
+}
+
+// The same for four doubles (two pixels): see STEP in k_pw_rows.
+__device__ __forceinline__ void round_x4(double h[4], double r[4])
+{
+    const double M = 6755399441055744.0;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %0, 0.5\n\t" "v_add_f64 %1, %1, 0.5\n\t" "v_add_f64 %2, %2, 0.5\n\t" "v_add_f64 %3, %3, 0.5\n\t"
+        "v_add_f64 %4, %0, %8\n\t"  "v_add_f64 %5, %1, %8\n\t"  "v_add_f64 %6, %2, %8\n\t"  "v_add_f64 %7, %3, %8\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "s"(M));
+}
+
+// The same for two doubles (the forward tile kernels): a, b become RTN(v + 0.5); ia, ib = Math.round(v) as int32, valid while |v| < 2^31.
+__device__ __forceinline__ void round_x2(double &a, double &b, int &ia, int &ib)
+{
+    const double M = 6755399441055744.0;
+    double ra, rb;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %0, 0.5\n\t" "v_add_f64 %1, %1, 0.5\n\t"
+        "v_add_f64 %2, %0, %4\n\t"  "v_add_f64 %3, %1, %4\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "+v"(a), "+v"(b), "=&v"(ra), "=&v"(rb)
+        : "s"(M));
+    ia = __double2loint(ra); ib = __double2loint(rb);
+}
+
+// best[k] = max(best[k], key) for the pixels k = 0..3 (at d + 64k relative to the span start) that lie inside the span,
+// i.e. (unsigned)(d + 64k) < len.  Two VALU instructions per pixel: the compare writes EXEC directly (v_cmpx) and the
+// max runs under it; a compare + select + max sequence (what the compiler emits) needs three.  All 64 lanes are active
+// here (uniform control flow, 256-thread blocks), EXEC is restored from the saved copy after every pixel.
+template <int STRIDE = 64>
+__device__ __forceinline__ void span_max4(int best[4], int d, int len, int key)
+{
+    const int d1 = d + STRIDE, d2 = d + 2 * STRIDE, d3 = d + 3 * STRIDE;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d0], %[len]\n\t" "v_max_i32_e32 %[b0], %[b0], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d1], %[len]\n\t" "v_max_i32_e32 %[b1], %[b1], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d2], %[len]\n\t" "v_max_i32_e32 %[b2], %[b2], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d3], %[len]\n\t" "v_max_i32_e32 %[b3], %[b3], %[key]\n\t" "s_mov_b64 exec, %[sv]"
+        : [b0] "+v"(best[0]), [b1] "+v"(best[1]), [b2] "+v"(best[2]), [b3] "+v"(best[3]), [sv] "=&s"(sv)
+        : [d0] "v"(d), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [len] "v"(len), [key] "v"(key)
+        : "vcc");
+}
+
+// same, the four pixel offsets given explicitly
+__device__ __forceinline__ void span_max4d(int best[4], int d0, int d1, int d2, int d3, int len, int key)
+{
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d0], %[len]\n\t" "v_max_i32_e32 %[b0], %[b0], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d1], %[len]\n\t" "v_max_i32_e32 %[b1], %[b1], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d2], %[len]\n\t" "v_max_i32_e32 %[b2], %[b2], %[key]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_u32_e32 vcc, %[d3], %[len]\n\t" "v_max_i32_e32 %[b3], %[b3], %[key]\n\t" "s_mov_b64 exec, %[sv]"
+        : [b0] "+v"(best[0]), [b1] "+v"(best[1]), [b2] "+v"(best[2]), [b3] "+v"(best[3]), [sv] "=&s"(sv)
+        : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [len] "v"(len), [key] "v"(key)
+        : "vcc");
+}
+
+} // namespace hg

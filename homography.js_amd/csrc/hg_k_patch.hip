@@ -1,0 +1,249 @@
+// hg_k_patch.hip -- inverse piecewise-affine warp of dense / sheared meshes: k_pw_patch
+// Hand-written HIP for gfx950 (MI355X / CDNA4), wave64; fp64 coordinate math with contraction off so that nearest-neighbour
+// source selection is bit-identical to the reference's JS doubles.
+// Citations are file:line into the reference's Homography.js (v1.8.0).  Design notes: DESIGN.md §4.
+#include "hg_dev.h"
+
+namespace hg {
+
+// ------------------------------------------------------------------------------------------------ k_pw_patch (dense meshes)
+// Same contract and the same row lists as k_pw_rows, for meshes whose rows carry 64..199 spans (C5: 5 000 triangles on 8K,
+// ~145 per row).  There k_pw_rows runs one row per workgroup, and under the steep shear such meshes usually have (source y
+// moves ~1 row per output pixel) the 64 lanes of a row-contiguous gather hit 64 different 128-byte source lines.  Here a
+// workgroup owns 4 output rows and every gather instruction covers a 2-D patch, 16 pixels x 4 rows: vertically adjacent
+// output pixels read horizontally adjacent source pixels, so a patch touches ~19 lines.  What makes four dense rows fit
+// in LDS: the matrix records are stored once per TRIANGLE of the group (a triangle crossing all four rows appears in four
+// lists), found through a small hash table while the lists are loaded; m2*y, m3*y are then formed per pixel (one more
+// fp64 multiply per coordinate, rounded exactly where the reference rounds them).  The span lookup is per lane (lanes of
+// a wave sit on four different rows), through per-(row, 64-pixel column) bins of span indices built in LDS.
+// Limits (host picks the kernel from its estimate; a group that exceeds one flags the frame -> map path, and the context
+// stops using this kernel): <= 199 spans per row, <= 208 triangles per 4-row group, obj_w <= 8192.  A bin with more than
+// 8 spans is handled inside the kernel (the block tests the row's whole list).
+constexpr int kPatchRows = 4, kPatchCap = 200, kPatchRecs = 208, kPatchBins = 128, kPatchBinSlots = 8, kPatchHash = 1024, kPatchTilePitch = 68;
+// (sized so that six workgroups fit a CU's 160 KB of LDS: 26.9 KB each)
+static_assert(kPatchHash * 4 <= kPatchRows * kPatchBins * kPatchBinSlots, "the hash table lives in the bin-slot area");
+// GLOBALREC variant for very dense meshes (up to 511 spans per row: README-scale, ~23 000 triangles on 4K): no matrix
+// records in LDS at all -- a pixel reads its triangle's inverse matrix (6 floats, the tap array k_tri_spans fills, L2
+// resident) from global memory and widens it itself; the LDS then holds 4 x 512 spans (30.4 KB, five workgroups per CU).
+constexpr int kPatchCapDense = 512;
+
+template <bool GLOBALREC, bool HIB>
+__global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
+                                                  int groups_per_xcd, int32_t *__restrict__ status_next)
+{
+    constexpr int CAPR = GLOBALREC ? kPatchCapDense : kPatchCap;            // spans per row
+    using slot_t = typename std::conditional<GLOBALREC, uint16_t, uint8_t>::type;
+    const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1), bi = bid >> fr.xcc_log2;
+    const int f = bi / groups_per_xcd;
+    const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * kPatchRows;
+    const FrameDesc fd = fr.frames[f];
+    if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;   // (see k_pw_rows)
+    if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
+
+    __shared__ __align__(16) double s_rec[GLOBALREC ? 6 : (kPatchRecs + 1) * 6];   // {m0, m2, m4, m1, m3, m5} per triangle; last = NaN record
+    __shared__ uint32_t s_lohi[kPatchRows * CAPR];                          // span cells [lo, hi) of the row, 16 bits each
+    __shared__ int s_key[kPatchRows * CAPR];                                // id << 14 | byte offset of the triangle's record (GLOBALREC: the id)
+    __shared__ int s_bincnt[kPatchRows * kPatchBins];
+    __shared__ __align__(4) slot_t s_bin[kPatchRows * kPatchBins * kPatchBinSlots];   // span indices per (row, 64-px column)
+    __shared__ uint32_t s_tile[4 * kPatchRows * kPatchTilePitch];          // per wave: 4 rows x 64 pixels (+ padding against bank conflicts)
+    __shared__ int s_nrec, s_fail;
+    uint32_t *s_hash = reinterpret_cast<uint32_t *>(s_bin);                 // id << 16 | (record + 1), 0 = empty; used before the bins
+
+    const int W = fd.obj_w;
+    const int nbins = (W + 63) >> 6;
+    const int nrows = min(kPatchRows, fd.obj_h - r0);
+    int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    int cnts[kPatchRows], cmax = 0;
+#pragma unroll
+    for (int j = 0; j < kPatchRows; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
+    for (int i = threadIdx.x; i < kPatchRows * kPatchBins; i += 256) s_bincnt[i] = 0;
+    if (!GLOBALREC) for (int i = threadIdx.x; i < kPatchHash; i += 256) s_hash[i] = 0u;
+    if (threadIdx.x == 0) { s_nrec = 0; s_fail = (cmax > rl.cap || cmax > CAPR - 1 || nbins > kPatchBins) ? 1 : 0; }
+    __syncthreads();
+    if ((int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;                    // every wave has read the counters: clean for the next step
+    const bool bad0 = s_fail != 0;
+
+    // ---- phase 1: span lists -> LDS; each triangle of the group gets ONE matrix record (hash on the id: the thread that
+    // claims the bucket writes the record and publishes its index; the others remember the bucket and read it later)
+    const float *__restrict__ ginv0 = fr.inv + (size_t)f * mesh.n_tris * kInvStride;     // this frame's inverse matrices (tap array)
+    int my_bucket[(kPatchRows * CAPR + 255) / 256];
+    int n_mine = 0;
+    if (!bad0) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
+        const int rr = e / CAPR, i = e - rr * CAPR;
+        const int cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
+        int bucket = -1;
+        if (i < cnt) {
+            const uint2 a = static_cast<const uint2 *>(rl.ent)[((size_t)f * rl.row_stride + r0 + rr) * rl.cap + i];      // RowEnt8 (the host pairs this kernel with compact lists)
+            s_lohi[e] = a.x;
+            const uint32_t id = a.y;
+            if (!GLOBALREC) {
+                uint32_t hpos = (id * 2654435761u) >> 22;                   // 10 bits
+                for (int probe = 0; probe < kPatchHash; probe++, hpos = (hpos + 1) & (kPatchHash - 1)) {
+                    const uint32_t old = atomicCAS(&s_hash[hpos], 0u, (id << 16) | 0xffffu);
+                    if (old == 0u) {                                        // claimed: this thread owns the triangle's record
+                        const int rec = atomicAdd(&s_nrec, 1);
+                        if (rec < kPatchRecs) {
+                            const float4 ma = *reinterpret_cast<const float4 *>(ginv0 + (size_t)id * kInvStride);
+                            const float2 mb = *reinterpret_cast<const float2 *>(ginv0 + (size_t)id * kInvStride + 4);
+                            double2 *mrec = reinterpret_cast<double2 *>(s_rec + rec * 6);
+                            mrec[0] = make_double2((double)ma.x, (double)ma.z);    // m0, m2
+                            mrec[1] = make_double2((double)mb.x, (double)ma.y);    // m4, m1
+                            mrec[2] = make_double2((double)ma.w, (double)mb.y);    // m3, m5
+                            s_hash[hpos] = (id << 16) | (uint32_t)(rec + 1);
+                        } else s_fail = 1;
+                        bucket = (int)hpos;
+                        break;
+                    }
+                    if ((old >> 16) == id) { bucket = (int)hpos; break; }
+                }
+            }
+            s_key[e] = (int)id;
+        }
+        my_bucket[n_mine++] = bucket;
+    }
+    if (!GLOBALREC && threadIdx.x < 3) reinterpret_cast<double2 *>(s_rec + kPatchRecs * 6)[threadIdx.x] = make_double2(NAN, NAN);
+    __syncthreads();
+    // ---- phase 2: keys (id << 14 | record offset), once every record index is published
+    const bool bad1 = s_fail != 0;
+    n_mine = 0;
+    if (!GLOBALREC && !bad1) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
+        const int bucket = my_bucket[n_mine++];
+        if (bucket >= 0) s_key[e] = (s_key[e] << kKeyShift) | (int)(((s_hash[bucket] & 0xffffu) - 1u) * 48u);
+    }
+    if (!GLOBALREC) __syncthreads();
+    // ---- phase 3: the hash table is dead, its memory becomes the bins: span index -> every 64-pixel column it overlaps
+    if (!bad1) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
+        const int rr = e / CAPR, i = e - rr * CAPR;
+        const int cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
+        if (i < cnt) {
+            const uint32_t lh = s_lohi[e];
+            const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
+            for (int b = lo >> 6; b <= (hi - 1) >> 6 && b < nbins; b++) {
+                const int pos = atomicAdd(&s_bincnt[rr * kPatchBins + b], 1);          // (a count beyond the slots marks the bin as overfull)
+                if (pos < kPatchBinSlots) s_bin[(rr * kPatchBins + b) * kPatchBinSlots + pos] = (slot_t)i;
+            }
+        }
+    }
+    __syncthreads();
+    if (s_fail) {                                           // the host redoes the frame through the materialised map
+        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+        return;
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rr = lane >> 4;                               // lane = (row of the group, columns (lane & 15) + 16k of the block)
+    int ck[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ck[k] = (lane & 15) + 16 * k;
+    const double y = (double)(r0 + rr + fd.y_off);
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 0, mesh.W * mesh.H * 4, 0x00020000);
+    // output: the group's rows as one raw buffer; lanes of rows past the frame end and pixels past the row end get an
+    // offset the hardware range check drops
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r0 * W * 4, 0, nrows * W * 4, 0x00020000);
+    const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
+    const double by_lo = (double)mesh.min_src_y + 0.5, by_hi = (double)mesh.H + (double)mesh.min_src_y + 0.5;
+    const HiBounds hb = make_hi_bounds(bx_lo, bx_hi, by_lo, by_hi);      // HIB: :1047 on the high dwords of h (hg_dev.h)
+    const int pitch4 = mesh.W * 4;
+    const int nan_key = GLOBALREC ? -1 : ((int)0x80000000u | (kPatchRecs * 48));
+    const int row_base = rr * CAPR;
+    const int my_cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
+    uint32_t *tile = s_tile + wave * (kPatchRows * kPatchTilePitch);
+    const float *__restrict__ ginv = fr.inv + (size_t)f * mesh.n_tris * kInvStride;     // GLOBALREC: this frame's inverse matrices
+
+    // One 64-pixel-wide column block, all 4 rows: span lookup, coordinates, gathers issued (not waited for).
+    auto resolve_gather = [&](int cw, uint32_t px[4]) {
+        const int c0 = cw << 6;                             // pixel k of the lane: (c0 + ck[k], r0 + rr)
+        int best[4] = { nan_key, nan_key, nan_key, nan_key };
+        const int bidx = rr * kPatchBins + cw;
+        const int nb = s_bincnt[bidx];
+        const slot_t *bin = s_bin + bidx * kPatchBinSlots;
+        if (!__any(nb > kPatchBinSlots)) {
+            for (int p = 0; __any(p < nb); p++) {
+                int lo = 0, len = 0, key = 0;               // len 0: no pixel passes the span test
+                if (p < nb) {
+                    const int e = row_base + bin[p];
+                    const uint32_t lh = s_lohi[e];
+                    lo = (int)(lh & 0xffffu); len = (int)(lh >> 16) - lo; key = s_key[e];
+                }
+                const int d = c0 - lo;
+                span_max4d(best, d + ck[0], d + ck[1], d + ck[2], d + ck[3], len, key);     // larger id wins (== last writer of :852-858)
+            }
+        } else {                                            // more spans in one 64-pixel bin than it has slots (slivers): test the
+            for (int i = 0; __any(i < my_cnt); i++) {       // row's whole list for this block -- slow, exact, rare
+                int lo = 0, len = 0, key = 0;
+                if (i < my_cnt) {
+                    const uint32_t lh = s_lohi[row_base + i];
+                    lo = (int)(lh & 0xffffu); len = (int)(lh >> 16) - lo; key = s_key[row_base + i];
+                }
+                const int d = c0 - lo;
+                span_max4d(best, d + ck[0], d + ck[1], d + ck[2], d + ck[3], len, key);
+            }
+        }
+        double h[8], rd[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double m0, m1, m2, m3, m4, m5;
+            if (GLOBALREC) {                                // the triangle's f32 inverse matrix straight from the tap array
+                const float4 a = *reinterpret_cast<const float4 *>(ginv + (size_t)max(best[k], 0) * kInvStride);
+                const float2 b = *reinterpret_cast<const float2 *>(ginv + (size_t)max(best[k], 0) * kInvStride + 4);
+                const double nanq = best[k] < 0 ? NAN : 0.0;     // no triangle: every coordinate becomes NaN and fails :1047
+                m0 = a.x; m1 = a.y; m2 = a.z; m3 = a.w; m4 = (double)b.x + nanq; m5 = (double)b.y + nanq;
+            } else {
+                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_rec) + (best[k] & kKeyOffMask));
+                const double2 m02 = mrec[0], m41 = mrec[1], m35 = mrec[2];
+                m0 = m02.x; m2 = m02.y; m4 = m41.x; m1 = m41.y; m3 = m35.x; m5 = m35.y;
+            }
+            const double xd = (double)(c0 + ck[k] + fd.x_off);
+            // :1383-1384  (m0*x) + (m2*y) + m4: m2*y rounded on its own, m0*x exact in fp64 (see k_pw_rows)
+            h[2 * k]     = fma(m0, xd, m2 * y) + m4;
+            h[2 * k + 1] = fma(m1, xd, m3 * y) + m5;
+        }
+        round_x8(h, rd);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool inb = HIB ? hi_inb(hb, h[2 * k], h[2 * k + 1])
+                                 : (bool)((int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi));   // :1047 (NaN fails)
+            const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
+            px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
+        }
+    };
+    // 64 x 4 transpose through this wave's LDS tile (wave-synchronous: no barrier), so that each store instruction
+    // writes 256 contiguous bytes of ONE row instead of four 64-byte pieces (measured: 0.62 -> 0.50 ms on C5)
+    auto transpose_store = [&](int cw, const uint32_t px[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) tile[rr * kPatchTilePitch + ck[k]] = px[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int xs = (cw << 6) + lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                       // row k of the group, pixel xs: past the row / frame end -> dropped
+            const uint32_t v = tile[k * kPatchTilePitch + lane];
+            __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && k < nrows) ? (uint32_t)(k * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // This wave's column blocks cw = wave, wave + 4, ...  (Measured and dropped: two blocks per phase -- the gathers of block A
+    // in flight while block B is resolved -- 0.504 vs 0.503 ms on C5: the wait for a block's gathers is not what limits it.)
+    for (int cw = wave; cw < nbins; cw += 4) {
+        uint32_t px[4];
+        resolve_gather(cw, px);
+        transpose_store(cw, px);
+    }
+}
+
+void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream)
+{
+    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
+    const int nx = 1 << fr.xcc_log2;
+    const int gpx = ((fr.max_obj_h + kPatchRows - 1) / kPatchRows + nx - 1) / nx;
+    const dim3 grid((unsigned)gpx * (unsigned)nx * (unsigned)fr.n_frames);
+    const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
+#define HG_PATCH(G, HB) hipLaunchKernelGGL((k_pw_patch<G, HB>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, status_next)
+    if (global_records) { if (hib) HG_PATCH(true, true); else HG_PATCH(true, false); }
+    else                { if (hib) HG_PATCH(false, true); else HG_PATCH(false, false); }
+#undef HG_PATCH
+}
+
+} // namespace hg

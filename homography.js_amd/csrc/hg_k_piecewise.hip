@@ -1,0 +1,571 @@
+// hg_k_piecewise.hip -- inverse piecewise-affine warp: k_tri_setup, k_pw_fused (general), k_tri_spans + k_pw_rows (fast path)
+// Hand-written HIP for gfx950 (MI355X / CDNA4), wave64; fp64 coordinate math with contraction off so that nearest-neighbour
+// source selection is bit-identical to the reference's JS doubles.
+// Citations are file:line into the reference's Homography.js (v1.8.0).  Design notes: DESIGN.md §4.
+#include "hg_dev.h"
+
+namespace hg {
+
+// ------------------------------------------------------------------------------------------------ k_tri_setup
+// Per (frame, triangle).  Replaces _calculatePiecewiseAffineTransformMatrices :785-804, the inverseAffineMatrix loop
+// :1036-1038 and the per-triangle head of fillTriangle :1113-1118.
+__global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (t >= mesh.n_tris) return;
+    const FrameDesc fd = fr.frames[f];
+    const float *dp = fr.dst_pts + (size_t)f * mesh.n_pts * 2;
+    float s[6], d[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t v = mesh.tris[3 * (size_t)t + k];
+        if (v < (uint32_t)mesh.n_pts) {
+            s[2 * k] = mesh.src_pts[2 * (size_t)v]; s[2 * k + 1] = mesh.src_pts[2 * (size_t)v + 1];
+            d[2 * k] = dp[2 * (size_t)v];           d[2 * k + 1] = dp[2 * (size_t)v + 1];
+        } else {                                   // typed-array read past the end: undefined -> NaN in the Float32Array(6)
+            s[2 * k] = s[2 * k + 1] = d[2 * k] = d[2 * k + 1] = NAN;
+        }
+    }
+    const size_t ft = (size_t)f * mesh.n_tris + t;
+    float fwd[6], inv[6];
+    solve_affine(s, d, fwd);
+    invert_affine(fwd, inv);
+#pragma unroll
+    for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];
+    *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+    *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
+
+    Seg *sg = fr.segs + ft * 3;
+    Seg a, b, c;
+    define_seg(d[0], d[1], d[2], d[3], a);          // p0->p1
+    define_seg(d[0], d[1], d[4], d[5], b);          // p0->p2
+    define_seg(d[2], d[3], d[4], d[5], c);          // p1->p2
+    sg[0] = a; sg[1] = b; sg[2] = c;
+
+    TriRange tr;
+    tri_rows(d[1], d[3], d[5], tr.y_min, tr.y_end);
+    tr.a = 0; tr.b = 0;
+    if (tr.y_end > tr.y_min && fd.obj_w > 0 && fd.obj_h > 0) {
+        // Conservative cell extent of any span of this triangle relative to its row base (y - yOff) * W:
+        // intersections lie between the vertex x's (+-1 for rounding).  Absurd / non-finite input or a triangle wider
+        // than the whole map (TypedArray.fill wrap-around could then straddle index 0) goes to the exact map path.
+        const double x0 = d[0], x1 = d[2], x2 = d[4];
+        const bool finite = fabs(x0) < 1.0e9 && fabs(x1) < 1.0e9 && fabs(x2) < 1.0e9 &&
+                            fabs((double)d[1]) < 1.0e9 && fabs((double)d[3]) < 1.0e9 && fabs((double)d[5]) < 1.0e9;
+        bool irregular = !finite || (tr.y_end - (int64_t)tr.y_min) > (1 << 24);
+        if (!irregular) {
+            const int64_t lo = (int64_t)floor(fmin(fmin(x0, x1), x2)) - 1;
+            const int64_t hi = (int64_t)ceil(fmax(fmax(x0, x1), x2)) + 1;
+            const int64_t len = (int64_t)fd.obj_w * fd.obj_h;
+            if (hi - lo >= len) irregular = true;
+            else {
+                tr.a = (int32_t)floordiv64(hi - 1, fd.obj_w);
+                tr.b = (int32_t)floordiv64(lo, fd.obj_w);
+            }
+        }
+        if (irregular) atomicOr(&fr.status[f], FRAME_IRREGULAR);
+    }
+    fr.trir[ft] = tr;
+}
+
+// ------------------------------------------------------------------------------------------------ k_pw_fused
+// One workgroup (4 waves) per output row of one frame.
+//   phase 1: every thread scans triangles; for each (triangle, source-row y) whose fillTriangle span can touch this
+//            output row it evaluates predictXLimits + the flat fill() indices exactly and appends the clipped span
+//            [lo,hi) x id to an LDS list;
+//   phase 2: each wave walks 256-pixel windows of the row; the spans overlapping a window are found with one ballot
+//            per 64 spans, and each lane keeps max(id) over the spans covering its 4 pixels ("last writer wins" of
+//            the sequential fill loop :852-858 == largest id); then the pixel loop body :1044-1053.
+__global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint8_t *__restrict__ out, int16_t *__restrict__ map_out)
+{
+    const int f = blockIdx.y;
+    const FrameDesc fd = fr.frames[f];
+    const int r = blockIdx.x;
+    if (r >= fd.obj_h || fd.obj_w <= 0) return;
+    if (fr.status[f] & FRAME_IRREGULAR) return;      // written by k_tri_setup (previous kernel on this stream)
+
+    __shared__ int s_lo[kRowSpanCap], s_hi[kRowSpanCap], s_id[kRowSpanCap];
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+
+    const int T = mesh.n_tris, W = fd.obj_w;
+    const int64_t len = (int64_t)W * fd.obj_h;
+    const int64_t row0 = (int64_t)r * W, row1 = row0 + W;
+    const TriRange *__restrict__ trir = fr.trir + (size_t)f * T;
+    const Seg *__restrict__ segs = fr.segs + (size_t)f * T * 3;
+
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const TriRange tr = trir[t];
+        if (tr.y_end <= tr.y_min) continue;
+#pragma unroll 1
+        for (int image = 0; image < 2; image++) {    // 0: indices >= 0;  1: negative indices wrapped by +len (= +objH rows)
+            const int64_t shift = image ? fd.obj_h : 0;
+            int64_t ylo = (int64_t)r - tr.a - shift + fd.y_off, yhi = (int64_t)r - tr.b - shift + fd.y_off;
+            if (ylo < tr.y_min) ylo = tr.y_min;
+            if (yhi > (int64_t)tr.y_end - 1) yhi = (int64_t)tr.y_end - 1;
+#pragma unroll 1
+            for (int64_t y = ylo; y <= yhi; y++) {
+                int64_t k, fin;
+                span_cells(segs + 3 * (size_t)t, (double)y, (double)fd.y_off, (double)W, len, k, fin);
+                if (k < row0) k = row0;
+                if (fin > row1) fin = row1;
+                if (k < fin) {
+                    const int slot = atomicAdd(&s_cnt, 1);
+                    if (slot < kRowSpanCap) { s_lo[slot] = (int)(k - row0); s_hi[slot] = (int)(fin - row0); s_id[slot] = t; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt > kRowSpanCap) {                         // frame is redone through the materialised-map path by the host
+        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+        return;
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwin = (W + 255) >> 8;
+    const float *__restrict__ invm = fr.inv + (size_t)f * T * kInvStride;
+    const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(frame_img(mesh, f));
+    const int64_t n_src_px = (int64_t)mesh.W * mesh.H;
+    uint32_t *__restrict__ orow = reinterpret_cast<uint32_t *>(out + fd.out_off) + row0;
+    const bool vec_ok = ((W & 3) == 0) && ((fd.out_off & 15) == 0);
+    const double y = (double)(r + fd.y_off);
+    const double bx0 = (double)mesh.min_src_x, bx1 = (double)mesh.W + (double)mesh.min_src_x;    // :1047
+    const double by0 = (double)mesh.min_src_y, by1 = (double)mesh.H + (double)mesh.min_src_y;
+
+    for (int w = wave; w < nwin; w += 4) {
+        const int c0 = w << 8, cq = c0 + (lane << 2);
+        int tid[4] = { -1, -1, -1, -1 };
+        for (int j = 0; j < cnt; j += 64) {
+            const int idx = j + lane;
+            int lo = 0x7fffffff, hi = 0;
+            if (idx < cnt) { lo = s_lo[idx]; hi = s_hi[idx]; }
+            unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int sl = s_lo[j + b], id = s_id[j + b];
+                const unsigned span = (unsigned)(s_hi[j + b] - sl);
+                const int d = cq - sl;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((unsigned)(d + k) < span) tid[k] = max(tid[k], id);
+            }
+        }
+        if (cq < W) {
+            uint32_t px[4];
+            MatCache mc; mc.id = -1;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                px[k] = pw_pixel(tid[k], cq + k + fd.x_off, y, mc, invm, img32, n_src_px, mesh.W, mesh.H, bx0, bx1, by0, by1);
+            store_quad(orow, cq, W, vec_ok, px);
+            if (map_out) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (cq + k < W) map_out[fd.map_off + row0 + cq + k] = (int16_t)tid[k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fast path: k_tri_spans + k_pw_rows
+// Two kernels per batch of frames replace _calculatePiecewiseAffineTransformMatrices (:785-804),
+// _buildInverseTrianglesCorrespondencesMatrix (:845-861), the inverseAffineMatrix loop (:1036-1038) and the pixel loop
+// (:1042-1056) without ever materialising the Int16 map:
+//
+//   k_tri_spans  triangle-major, like the reference's fill loop: one workgroup per (frame, triangle) solves the
+//                triangle's forward/inverse matrices, then one thread per source row y of fillTriangle (:1120) evaluates
+//                predictXLimits + the two flat fill() indices exactly (TypedArray.fill semantics incl. negative-index
+//                wrap) and appends the covered cells, cut at output-row boundaries, to that OUTPUT row's span list
+//                {lo, hi, triangle id, inverse matrix as 6 f32} (32 bytes, global memory, atomic slot counter per row).
+//                Exact for any input; the only limit is the per-row list capacity (overflow -> frame redone via the map).
+//   k_pw_rows    one workgroup per group of 4 output rows (or per row for dense meshes): loads the rows' lists into LDS
+//                (matrix widened to f64 and specialised to the row: {m0, m2*y, m4, m1, m3*y, m5}; m2*y and m3*y are the
+//                separately rounded products of :1383-1384), then each wave walks the 256-pixel windows of its row: spans
+//                overlapping the window are found with one ballot per 64 spans and every lane keeps the LARGEST covering
+//                id per pixel (== the sequential overwrite order of :852-858), then the pixel body: 1 fma + 1 add per
+//                coordinate in fp64, Math.round and the bounds test :1047 through two round-toward-minus-infinity adds
+//                per coordinate (see round_x8), one buffer load whose hardware range check returns 0 outside the RGBA
+//                array (the JS `undefined` -> 0 case), coalesced non-temporal stores.
+// Requirements checked by pw_fast_ok(): n_tris <= 32767 (ids == their Int16 value), obj_w <= 65535, source < 2^31 bytes,
+// |min_src_x/y| < 2^22.
+
+
+template <class X, bool COMPACT>      // X: experiment hooks (hg_dev.h); the product only instantiates NoExperiment
+__global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, RowLists rl)
+{
+    const int t = blockIdx.x, f = blockIdx.y;
+    const FrameDesc fd = fr.frames[f];
+    const float *dp = fr.dst_pts + (size_t)f * mesh.n_pts * 2;
+    float s[6], d[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t v = mesh.tris[3 * (size_t)t + k];
+        if (v < (uint32_t)mesh.n_pts) {
+            s[2 * k] = mesh.src_pts[2 * (size_t)v]; s[2 * k + 1] = mesh.src_pts[2 * (size_t)v + 1];
+            d[2 * k] = dp[2 * (size_t)v];           d[2 * k + 1] = dp[2 * (size_t)v + 1];
+        } else {
+            s[2 * k] = s[2 * k + 1] = d[2 * k] = d[2 * k + 1] = NAN;
+        }
+    }
+    float fwd[6], inv[6];
+    solve_affine(s, d, fwd);                       // every thread redundantly: cheaper than a broadcast through LDS
+    invert_affine(fwd, inv);
+    Seg seg[3];
+    define_seg(d[0], d[1], d[2], d[3], seg[0]);     // p0->p1
+    define_seg(d[0], d[1], d[4], d[5], seg[1]);     // p0->p2
+    define_seg(d[2], d[3], d[4], d[5], seg[2]);     // p1->p2
+    int32_t y_min, y_end;
+    tri_rows(d[1], d[3], d[5], y_min, y_end);
+    const size_t ft = (size_t)f * mesh.n_tris + t;
+    if (threadIdx.x == 0) {                        // taps + inputs of the map path
+#pragma unroll
+        for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
+        fr.segs[ft * 3] = seg[0]; fr.segs[ft * 3 + 1] = seg[1]; fr.segs[ft * 3 + 2] = seg[2];
+        TriRange tr; tr.y_min = y_min; tr.y_end = y_end; tr.a = 0; tr.b = 0;
+        fr.trir[ft] = tr;
+    }
+    const int W = fd.obj_w;
+    if (W <= 0 || fd.obj_h <= 0) return;
+    const int64_t len = (int64_t)W * fd.obj_h;
+    int32_t *__restrict__ rowcnt = rl.cnt + (size_t)f * rl.row_stride;
+    const size_t ent0 = (size_t)f * rl.row_stride * rl.cap;
+    int64_t y_first = y_min, y_stop = y_end;
+    clamp_rows(y_first, y_stop, fd.y_off, W, len);           // rows that cannot write a cell are skipped (hg_math.h)
+    for (int64_t y = y_first + threadIdx.x; y < y_stop; y += blockDim.x) {
+        int64_t k, fin;
+        span_cells(seg, (double)y, (double)fd.y_off, (double)W, len, k, fin);
+        if (k >= fin) continue;
+        // usual case: the span sits in output row (y - yOff) (+objH when it wrapped); otherwise divide
+        int64_t r = y - fd.y_off;
+        if (r < 0) r += fd.obj_h;
+        if (r < 0 || r >= fd.obj_h || k < r * W || k >= (r + 1) * W) r = k / W;
+        for (; r * W < fin; r++) {
+            const int64_t lo = (k > r * W ? k : r * W) - r * W, hi = (fin < (r + 1) * W ? fin : (r + 1) * W) - r * W;
+            const int slot = X::slot(&rowcnt[r], t, y);
+            if (slot < rl.cap && X::store_entries) {
+                const size_t idx = ent0 + (size_t)r * rl.cap + slot;
+                const uint32_t lh = (uint32_t)lo | ((uint32_t)hi << 16);
+                if (COMPACT) static_cast<uint2 *>(rl.ent)[idx] = make_uint2(lh, (uint32_t)t);
+                else {
+                    uint4 *dst = static_cast<uint4 *>(rl.ent) + 2 * idx;
+                    dst[0] = make_uint4(lh, (uint32_t)t, __float_as_uint(inv[0]), __float_as_uint(inv[1]));
+                    dst[1] = make_uint4(__float_as_uint(inv[2]), __float_as_uint(inv[3]), __float_as_uint(inv[4]), __float_as_uint(inv[5]));
+                }
+            }
+        }
+    }
+}
+
+template <int CAP, class X, bool MAP, int PH, bool COMPACT, bool HIB>
+__device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *__restrict__ out,
+                                             int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
+                                             int32_t *__restrict__ status_next)
+{
+    // A workgroup owns rows_per_group consecutive output rows: kRowGroup = 4 when the host expects short span lists, 1
+    // for dense meshes (there, rows that share source lines should run side by side in different workgroups).  1-D grid decoded so that XCD x (= block id % number of XCCs of the device -- hipDeviceAttributeNumberOfXccs, hg_create --, the observed
+    // dispatch order; speed only, never correctness) walks a contiguous band of rows of one frame: vertically adjacent
+    // output rows share source cache lines, which then stay in that XCD's L2 instead of being fetched by up to 8 of them.
+    const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1), bi = bid >> fr.xcc_log2;
+    const int f = bi / groups_per_xcd;
+    const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * rows_per_group;
+    const FrameDesc fd = fr.frames[f];
+    // housekeeping for the NEXT step (saves its memset): the other parity's status words are cleared here, and below every
+    // workgroup zeroes the span counters of its rows once all its waves have read them
+    if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;
+    if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
+
+    __shared__ __align__(16) double s_m[CAP * 6];
+    __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (KS)
+    static_assert(CAP >= 64 * kRowGroup, "packed mode gives each of the 4 rows a 64-slot block");
+    constexpr int KS = CAP * 48 <= (1 << kKeyShift) ? kKeyShift : kKeyShift + 1, KMASK = (1 << KS) - 1;   // id << KS | record offset
+    static_assert(CAP * 48 <= (1 << KS) && KS <= 15, "record offsets must fit below the 15-bit id");
+
+    const int W = fd.obj_w;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: the window loop runs on the scalar unit
+    const int nwin = (W + 255) >> 8;
+    const int nrows = min(rows_per_group, fd.obj_h - r0);
+
+    // ---- span counts of the group's rows.  Packed mode (every row has at most 63 spans: the common case): all four
+    // lists are loaded at once, one barrier, then wave j walks row r0 + j alone -- the list-load latency is paid once per
+    // four rows and a row's span scan is a single ballot.  Otherwise the rows are taken one after the other with the
+    // whole LDS (up to CAP - 1 spans) and the windows of a row are dealt to the four waves.
+    int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    int cnts[kRowGroup], cmax = 0;
+#pragma unroll
+    for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
+    if (cmax > rl.cap || cmax > CAP - 1) {
+        __syncthreads();                                    // every wave has read the counters before they are cleared
+        if ((int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;
+        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+        return;
+    }
+    const bool packed = rows_per_group == kRowGroup && __builtin_amdgcn_readfirstlane(cmax) <= 63;
+
+    // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
+    // from the hardware range check == the JS `undefined` -> 0 of :1051.
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 0, mesh.W * mesh.H * 4, 0x00020000);
+    // :1047 on h = RTN(s + 0.5):  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= hx < W + minSrcX + 0.5, same for y.
+    // All four are tested on the doubles: the rounded coordinates are only 32-bit (a source row of 300 * 2^24 must be
+    // rejected, not wrapped back into the image); what the range check of the buffer load still provides is the `undefined`
+    // -> 0 of flat indices that pass :1047 and yet fall outside the array (sx in [W - 0.5, W) on the last row).
+    const double bx_lo = sgpr_f64((double)mesh.min_src_x + 0.5), bx_hi = sgpr_f64((double)mesh.W + (double)mesh.min_src_x + 0.5);
+    const double by_lo = sgpr_f64((double)mesh.min_src_y + 0.5), by_hi = sgpr_f64((double)mesh.H + (double)mesh.min_src_y + 0.5);
+    // HIB (host: hi_bounds_ok): the same four tests as two 32-bit compares on the high dwords of h (hg_dev.h)
+    const HiBounds hb = make_hi_bounds((double)mesh.min_src_x + 0.5, (double)mesh.W + (double)mesh.min_src_x + 0.5,
+                                       (double)mesh.min_src_y + 0.5, (double)mesh.H + (double)mesh.min_src_y + 0.5);
+    const int pitch4 = mesh.W * 4;
+
+    const float *__restrict__ ginv = fr.inv + (size_t)f * mesh.n_tris * kInvStride;
+    // row `row` of the group -> LDS slots [base, base + cnt) (+ a NaN record in slot base + nan_slot that pixels without a
+    // triangle point at); threads t0, t0 + step, ... of the caller's thread set do the copying
+    auto load_row = [&](int row, int cnt, int base, int nan_slot, int t0, int step) {
+        const double y = (double)(r0 + row + fd.y_off);
+        const size_t e0 = X::list_base(((size_t)f * rl.row_stride + r0 + row) * rl.cap, xcd, groups_per_xcd, bi, f, rows_per_group, row, rl.cap);
+        for (int i = t0; i < cnt; i += step) {
+            uint32_t lh, id;
+            double m0, m1, m2, m3, m4, m5;
+            if (COMPACT) {                                  // 8-byte entry; the triangle's f32 inverse matrix from the tap array (L2)
+                const uint2 a = static_cast<const uint2 *>(rl.ent)[e0 + i];
+                lh = a.x; id = a.y;
+                const float4 ma = *reinterpret_cast<const float4 *>(ginv + (size_t)id * kInvStride);
+                const float2 mb = *reinterpret_cast<const float2 *>(ginv + (size_t)id * kInvStride + 4);
+                m0 = (double)ma.x; m1 = (double)ma.y; m2 = (double)ma.z; m3 = (double)ma.w; m4 = (double)mb.x; m5 = (double)mb.y;
+            } else {                                        // 32-byte entry carrying the matrix
+                const uint4 a = static_cast<const uint4 *>(rl.ent)[2 * (e0 + i)], b = static_cast<const uint4 *>(rl.ent)[2 * (e0 + i) + 1];
+                lh = a.x; id = a.y;
+                m0 = (double)__uint_as_float(a.z); m1 = (double)__uint_as_float(a.w); m2 = (double)__uint_as_float(b.x);
+                m3 = (double)__uint_as_float(b.y); m4 = (double)__uint_as_float(b.z); m5 = (double)__uint_as_float(b.w);
+            }
+            const int elo = (int)(lh & 0xffffu), ehi = (int)(lh >> 16);
+            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)id << KS) | ((base + i) * 48);
+            double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
+            mrec[0] = make_double2(m0, m2 * y);              // {m0, m2*y, m4, m1, m3*y, m5}: m2*y and m3*y are the separately
+            mrec[1] = make_double2(m4, m1);                  // rounded products of :1383-1384
+            mrec[2] = make_double2(m3 * y, m5);
+        }
+        if (t0 < 3) reinterpret_cast<double2 *>(s_m + (base + nan_slot) * 6)[t0] = make_double2(NAN, NAN);
+    };
+
+    // All 256-pixel windows w0, w0 + wstep, ... of one row whose spans sit in LDS slots [base, base + cnt).
+    // PH windows per phase: the gathers of PH windows are issued (each right after its window is resolved, so they overlap
+    // the next window's arithmetic), then the PH x 4 stores.  On gfx9 loads and stores share one in-order counter (vmcnt): with
+    // one window per phase every wait for gather data also waits for the previous window's write acknowledgements, and only 4
+    // requests per wave are ever in flight.  A streaming copy in the same instruction forms (tools/calib_fetch: 4 loads + 4
+    // stores per step 4.7 TB/s, 16 + 16 per step 5.7 TB/s) shows what that costs once the source comes from HBM.
+    auto do_row = [&](int row, int cnt, int base, int nan_slot, int w0, int wstep) {
+        // "no triangle": smaller than every real key, its low bits address the NaN record
+        const int nan_key = (int)0x80000000u | ((base + nan_slot) * 48);
+        const int r = r0 + row;
+        const int64_t row_px = (int64_t)r * W;
+        // Output row: raw buffer of 4*W bytes, so the ragged last window needs no per-pixel guard (stores past the row
+        // end are dropped by the hardware range check).
+        const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + row_px * 4, 0, W * 4, 0x00020000);
+        // (16-byte stores need 16-byte aligned addresses and must not straddle the row end: the range check drops a store whole)
+        const bool vec_zero = ((W & 3) == 0) && (((fd.out_off + (uint64_t)row_px * 4) & 15) == 0);
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u zero4 = { 0u, 0u, 0u, 0u };
+        for (int wb = w0; wb < nwin; wb += wstep * PH) {
+            uint32_t px[PH][4];
+            bool empty[PH];                                 // wave-uniform
+#pragma unroll
+            for (int p = 0; p < PH; p++) {
+                const int w = wb + p * wstep;               // wave-uniform
+                if (w >= nwin) break;
+                const int c0 = w << 8, cq = c0 + lane;      // lane l owns pixels c0 + l + 64k: every gather instruction covers
+                int best[4];                                // 64 consecutive pixels and every store instruction 256 contiguous bytes
+#pragma unroll
+                for (int k = 0; k < 4; k++) best[k] = nan_key;
+                unsigned long long any = 0ull;
+                if (!X::fake_search(best, any, base, w, cnt)) for (int j = 0; j < cnt; j += 64) {
+                    const int idx = j + lane;
+                    int lo = 0x7fffffff, hi = 0;
+                    if (idx < cnt) { lo = s_lo[base + idx]; hi = s_hi[base + idx]; }
+                    unsigned long long mask = __ballot(lo < c0 + 256 && hi > c0);
+                    any |= mask;
+                    while (mask) {
+                        const int bit = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int slot = base + j + bit;
+                        const int d = cq - s_lo[slot];
+                        span_max4(best, d, s_len[slot], s_key[slot]);   // larger id wins (== last writer of :852-858); its slot rides along
+                    }
+                }
+                empty[p] = any == 0;                         // no span of this row reaches the window
+                if (empty[p]) px[p][0] = px[p][1] = px[p][2] = px[p][3] = 0u;
+                else {
+                    const double xd0 = (double)(cq + fd.x_off);     // exact: integers far below 2^53
+                    // Pixels are transformed and rounded STEP at a time.  With 2 or 4 windows per phase two at a time: only 8 + 8
+                    // instead of 16 + 16 registers of coordinates are live at once, which brings the 2-window instantiation
+                    // from 66 to 58 VGPRs (8 waves/SIMD instead of 7; C3 -1.4 %, and the 4-window one from 78 to 66).  With one
+                    // window per phase (one source per frame) all four at once measured 2 % faster.
+                    constexpr int STEP = PH == 1 ? 4 : 2;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk += STEP) {
+                        double h[2 * STEP], rd[2 * STEP];
+#pragma unroll
+                        for (int k = kk; k < kk + STEP; k++) {
+                            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KMASK));
+                            const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+                            const double xd = X::pixel_x(xd0 + (double)(k * 64), c0, lane, k, fd.x_off);
+                            // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
+                            // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
+                            h[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
+                            h[2 * (k - kk) + 1] = X::pixel_hy(fma(m1.y, xd, m2.x) + m2.y, lane);
+                        }
+                        if constexpr (STEP == 4) round_x8(h, rd); else round_x4(h, rd);
+#pragma unroll
+                        for (int k = kk; k < kk + STEP; k++) {
+                            const int q = 2 * (k - kk);
+                            const bool inb = HIB ? hi_inb(hb, h[q], h[q + 1])
+                                                 : (bool)((int)(h[q] >= bx_lo) & (int)(h[q] < bx_hi) & (int)(h[q + 1] >= by_lo) & (int)(h[q + 1] < by_hi));   // NaN fails
+                            const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[q + 1]), pitch4) + ((int)dlo(rd[q]) << 2));     // :1048-1049
+                            const uint32_t off = inb ? o : 0xffffffffu;
+                            px[p][k] = X::gather(src, off);                 // range-checked buffer load: outside the array -> 0
+                        }
+                    }
+                }
+                if (MAP) {                                  // parity tap (hg_get_tri_map_fused): a separate instantiation
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (cq + k * 64 < W) map_out[fd.map_off + row_px + cq + k * 64] = best[k] < 0 ? (int16_t)-1 : (int16_t)(best[k] >> KS);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < PH; p++) {
+                const int w = wb + p * wstep;
+                if (w >= nwin) break;
+                const int cq = (w << 8) + lane;
+                if (X::skip_store(px[p])) continue;
+                if (empty[p] && vec_zero) {                 // 1 KB of zeros: which lane writes which pixel does not matter -> one 16-byte store per lane
+                    __builtin_amdgcn_raw_buffer_store_b128(zero4, dst, ((w << 8) + lane * 4) * 4, 0, kStoreNT);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) __builtin_amdgcn_raw_buffer_store_b32(px[p][k], dst, (cq + k * 64) * 4, 0, kStoreNT);
+                }
+            }
+        }
+    };
+
+    // One window per wave iteration.  Measured alternatives: two windows in flight per wave (74 VGPRs, 6
+    // waves/SIMD) and a phased variant (4 windows resolved, then 16 gathers, then 16 stores) are both ~4 % slower: with
+    // 8 waves/SIMD the other waves already cover a window's memory latency, and reads + writes together run at ~5.2 TB/s.
+    const int npass = packed ? 1 : nrows;
+    for (int pass = 0; pass < npass; pass++) {
+        const int row = packed ? wave : pass;               // everything below is wave-uniform (scalar registers)
+        const int cnt = __builtin_amdgcn_readfirstlane(cnts[0] * (row == 0) + cnts[1] * (row == 1) + cnts[2] * (row == 2) + cnts[3] * (row == 3));
+        const int base = packed ? wave * 64 : 0, nan_slot = packed ? 63 : CAP - 1;
+        load_row(row, cnt, base, nan_slot, packed ? lane : (int)threadIdx.x, packed ? 64 : 256);
+        __syncthreads();
+        if (pass == 0 && (int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;
+        if (row < nrows) do_row(row, cnt, base, nan_slot, packed ? 0 : wave, packed ? 1 : 4);
+        if (!packed) __syncthreads();                       // the next row overwrites the records
+    }
+}
+
+template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false>
+__global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int16_t *__restrict__ map_out,
+                                                 int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
+{
+    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
+}
+
+// The same kernel held to 80 SGPRs.  A 256-thread workgroup puts one wave on each SIMD and a SIMD has 800 SGPRs, allocated in
+// granules of 16 (+16): the 89-104 the compiler takes by itself admit 7 (or 6) workgroups per CU although VGPRs and LDS allow
+// 8; capped, ~20 scalars move into VGPR lanes and 8 workgroups fit.  Measured on one box (round 3): with a shared,
+// cache-resident source (instruction-bound) 2 windows per phase 0.555 -> 0.543 ms on C3; with one source per frame (HBM-bound) the
+// extra waves LOSE 1-3 %, and C4's 4-windows-per-phase layout loses 6 % -- so only the shared-source PH = 2 layout takes it.
+template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_pw_rows_s80(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
+                                                 int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
+{
+    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+#ifdef HG_EXPERIMENTS
+} // namespace hg
+#include "experiments/hg_ablate.h"      // ablation policies + their launch switches; never part of libhgwarp.so
+namespace hg {
+#endif
+
+void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream)
+{
+    if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
+    dim3 grid((mesh.n_tris + 255) / 256, fr.n_frames);
+    hipLaunchKernelGGL(k_tri_setup, grid, dim3(256), 0, stream, mesh, fr);
+}
+
+void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16_t *map_out, hipStream_t stream)
+{
+    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
+    dim3 grid(fr.max_obj_h, fr.n_frames);
+    hipLaunchKernelGGL(k_pw_fused, grid, dim3(256), 0, stream, mesh, fr, out, map_out);
+}
+
+bool pw_fast_ok(const PwMesh &mesh, int max_obj_w)
+{
+    return mesh.n_tris > 0 && mesh.n_tris <= 32767 && max_obj_w <= 65535 && (int64_t)mesh.W * mesh.H * 4 < ((int64_t)1 << 31) &&
+           mesh.W < (1 << 21) && mesh.H < (1 << 22) && std::abs(mesh.min_src_x) < (1 << 22) && std::abs(mesh.min_src_y) < (1 << 22) &&
+           // the flat byte offset (round(sy) * W + round(sx)) * 4 of every pixel that passes :1047 stays inside 32 bits, so that
+           // negative ones (negative source minimum) wrap to >= 2^31 and are dropped by the range check like the rest
+           (((int64_t)mesh.H + std::abs(mesh.min_src_y) + 2) * mesh.W + std::abs(mesh.min_src_x) + 2) * 4 < ((int64_t)1 << 31);
+}
+
+void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream)
+{
+    if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
+    const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads == 64 ? 64 : 128);
+#ifdef HG_EXPERIMENTS
+    if (launch_tri_spans_ablated(mesh, fr, rl, grid, block, stream)) return;      // experiments/hg_ablate.h
+#endif
+    if (rl.compact) hipLaunchKernelGGL((k_tri_spans<NoExperiment, true>), grid, block, 0, stream, mesh, fr, rl);
+    else            hipLaunchKernelGGL((k_tri_spans<NoExperiment, false>), grid, block, 0, stream, mesh, fr, rl);
+}
+
+void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
+{
+    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
+    const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
+    const int nx = 1 << fr.xcc_log2;                                            // XCCs of this device (partition mode), hg_create
+    const int rpx = ((fr.max_obj_h + rg - 1) / rg + nx - 1) / nx;               // row groups per XCD band
+    dim3 grid((unsigned)rpx * (unsigned)nx * (unsigned)fr.n_frames);
+    // bounds :1047 on the high dwords of the rounded coordinates (hg_dev.h) whenever the source window allows it; the fp64
+    // compares otherwise (negative source minimum, sources beyond 2^20 pixels a side) and in the parity-tap instantiations
+    const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
+#define HG_ROWS(CAP, MAPF, PHV, CMP, HB) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB>), grid, dim3(256), (size_t)fr.lds_pad_kb * 1024, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
+#define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true); else HG_ROWS(CAP, false, 1, CMP, false); } while (0)
+    if (rl.cap > kRowSpanCapFast) {                          // very dense meshes: 512 LDS slots per row (32 KB), one row per workgroup
+        if (rl.compact) { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, true, false); else HG_ROWS_B(kRowSpanCapDense, 1, true); }
+        else            { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, false, false); else HG_ROWS_B(kRowSpanCapDense, 1, false); }
+        return;
+    }
+    if (map_out) { if (rl.compact) HG_ROWS(kRowSpanCapFast, true, 1, true, false); else HG_ROWS(kRowSpanCapFast, true, 1, false, false); return; }
+    if (rl.compact) {                                        // dense rows: 8-byte entries
+        if (fr.phase >= 2) HG_ROWS_B(kRowSpanCapFast, 2, true); else HG_ROWS_B(kRowSpanCapFast, 1, true);     // (no 4-window instantiation here)
+        return;
+    }
+#ifdef HG_EXPERIMENTS
+    // Timing experiments of DESIGN.md §6 (ablated variants produce WRONG pixels): only in the separate experiments build
+    // (`make experiments` -> lib/libhgwarp_exp.so); the shipped library has neither the instantiations nor the switch.
+    if (launch_pw_rows_ablated(mesh, fr, rl, out, map_out, rpx, rg, status_next, grid, stream)) return;     // experiments/hg_ablate.h
+#endif
+    switch (fr.phase) {
+    case 4:  HG_ROWS_B(kRowSpanCapFast, 4, false); break;
+    case 2:
+        if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true>), grid, dim3(256), (size_t)fr.lds_pad_kb * 1024, stream,
+                                                   mesh, fr, rl, out, map_out, rpx, rg, status_next);
+        else HG_ROWS_B(kRowSpanCapFast, 2, false);
+        break;
+    default: HG_ROWS_B(kRowSpanCapFast, 1, false); break;
+    }
+#undef HG_ROWS_B
+#undef HG_ROWS
+}
+
+} // namespace hg

@@ -1,4 +1,4 @@
-// hg_kernels.h -- device-side data layout and kernel launchers (implemented in hg_kernels.hip).
+// hg_kernels.h -- device-side data layout and kernel launchers (implemented in hg_k_*.hip, one translation unit per kernel family).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -62,6 +62,11 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t row_group;              // output rows per k_pw_rows workgroup: kRowGroup (sparse rows) or 1 (dense meshes)
     int32_t tri_threads;            // k_tri_spans workgroup size: 128, or 64 when the triangles are short (one row per thread)
     int32_t phase;                  // k_pw_rows: windows whose gathers are issued before their stores (1, 2 or 4)
+    int32_t xcc_log2;               // log2 of the device's XCC count (8 on an unpartitioned MI355X): block id -> XCD row band
+    int32_t lds_pad_kb;             // option "lds_pad": KB of unused dynamic LDS per k_pw_rows workgroup (caps the workgroups resident per CU)
+    int32_t lds_pad_patch_kb;       // the same for k_pw_patch (explicit option only: it loses with fewer workgroups)
+    int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only
+    int32_t no_hi_bounds;           // option "hi_bounds" = 0: keep the fp64 bounds compares (parity suite runs both forms)
 };
 
 // Per-output-row span lists of the fast path (k_tri_spans -> k_pw_rows), in global memory.
@@ -92,7 +97,7 @@ void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream
 // lookup resolved == the reference's _trianglesCorrespondencesMatrix.
 void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16_t *map_out, hipStream_t stream);
 
-// Fast path (see hg_kernels.hip): eligibility, span-list build (includes the per-triangle solves), row warp.
+// Fast path (see hg_k_piecewise.hip): eligibility, span-list build (includes the per-triangle solves), row warp.
 bool pw_fast_ok(const PwMesh &mesh, int max_obj_w);
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream);
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream);
@@ -111,6 +116,7 @@ void launch_map_build(const PwMesh &mesh, const PwFrames &fr, int f, const Frame
 void launch_pw_from_map(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, const int32_t *map32,
                         uint8_t *out, hipStream_t stream);
 void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream_t stream);
+void launch_fill_i32(int32_t *p, size_t n, int32_t v, hipStream_t stream);      // grid-stride fill (map / winner-buffer initialisation)
 
 // k_geo: _inverseGeometricWarp pixel loop :997-1011 for all frames.  mats = F x 8 doubles (inverse matrices).
 // f32_exact: every affine matrix entry is a float value and |x| < 2^28 (lets the kernel use an exact-product fma).

@@ -148,7 +148,7 @@ HG_HD void solve_projective_regs(const float *s, const float *d, double *out)
 }
 
 // Can every division (m0*x + m1*y + m2) / (m6*x + m7*y + 1), (m3*x + m4*y + m5) / (same) of this frame be done by
-// div2_plain (hg_kernels.hip), i.e. without the scaling / special-value steps of the full IEEE expansion?
+// div2_plain (hg_k_geo.hip), i.e. without the scaling / special-value steps of the full IEEE expansion?
 //   * matrix entries finite, each 0 or 2^-100 <= |m| <= 2^100; pixel coordinates |x|, |y| < 2^28
 //     => numerators are 0 or in [2^-210, 2^130] (a non-zero sum of two such roundings cannot fall below 2^-206);
 //   * the denominator, evaluated in the kernel's own operation order, is weakly monotone along x and along y (every

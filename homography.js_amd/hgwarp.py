@@ -35,7 +35,7 @@ EXPORTS = [
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
     "hg_warp_forward_geometric", "hg_warp_forward_piecewise", "hg_warp_forward_geometric_device", "hg_warp_forward_geometric_batch_device",
     "hg_warp_forward_piecewise_device", "hg_warp_forward_piecewise_batch_device",
-    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_set_option", "hg_selftest_division", "hg_projective_plain_range",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range",
 ]
 
 
@@ -95,7 +95,7 @@ def lib():
         "hg_warp_inverse_piecewise_batch_device": (i, [vp, f32p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
         "hg_get_tri_map": (i, [vp, C.POINTER(C.c_int16), sz]), "hg_get_tri_map_fused": (i, [vp, C.POINTER(C.c_int16), sz]),
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
-        "hg_last_piecewise_kernel": (i, [vp]), "hg_last_forward_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]),
+        "hg_last_piecewise_kernel": (i, [vp]), "hg_last_forward_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]), "hg_xcc_count": (i, [vp]),
         "hg_selftest_division": (i, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
         "hg_projective_plain_range": (i, [f64p, Geom]), "hg_forward_tiles_admissible": (i, [i, f64p, i, i, Geom]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
@@ -107,7 +107,10 @@ def lib():
         "hg_warp_forward_piecewise_device": (i, [vp, f32p, i, i, Geom, vp]),
         "hg_warp_forward_piecewise_batch_device": (i, [vp, f32p, i, i, C.POINTER(Geom), C.POINTER(sz), i, vp]),
     }
+    older = "HGWARP_LIB" in os.environ       # A/B tooling (tools/ab*.sh) loads an OLDER build beside the current one: it may lack newer symbols
     for name, (res, args) in sig.items():
+        if older and not hasattr(L, name):
+            continue
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
     _lib = L
@@ -291,6 +294,10 @@ class Context:
     def redone_frames(self):
         """Frames redone through the materialised map since the context was created."""
         return lib().hg_redone_frames(self._h)
+
+    def xcc_count(self):
+        """XCCs the warp kernels' block id -> row band mapping assumes (read from the device at creation, or option 'xcc')."""
+        return lib().hg_xcc_count(self._h)
 
     def set_option(self, key, value):
         """Layout knobs of the piecewise fast path ("min_row_groups", "patch"); results never depend on them."""

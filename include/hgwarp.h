@@ -253,8 +253,15 @@ long hg_redone_frames(hg_ctx *ctx);
  *           global-record variant;
  *   "phase" (default -1 = 2 for a shared source -- 4 when the rows carry 3 or more spans per window --, 1 with one source per frame):
  *           windows per k_pw_rows gather/store phase, 1, 2 or 4;
- *   "geo_windows" (default 4): 256-pixel windows per wave of the affine / projective kernel, 1, 2 or 4. */
+ *   "geo_windows" (default 4): 256-pixel windows per wave of the affine / projective kernel, 1, 2 or 4;
+ *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
+ *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
+ *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;
+ *   "xcc" (default: hipDeviceAttributeNumberOfXccs of the device, 8 on an unpartitioned MI355X): number of XCCs the
+ *           block id -> row band mapping of the warp kernels assumes; a power of two in 1..64. */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);
+/* Number of XCCs the ctx maps row bands to (what hg_create read from the device, or the "xcc" option). */
+int hg_xcc_count(const hg_ctx *ctx);
 /* Host-side proof obligation of that division (no GPU needed): 1 if every pixel of the window `geom` under the inverse
  * projective matrix m[8] keeps numerators and denominator in the plain range (entries 0 or in [2^-100, 2^100], coordinates
  * below 2^28, denominator of one sign and in [2^-100, 2^130] at the four corners), else 0 (-> IEEE divides in the kernel). */

@@ -17,10 +17,12 @@ GOLD = G.load()
 
 # The piecewise fast path picks a kernel layout from the frame set (rows per workgroup, k_pw_patch for dense sheared meshes);
 # results must not depend on it, so every test that takes `ctx` runs under each layout policy.
-LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0}, "rows1": {"min_row_groups": 1 << 30, "patch": 0},
-           "patch": {"min_row_groups": 0, "patch": 1}, "patch_global": {"min_row_groups": 0, "patch": 2},
-           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1},
-           "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0}}
+# ("hi_bounds": 0 keeps the fp64 form of the source-bounds tests, "xcc" changes the block id -> row band mapping: both are folded
+#  into the existing layouts so that every kernel runs under either form without multiplying the suite.)
+LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds": 0, "xcc": 4}, "rows1": {"min_row_groups": 1 << 30, "patch": 0, "xcc": 1},
+           "patch": {"min_row_groups": 0, "patch": 1}, "patch_global": {"min_row_groups": 0, "patch": 2, "hi_bounds": 0, "xcc": 2},
+           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0},
+           "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))
@@ -30,6 +32,24 @@ def ctx(request):
         c.set_option(k, v)
     yield c
     c.close()
+
+
+def test_xcc_count_comes_from_the_device():
+    """The row-band mapping is sized from hipDeviceAttributeNumberOfXccs, not from a constant: 8 on an unpartitioned MI355X
+    (the only mode the test boxes run), and the option overrides it."""
+    c = HG.Context(0)
+    try:
+        assert c.xcc_count() in (1, 2, 4, 8, 16), c.xcc_count()
+        import torch
+        props = torch.cuda.get_device_properties(0)
+        if "gfx950" in props.gcnArchName and props.multi_processor_count == 256:
+            assert c.xcc_count() == 8                              # unpartitioned MI355X: 8 XCDs x 32 CUs
+        c.set_option("xcc", 2)
+        assert c.xcc_count() == 2
+        with pytest.raises(Exception):
+            c.set_option("xcc", 3)
+    finally:
+        c.close()
 
 
 def _inverse_warps():

@@ -26,6 +26,8 @@ for t in range(trials):
     ctx.set_option("min_row_groups", int(rng.choice([1536, 0, 1 << 30])))
     ctx.set_option("geo_windows", int(rng.choice([1, 2, 4])))
     ctx.set_option("fwd_tiles", int(rng.choice([-1, 0, 1, 1])))
+    ctx.set_option("hi_bounds", int(rng.choice([1, 1, 0])))
+    ctx.set_option("xcc", int(rng.choice([8, 8, 1, 2, 4, 16])))
     nx, ny = int(rng.integers(1, 24)), int(rng.integers(1, 16))
     if mode == 6:
         nx, ny = int(rng.integers(30, 140)), int(rng.integers(1, 6))                      # dense rows: 1 row per workgroup, > 63 spans per row
