@@ -10,6 +10,7 @@ projective config C2 the 8x8 DLT solve of every frame (k_solve_frames) is part o
 RGBA, meshes, destination points) are resident in HBM before the timed region; outputs stay in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config C3|C4|C5|C2] [--sources both|shared|distinct]
+                    [--points both|resident|fresh]
 
 --gpus N > 1 without a torchrun environment re-executes itself under
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
@@ -21,6 +22,9 @@ Two source layouts are measured:
             carries `hbm_compulsory_frac` (output written once + source read once).
   distinct  the video case (README.md:121-137): every frame has its own 33 MB source (F x 33 MB >> Infinity Cache), where
             the algorithmic bytes ARE HBM bytes: `roofline_distinct`.
+`--points fresh` (part of the default run) times the reference's own loop shape as well: a NEW destination point set goes up
+inside every timed step (hg_piecewise_set_frames: host copy into page-locked staging + stream-ordered upload, no GPU wait),
+reported as `roofline_fresh` next to the resident-points line (`value`).
 After each timed region the bytes the timed kernels wrote are checked (untimed): frame 0 against the reference-generated
 golden SHA-256 (tests/golden/golden.json; a data fixture, not the oracle), the other frames against frame f mod 4, the
 distinct-source frames through XOR-linearity against the shared-source frames.  `verified` must be true; exit status 3
@@ -114,6 +118,9 @@ def main():
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "C5", "C2", "C5flat"])
     ap.add_argument("--sources", default="both", choices=["both", "shared", "distinct"],
                     help="shared: one source for all frames (BASELINE config, `value`); distinct: one source per frame; both (default)")
+    ap.add_argument("--points", default="both", choices=["both", "resident", "fresh"],
+                    help="resident: destination points uploaded once before the timed region (`value`); fresh: a new point set goes up "
+                         "inside EVERY timed step, like the reference's loop setDestinyPoints(dst_i); warp() (`roofline_fresh`); both (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) output checks")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
@@ -197,7 +204,7 @@ def main():
         ctx.piecewise_set_mesh(sp, tris, msx, msy)
         offs, total = hg.pack_offsets(geoms)
         ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
-        run = ctx.warp_inverse_piecewise_frames_device
+        run_resident = ctx.warp_inverse_piecewise_frames_device
         workload = (f"{args.config}: {W}x{H} RGBA piecewise-affine, {mesh_txt} "
                     f"({tris.size // 3} triangles), {F} frames/GPU/step")
     else:
@@ -213,9 +220,24 @@ def main():
         offs, total = hg.pack_offsets(geoms)
         ctx.geometric_set_frames_points(1, np.concatenate(d4s), np.tile(s4, F), geoms, offs)     # inverse: dst -> src (:994)
         solve_txt = ", 8x8 DLT solve per frame on the device inside the step"
-        run = ctx.warp_inverse_geometric_frames_device
+        run_resident = ctx.warp_inverse_geometric_frames_device
         workload = f"{args.config}: {W}x{H} RGBA projective, 4 corner points, {F} frames/GPU/step{solve_txt}"
 
+    run = run_resident
+    # --points fresh: a ring of R point sets (the config's own sequence shifted by k frames), one uploaded per timed step
+    fresh_sets = None
+    if piecewise and args.points in ("both", "fresh") and args.sources != "distinct":
+        R = 8
+        fresh_sets = []
+        for k in range(R):
+            if cfg["kind"] == "face":
+                fr_k = [seq[(i + k) % len(seq)] for i in frame_ids]
+            else:
+                fr_k = [wl.sin_grid_dst(W, H, cfg["nx"], cfg["ny"], cfg["A"], 8 + ((i + k) % 4)) for i in frame_ids]
+            g_k = [wl.piecewise_geom(d) for d in fr_k]
+            o_k, t_k = hg.pack_offsets(g_k)
+            fresh_sets.append({"frames": fr_k, "geoms": g_k, "offs": o_k, "total": t_k, "args": ctx.frame_set_args(np.concatenate(fr_k), g_k, o_k)})
+        total = max([total] + [fs["total"] for fs in fresh_sets])
     out_t = torch.empty(total, dtype=torch.uint8, device=dev)
     d_out = out_t.data_ptr()
     n_out = [g[2] * g[3] for g in geoms]
@@ -243,8 +265,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region():
+    def timed_region(run=None):
         """ramp -> W warmup steps -> K timed steps (barrier + synchronize on both sides); returns (elapsed_s, kernel_ms, launches)"""
+        run = run or run_resident
         # The GPU sat idle during the untimed host work: ~50 ms of the same steps first, so that warmup and the timed region
         # run at the sustained clocks (a 0.6 ms step is far shorter than the power-state ramp).  Untimed.
         t_ramp = time.perf_counter()
@@ -318,8 +341,44 @@ def main():
                         break
             else:
                 check("every frame == the frame with its point set among the first few (f mod period)", True)
-            if do_distinct:
+            if do_distinct or fresh_sets:
                 shared_copy = out_t.clone()
+
+    # ---------------------------------------------------------------- fresh destination points inside every timed step
+    # What the reference's loop does (test/benchmark.js:107-110: setDestinyPoints(dst_i); warp()): per step one
+    # hg_piecewise_set_frames (host copy into page-locked staging + stream-ordered upload, no GPU wait) and the two kernels.
+    fresh = None
+    if do_shared and fresh_sets:
+        step_i = [0]
+
+        def run_fresh(d):
+            fs = fresh_sets[step_i[0] % len(fresh_sets)]
+            step_i[0] += 1
+            ctx.piecewise_set_frames_prepared(fs["args"])
+            ctx.warp_inverse_piecewise_frames_device(d)
+        walks0, redone0 = ctx.layout_walks(), ctx.redone_frames()
+        elapsed_f, k_ms_f, k_launches_f = timed_region(run_fresh)
+        k_last = (step_i[0] - 1) % len(fresh_sets)
+        fs = fresh_sets[k_last]
+        fresh = {"ms_per_step": round(elapsed_f * 1e3 / args.steps, 4), "kernel_ms": round(k_ms_f, 5),
+                 "value_mpixels_per_s": round(px_all * args.steps / elapsed_f / 1e6, 1),
+                 "vs_resident_ms_per_step": round(elapsed_f / res["shared"][0], 4),
+                 "layout_walks_in_region": ctx.layout_walks() - walks0, "frames_redone_in_region": ctx.redone_frames() - redone0,
+                 "point_sets": f"ring of {len(fresh_sets)} sets (the config's sequence shifted by k frames), one hg_piecewise_set_frames per step: "
+                               f"{F} frames x {sp.size // 2} points copied to page-locked staging and uploaded stream-ordered, no GPU wait"}
+        if not args.no_verify and shared_copy is not None:
+            ok, n_cmp = True, 0
+            for f in range(F):
+                fp = ((f + k_last) % 4) if cfg["kind"] != "face" else f + k_last      # resident frame with the same point set
+                if fp >= F or fs["geoms"][f] != tuple(geoms[fp]):
+                    continue
+                nb = n_out[fp] * 4
+                n_cmp += 1
+                if not torch.equal(out_t[fs["offs"][f]: fs["offs"][f] + nb], shared_copy[offs[fp]: offs[fp] + nb]):
+                    ok = False
+                    break
+            check(f"fresh-points step (set {k_last}): {n_cmp} frames == the resident-points frames with the same point set", ok and n_cmp > 0)
+        ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)          # back to the resident set
 
     # ---------------------------------------------------------------- distinct sources: one 4*W*H source per frame (video case)
     if do_distinct:
@@ -329,9 +388,10 @@ def main():
             srcs[f] ^= consts[f]
         ctx.set_images_device(srcs.data_ptr(), W, H, F, W * H * 4)
         elapsed_d, k_ms_d, k_launches_d = timed_region()
-        if kernel_name is None:
-            kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
+        kernel_shared = kernel_name                 # (the layout policy may pick another kernel when every frame streams its own source)
+        kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
         rd = roofline_block(k_ms_d, k_launches_d, "distinct")
+        kernel_name = kernel_shared or kernel_name
         rd["sources"] = f"{F} distinct {W}x{H} RGBA sources per step ({F * W * H * 4 / 1e6:.0f} MB >> 256 MiB Infinity Cache): algorithmic bytes are HBM bytes"
         rd["ms_per_step"] = round(elapsed_d * 1e3 / args.steps, 4)
         rd["value_mpixels_per_s"] = round(px_all * args.steps / elapsed_d / 1e6, 1)
@@ -437,7 +497,7 @@ def main():
                            "parallelism": f"frames sharded over {world} GPU(s); shared source broadcast once (scatter+all_gather over RCCL)",
                            "broadcast_ms": round(broadcast_ms, 3)},
                 "verified": None if args.no_verify else verified, "checks": checks,
-                "roofline": roofline, "roofline_distinct": res["distinct"][1] if "distinct" in res and primary != "distinct" else None,
+                "roofline": roofline, "roofline_fresh": fresh, "roofline_distinct": res["distinct"][1] if "distinct" in res and primary != "distinct" else None,
                 "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     ctx.close()

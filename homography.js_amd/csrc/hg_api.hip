@@ -76,8 +76,30 @@ struct hg_ctx {
     int opt_hi_bounds = 1;                                     // 0: fp64 bounds compares instead of the high-dword form (hg_dev.h)
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
-    struct Pending { uint8_t *out; int slot; };
+    struct Pending { uint8_t *out; int slot; int stage; };     // stage: which staged frame set (points + windows) the run warped
     std::vector<Pending> pw_pending_out;
+    // Frame sets arrive through a ring of page-locked staging buffers (FrameDesc[F], then the F x n_pts x 2 destination
+    // points): hg_piecewise_set_frames copies the caller's arrays there and queues stream-ordered uploads -- it neither waits
+    // for the GPU nor keeps caller memory.  A staged set stays intact until every run that used it has been settled, so frames a
+    // fused run flagged can still be redone (through the materialised map) after newer sets were uploaded.
+    struct Stage { uint8_t *h = nullptr; size_t cap = 0; int n = 0, n_pts = 0; };
+    Stage stage[kStatusRing];
+    int stage_cur = -1;
+    // scratch of the deferred redo (one frame): its FrameDesc, points, solves
+    FrameDesc *d_redo_frame = nullptr; size_t redo_frame_cap = 0;
+    float *d_redo_dst = nullptr; size_t redo_dst_cap = 0;
+    TriRange *d_redo_trir = nullptr; size_t redo_trir_cap = 0;
+    Seg *d_redo_segs = nullptr; size_t redo_segs_cap = 0;
+    float *d_redo_fwd = nullptr; size_t redo_fwd_cap = 0;
+    float *d_redo_inv = nullptr; size_t redo_inv_cap = 0;
+    int32_t *d_redo_status = nullptr; size_t redo_status_cap = 0;
+    // layout of the row counters / status ring as of their last memset (a frame set with the same layout reuses them as they are)
+    size_t rows_F = 0; int rows_stride = 0, rows_cap = 0;
+    // layout estimates of the last frame set, reused for the next set of the same shape (the kernels check the real counts)
+    struct LayoutKey { int n = -1, n_tris = -1, max_w = -1, max_h = -1; uint64_t mesh_gen = 0; bool quick = false; } layout_key;
+    uint64_t mesh_gen = 0; int layout_age = 0;
+    double pw_tri_rows = 0.0; int pw_group_tris = 0;
+    long pw_layout_walks = 0;                                  // host walks over the triangles (hg_layout_walks(): tests / bench)
 
     // geometric frames
     int geo_kind = 0;
@@ -217,6 +239,9 @@ extern "C" void hg_destroy(hg_ctx *c)
                      c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    for (hg_ctx::Stage &st : c->stage) if (st.h) (void)hipHostFree(st.h);
+    { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status };
+      for (void *q : rp) if (q) (void)hipFree(q); }
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -295,6 +320,7 @@ extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kerne
 extern "C" int hg_last_forward_kernel(hg_ctx *c) { return c ? c->fwd_last_kernel : 0; }
 
 extern "C" long hg_redone_frames(hg_ctx *c) { return c ? c->pw_redone : 0; }
+extern "C" long hg_layout_walks(hg_ctx *c) { return c ? c->pw_layout_walks : 0; }
 
 extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
 {
@@ -666,6 +692,7 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
     c->h_src.assign(src, src + (size_t)2 * n_pts);
     c->fmap_valid = false;
     c->have_mesh = true;
+    c->mesh_gen++;
     c->fwd_pw_tiles_disabled = false; c->fwd_pw_cap = 64;     // (learned on the previous mesh)
     c->pw_frames.clear(); c->pw_setup_done = false;
     return HG_OK;
@@ -761,9 +788,14 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     if (!coords_ok(dst, (size_t)n * c->n_pts * 2))
         return fail(c, HG_ERR_INVALID, "hg_piecewise_set_frames: a destiny coordinate is infinite or beyond 2^24 in magnitude "
                                        "(the reference's fillTriangle row loop would run for that many rows, forever for Infinity)");
-    HG_TRY(hg_sync(c));                                 // settle a pending run before its inputs are replaced
-    HG_TRY(fill_frames(c, c->pw_frames, geoms, offs, n));
+    // Queued runs are NOT waited for: the uploads below are ordered behind them on the stream, and each of them keeps its own
+    // staged copy of the set it warped (deferred redo, hg_sync).  Only a staging slot that a queued run still refers to forces a
+    // settlement first (a caller that uploads 64 sets per run).
     const size_t T = (size_t)std::max(c->n_tris, 1), F = (size_t)n;
+    const int slot = (c->stage_cur + 1) % (int)kStatusRing;
+    for (const hg_ctx::Pending &pd : c->pw_pending_out) if (pd.stage == slot) { HG_TRY(hg_sync(c)); break; }
+    std::vector<FrameDesc> fresh;
+    HG_TRY(fill_frames(c, fresh, geoms, offs, n));
     HG_TRY(ensure(c, c->d_pw_frames, c->pw_frames_cap, F));
     HG_TRY(ensure(c, c->d_dst, c->dst_cap, F * c->n_pts * 2));
     HG_TRY(ensure(c, c->d_trir, c->trir_cap, F * T));
@@ -772,19 +804,52 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     HG_TRY(ensure(c, c->d_inv, c->inv_cap, F * T * kInvStride));
     HG_TRY(ensure(c, c->d_status, c->status_cap, F));
     if (F * kStatusRing > c->h_status_cap) {
+        HG_TRY(hg_sync(c));
         if (c->h_status) HIP_TRY(c, hipHostFree(c->h_status));
         c->h_status = nullptr; c->h_status_cap = 0;
         void *q = nullptr;
         HIP_TRY(c, hipHostMalloc(&q, sizeof(int32_t) * F * kStatusRing, hipHostMallocDefault));
         c->h_status = static_cast<int32_t *>(q); c->h_status_cap = F * kStatusRing;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, c->pw_frames.data(), sizeof(FrameDesc) * F, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_dst, dst, sizeof(float) * 2 * c->n_pts * F, hipMemcpyHostToDevice, c->stream));
+    hg_ctx::Stage &st = c->stage[slot];
+    const size_t fd_bytes = sizeof(FrameDesc) * F, pt_bytes = sizeof(float) * 2 * c->n_pts * F;
+    if (fd_bytes + pt_bytes > st.cap) {
+        // (an older upload out of this slot may still be queued; no queued run refers to it -- checked above -- but the DMA does)
+        if (st.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(st.h)); st.h = nullptr; st.cap = 0; }
+        void *q = nullptr;
+        const size_t want = fd_bytes + pt_bytes + (fd_bytes + pt_bytes) / 4;
+        hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipHostMalloc (frame-set staging): ") + hipGetErrorString(e));
+        st.h = static_cast<uint8_t *>(q); st.cap = want;
+    }
+    std::memcpy(st.h, fresh.data(), fd_bytes);
+    std::memcpy(st.h + fd_bytes, dst, pt_bytes);
+    st.n = n; st.n_pts = c->n_pts;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, st.h, fd_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_dst, st.h + fd_bytes, pt_bytes, hipMemcpyHostToDevice, c->stream));
+    c->pw_frames.swap(fresh);
+    c->stage_cur = slot;
     double tri_rows = 0.0, shear = 0.0;
     int group_tris = 0, max_w = 0, cover = 0;
     int64_t total_px = 0;
     for (const FrameDesc &d : c->pw_frames) { max_w = std::max(max_w, d.obj_w); if (d.obj_w > 0 && d.obj_h > 0) total_px += (int64_t)d.obj_w * d.obj_h; }
-    if (c->pw_quick_layout || (total_px < ((int64_t)4 << 20) && (int64_t)F * c->n_tris > 4096)) {
+    int max_h = 0;
+    for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) max_h = std::max(max_h, d.obj_h);
+    const bool quick = c->pw_quick_layout || (total_px < ((int64_t)4 << 20) && (int64_t)F * c->n_tris > 4096);
+    // The host walk over every triangle of every frame only picks kernel LAYOUTS (rows per workgroup, entry format, k_pw_patch);
+    // the kernels check the real counts and flag what does not fit.  A caller that uploads fresh points for the same mesh and
+    // the same window shape every step (the reference's loop, test/benchmark.js:107-110) therefore keeps the previous estimate:
+    // same frame count, same mesh, window extents within 1/16; re-walked every 256 sets and whenever a run had to be redone.
+    hg_ctx::LayoutKey key;
+    key.n = n; key.n_tris = c->n_tris; key.max_w = max_w; key.max_h = max_h; key.mesh_gen = c->mesh_gen; key.quick = quick;
+    const hg_ctx::LayoutKey &ok = c->layout_key;
+    const bool same_shape = ok.n == key.n && ok.n_tris == key.n_tris && ok.mesh_gen == key.mesh_gen && ok.quick == key.quick &&
+                            std::abs(ok.max_w - key.max_w) * 16 <= ok.max_w && std::abs(ok.max_h - key.max_h) * 16 <= ok.max_h &&
+                            c->layout_age < 256;
+    if (same_shape) {
+        cover = c->pw_cover; tri_rows = c->pw_tri_rows; group_tris = c->pw_group_tris; shear = c->pw_shear;
+        c->layout_age++;
+    } else if (quick) {
         // small frames of a dense mesh (the README's 400x400 / 23 000-triangle benchmark): walking every triangle on the host
         // would cost more than the frame (and the forward paths, which only need the per-triangle solves, skip the walk); guess the row density from the triangle count (the span lists grow if it was low)
         cover = (int)(2.5 * std::sqrt((double)c->n_tris));
@@ -792,7 +857,10 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
         tri_rows = 64.0;
     } else {
         cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear);
+        c->pw_layout_walks++;
     }
+    if (!same_shape) { c->layout_key = key; c->layout_age = 0; }
+    c->pw_tri_rows = tri_rows; c->pw_group_tris = group_tris;
     c->pw_cover = cover;
     c->pw_spans_per_window = max_w > 0 ? (double)cover * 256.0 / (double)max_w : 0.0;
     c->pw_row_group = cover <= 56 ? kRowGroup : 1;
@@ -826,8 +894,8 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
     if (cover > 200 && c->row_cap < kRowSpanCapDense) c->row_cap = kRowSpanCapDense;
-    c->rows_clean = false;                                   // new geometry: the counter layout changes
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // (the row counters and the status ring are reused as they are when their layout -- frame count, rows per frame, list
+    //  capacity, entry format -- is that of the previous set: run_setup())
     c->pw_setup_done = false;
     return HG_OK;
 }
@@ -914,10 +982,13 @@ static int run_setup(hg_ctx *c)
         // for the first step after new frames (or after a setup whose warp never ran): k_pw_rows leaves the counters and
         // the next status set zeroed for the step that follows it.
         const int32_t *before = c->d_rowcnt;
+        if (F * rl.row_stride + kStatusRing * F > c->rowcnt_cap ||
+            F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt)) > c->rowent_cap) HG_TRY(hg_sync(c));   // (queued runs flag into the old ring)
         HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, F * rl.row_stride + kStatusRing * F));
         HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt))));
         rl = rows_of(c);
-        if (before != c->d_rowcnt) c->rows_clean = false;
+        if (before != c->d_rowcnt || c->rows_F != F || c->rows_stride != rl.row_stride || c->rows_cap != rl.cap) c->rows_clean = false;
+        c->rows_F = F; c->rows_stride = rl.row_stride; c->rows_cap = rl.cap;
         if (c->rows_clean) c->status_slot = (c->status_slot + 1) % (int)kStatusRing;
         else {
             HG_TRY(hg_sync(c));                              // (queued runs still own status sets)
@@ -930,6 +1001,7 @@ static int run_setup(hg_ctx *c)
         c->rows_clean = false;                               // dirty until the warp kernel has consumed them
         launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
     } else {
+        HG_TRY(hg_sync(c));                                  // (queued fast-path runs are settled against their own status ring first)
         c->status_ptr = c->d_status;
         HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * F, c->stream));
         launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
@@ -973,6 +1045,42 @@ static int run_frame_via_map(hg_ctx *c, int f, uint8_t *d_out)
     return HG_OK;
 }
 
+// Deferred redo: frame f of the staged set `stage` (the set a queued run warped; newer sets may have been uploaded since)
+// through the materialised map, into `d_out` at the frame's own offset.  Self-contained: the frame's window and points go from
+// the staging buffer to a one-frame scratch, k_tri_setup solves it there, then rasteriser + pixel loop.  Mesh and source
+// image are those of the context (changing either settles queued runs first).
+static int redo_frame_staged(hg_ctx *c, int stage, int f, uint8_t *d_out)
+{
+    const hg_ctx::Stage &st = c->stage[stage];
+    if (stage < 0 || !st.h || f >= st.n || st.n_pts != c->n_pts) return fail(c, HG_ERR_STATE, "deferred redo: the staged frame set is gone");
+    const FrameDesc fd = reinterpret_cast<const FrameDesc *>(st.h)[f];
+    const size_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h : 0;
+    if (n == 0) return HG_OK;
+    const size_t T = (size_t)std::max(c->n_tris, 1);
+    HG_TRY(ensure(c, c->d_redo_frame, c->redo_frame_cap, (size_t)1));
+    HG_TRY(ensure(c, c->d_redo_dst, c->redo_dst_cap, (size_t)c->n_pts * 2));
+    HG_TRY(ensure(c, c->d_redo_trir, c->redo_trir_cap, T));
+    HG_TRY(ensure(c, c->d_redo_segs, c->redo_segs_cap, T * 3));
+    HG_TRY(ensure(c, c->d_redo_fwd, c->redo_fwd_cap, T * 6));
+    HG_TRY(ensure(c, c->d_redo_inv, c->redo_inv_cap, T * kInvStride));
+    HG_TRY(ensure(c, c->d_redo_status, c->redo_status_cap, (size_t)1));
+    HG_TRY(ensure(c, c->d_map32, c->map32_cap, n));
+    const float *pts = reinterpret_cast<const float *>(st.h + sizeof(FrameDesc) * (size_t)st.n) + (size_t)f * c->n_pts * 2;
+    HIP_TRY(c, hipMemcpyAsync(c->d_redo_frame, st.h + sizeof(FrameDesc) * (size_t)f, sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_redo_dst, pts, sizeof(float) * 2 * c->n_pts, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_redo_status, 0, sizeof(int32_t), c->stream));
+    PwMesh mesh = mesh_of(c);
+    mesh.img = frame_img(mesh, f); mesh.n_imgs = 1;          // this frame's own source
+    PwFrames fr = frames_of(c);
+    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
+    fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
+    launch_tri_setup(mesh, fr, c->stream);
+    launch_map_build(mesh, fr, 0, fd, c->d_map32, c->stream);
+    launch_pw_from_map(mesh, fr, 0, fd, c->d_map32, d_out, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
 extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
 {
     HG_TRY(bind(c));
@@ -986,11 +1094,11 @@ extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
     run_warp(c, static_cast<uint8_t *>(d_out), nullptr);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
-    if (c->pw_fast) c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), c->status_slot});
+    if (c->pw_fast) c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), c->status_slot, c->stage_cur});
     else {                                                   // general path: one status set, checked right away
         HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
         c->status_base = nullptr;
-        c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), 0});
+        c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), 0, c->stage_cur});
         HG_TRY(hg_sync(c));
     }
     return HG_OK;
@@ -1006,16 +1114,19 @@ extern "C" int hg_sync(hg_ctx *c)
         std::vector<hg_ctx::Pending> pending;
         pending.swap(c->pw_pending_out);
         bool redo = false;
-        const size_t F = c->pw_frames.size();
+        // (all queued runs share one layout of the status ring: a set with another frame count settles them before it runs)
+        const int st0 = pending.front().stage;
+        const size_t F = (st0 >= 0 && c->stage[st0].h) ? (size_t)c->stage[st0].n : c->pw_frames.size();
         if (c->status_base) HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
         for (const hg_ctx::Pending &p : pending)
             for (size_t f = 0; f < F; f++)
-                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; HG_TRY(run_frame_via_map(c, (int)f, p.out)); }
+                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; HG_TRY(redo_frame_staged(c, p.stage, (int)f, p.out)); }
         if (redo) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->pw_used_patch) c->pw_patch_disabled = true;   // (its limits are tighter than k_pw_rows': do not pay the map path again)
             if (c->pw_fast && c->row_cap < kRowSpanCapDense)      // denser mesh than assumed: larger lists next time
                 c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
+            c->layout_age = 1 << 30;                             // ... and a fresh layout estimate for the next frame set
         }
     }
     if (c->fwd_pending.n > 0) {

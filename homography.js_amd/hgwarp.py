@@ -35,7 +35,7 @@ EXPORTS = [
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
     "hg_warp_forward_geometric", "hg_warp_forward_piecewise", "hg_warp_forward_geometric_device", "hg_warp_forward_geometric_batch_device",
     "hg_warp_forward_piecewise_device", "hg_warp_forward_piecewise_batch_device",
-    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_layout_walks", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range",
 ]
 
 
@@ -95,7 +95,7 @@ def lib():
         "hg_warp_inverse_piecewise_batch_device": (i, [vp, f32p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
         "hg_get_tri_map": (i, [vp, C.POINTER(C.c_int16), sz]), "hg_get_tri_map_fused": (i, [vp, C.POINTER(C.c_int16), sz]),
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
-        "hg_last_piecewise_kernel": (i, [vp]), "hg_last_forward_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]), "hg_xcc_count": (i, [vp]),
+        "hg_last_piecewise_kernel": (i, [vp]), "hg_last_forward_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]), "hg_layout_walks": (C.c_long, [vp]), "hg_xcc_count": (i, [vp]),
         "hg_selftest_division": (i, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
         "hg_projective_plain_range": (i, [f64p, Geom]), "hg_forward_tiles_admissible": (i, [i, f64p, i, i, Geom]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
@@ -295,6 +295,10 @@ class Context:
         """Frames redone through the materialised map since the context was created."""
         return lib().hg_redone_frames(self._h)
 
+    def layout_walks(self):
+        """Host walks over the triangles of a frame set (layout estimates) since the context was created."""
+        return lib().hg_layout_walks(self._h)
+
     def xcc_count(self):
         """XCCs the warp kernels' block id -> row band mapping assumes (read from the device at creation, or option 'xcc')."""
         return lib().hg_xcc_count(self._h)
@@ -437,6 +441,17 @@ class Context:
         assert d.size == 2 * self._n_pts * len(geoms), "frames x mesh points x,y pairs"
         offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
         self._c(lib().hg_piecewise_set_frames(self._h, dp, _geoms(geoms), offs, len(geoms)))
+
+    def frame_set_args(self, dst_pts, geoms, offsets=None):
+        """The ctypes arguments of piecewise_set_frames, built once: a caller that uploads one of a few point sets per step
+        (bench.py --points fresh) then pays only the C call.  Returns an opaque tuple for piecewise_set_frames_prepared."""
+        d, dp = _f32(dst_pts)
+        assert d.size == 2 * self._n_pts * len(geoms), "frames x mesh points x,y pairs"
+        offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
+        return (d, dp, _geoms(geoms), offs, len(geoms))
+
+    def piecewise_set_frames_prepared(self, args):
+        self._c(lib().hg_piecewise_set_frames(self._h, args[1], args[2], args[3], args[4]))
 
     def warp_inverse_piecewise_frames_device(self, d_out):
         self._c(lib().hg_warp_inverse_piecewise_frames_device(self._h, C.c_void_p(int(d_out))))

@@ -165,7 +165,12 @@ int hg_warp_inverse_piecewise(hg_ctx *ctx, uint8_t *out_host);
 int hg_warp_inverse_piecewise_device(hg_ctx *ctx, void *d_out);
 /* F frames (F destination point sets on the mesh set above) in one pass: dst_points = F x n_points x 2 float32.
  * set_frames uploads points + windows (kept until replaced; hg_piecewise_prepare == set_frames with one frame);
- * frames_device runs the per-frame solves and the warp for all uploaded frames; batch_device = both. */
+ * frames_device runs the per-frame solves and the warp for all uploaded frames; batch_device = both.
+ * set_frames does NOT wait for the GPU (the reference's loop calls setDestinyPoints before every warp, test/benchmark.js:107-110,
+ * Homography.js:337-380): the caller's arrays are copied into page-locked staging owned by the ctx before it returns, the
+ * uploads are ordered behind the queued runs on the ctx stream, and every queued run keeps the staged copy of the set it
+ * warped, so that frames it flagged can still be redone by hg_sync after newer sets went up.  Up to 63 set / run pairs
+ * queue between two hg_sync calls; the 64th settles the queue by itself. */
 int hg_piecewise_set_frames(hg_ctx *ctx, const float *dst_points, const hg_geom *geoms, const size_t *out_offsets, int n_frames);
 int hg_warp_inverse_piecewise_frames_device(hg_ctx *ctx, void *d_out);
 int hg_warp_inverse_piecewise_batch_device(hg_ctx *ctx, const float *dst_points, const hg_geom *geoms,
@@ -246,6 +251,9 @@ int hg_forward_tiles_admissible(int kind, const double *m, int W, int H, hg_geom
 /* Frames the fused kernels only flagged (row lists / kernel limits exceeded, irregular spans) and hg_sync redid through the
  * materialised map, since the ctx was created (tests / profiling: a steady-state workload should show 0). */
 long hg_redone_frames(hg_ctx *ctx);
+/* Host-side walks over every triangle of a frame set (the layout estimate of hg_piecewise_set_frames) since the ctx was created:
+ * a caller that uploads fresh points of one mesh and window shape per step should see this stand still. */
+long hg_layout_walks(hg_ctx *ctx);
 /* Layout knobs of the piecewise fast path; they never change results (tests run the parity suite under each setting), only
  * which kernel layout the next hg_piecewise_set_frames picks:
  *   "min_row_groups" (default 1536): frame sets with fewer 4-row groups run one row per workgroup;

@@ -692,6 +692,59 @@ def test_irregular_and_overflow_frames_fall_back_to_map_path(ctx):
     assert np.array_equal(ctx.warp_inverse_piecewise_via_map(), want2)
 
 
+def test_fresh_point_sets_queue_without_settling_and_redo_from_their_own_set(ctx):
+    """The reference's loop uploads new destination points before every warp (test/benchmark.js:107-110).  Here sets and runs
+    are queued back to back with no sync in between, into different outputs; set 1 is a mesh too dense for the row lists (its
+    frames are flagged and redone through the map path at hg_sync -- by then two newer sets have been uploaded, so the redo has
+    to come from the staged copy of ITS set).  Every output matches the oracle; the layout estimate is walked once per shape."""
+    W, H, nx, ny = 512, 96, 8, 4
+    img = G.lcg_image(W, H, 77)
+    sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+    ms = WL.src_min(sp)
+    sets = [[WL.sin_dst(sp, 3.0 + s, 8 + f) for f in range(3)] for s in range(4)]
+    # set 1: fold the mesh so that every row is crossed by far more spans than the lists hold (-> flagged, redone)
+    folded = []
+    for f in range(3):
+        d = sets[1][f].copy().reshape(-1, 2)
+        d[:, 0] = (d[:, 0] * 37.0) % 97.0 + 0.25 * f          # x scrambled into [0, 97): hundreds of sliver spans per row
+        folded.append(d.ravel().astype(np.float32))
+    sets[1] = folded
+    ctx.set_image(img)
+    ctx.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+    geoms = [[WL.piecewise_geom(d) for d in fs] for fs in sets]
+    packs = [HG.pack_offsets(g) for g in geoms]
+    outs = [ctx.alloc(total) for _, total in packs]
+    try:
+        ctx.sync()
+        walks0, redone0 = ctx.layout_walks(), ctx.redone_frames()
+        for s in range(4):
+            ctx.piecewise_set_frames(np.concatenate(sets[s]), geoms[s], packs[s][0])
+            ctx.warp_inverse_piecewise_frames_device(outs[s])
+        ctx.sync()
+        for s in range(4):
+            for f, g in enumerate(geoms[s]):
+                want = O.warp_inverse_piecewise(sp, sets[s][f], tris, img, ms[0], ms[1], *g)
+                got = ctx.to_host(outs[s], g[2] * g[3] * 4, packs[s][0][f]).reshape(g[3], g[2], 4)
+                assert np.array_equal(got, want), (s, f)
+        assert ctx.layout_walks() - walks0 <= 4
+        # the same sets again, resident shapes: sets 0, 2, 3 share a window shape -> at most one more walk each for 0 and 1
+        w1 = ctx.layout_walks()
+        for _ in range(3):
+            for s in (0, 2, 3):
+                ctx.piecewise_set_frames(np.concatenate(sets[s]), geoms[s], packs[s][0])
+                ctx.warp_inverse_piecewise_frames_device(outs[s])
+        ctx.sync()
+        assert ctx.layout_walks() - w1 <= 1, ctx.layout_walks() - w1
+        for s in (0, 2, 3):
+            for f, g in enumerate(geoms[s]):
+                want = O.warp_inverse_piecewise(sp, sets[s][f], tris, img, ms[0], ms[1], *g)
+                got = ctx.to_host(outs[s], g[2] * g[3] * 4, packs[s][0][f]).reshape(g[3], g[2], 4)
+                assert np.array_equal(got, want), (s, f)
+    finally:
+        for o in outs:
+            ctx.free(o)
+
+
 def test_empty_and_degenerate_inputs(ctx):
     img = G.lcg_image(32, 24, 3)
     ctx.set_image(img)
