@@ -150,6 +150,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback to measure)")
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    hgdist = _load("hg_dist", os.path.join(PKG, "dist.py"))
+    n_devices = torch.cuda.device_count()
+    try:
+        hgdist.check_launch(world, rank, local_rank, n_devices)      # one rank per GPU of ONE node: a mis-launch is loud
+    except RuntimeError as e:
+        raise SystemExit(f"bench.py: {e}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -158,7 +164,6 @@ def main():
 
     hg = _load("hgwarp", os.path.join(PKG, "hgwarp.py"))
     wl = _load("hg_workloads", os.path.join(PKG, "workloads.py"))
-    hgdist = _load("hg_dist", os.path.join(PKG, "dist.py"))
     cfg = wl.CONFIGS[args.config]
     W, H, F = cfg["W"], cfg["H"], args.frames
     do_shared, do_distinct = args.sources in ("both", "shared"), args.sources in ("both", "distinct")
@@ -168,22 +173,13 @@ def main():
     if rank == 0:
         img_t.copy_(torch.from_numpy(wl.lcg_image(W, H, 1)))
     torch.cuda.synchronize()
-    broadcast_ms = 0.0
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        img_t = hgdist.broadcast_source(img_t, rank, world, dist, verify=False)
-        torch.cuda.synchronize()
-        broadcast_ms = (time.perf_counter() - t0) * 1e3
-        hgdist.verify_replicas(img_t, dist)                 # untimed: every rank holds the same bytes, or this raises
-
     stream = torch.cuda.Stream(device=dev)
     ctx = hg.Context(local_rank, stream=stream.cuda_stream)
-    ctx.set_image_device(img_t.data_ptr(), W, H)
+    if world == 1:
+        ctx.set_image_device(img_t.data_ptr(), W, H)         # (N > 1: attached below, once the broadcast has delivered it)
 
     piecewise = cfg["kind"] in ("piecewise", "face")
-    frame_ids = [rank * F + f for f in range(F)]            # different ranks get different frames of the same sequence
+    frame_ids = hgdist.rank_frame_ids(rank, F)              # different ranks get different frames of the same sequence
     if piecewise:
         if cfg["kind"] == "face":
             sp = wl.face_mesh(W, H, cfg["landmarks"])
@@ -240,6 +236,40 @@ def main():
         total = max([total] + [fs["total"] for fs in fresh_sets])
     out_t = torch.empty(total, dtype=torch.uint8, device=dev)
     d_out = out_t.data_ptr()
+
+    # ---------------------------------------------------------------- N > 1: the one exchange of the job, untimed
+    # Shared source texture, rank 0 -> everybody: scatter of 1/N slices + all-gather, so that every xGMI link carries 1/N of
+    # the image.  The root does not wait for it: it already holds the image, so its first step is queued on the warp stream
+    # BEFORE the collectives start on torch's stream and runs under them (`broadcast_hidden_ms` = how much of the two
+    # overlapped); the other ranks attach the texture when it has arrived.
+    broadcast = None
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        t0 = time.perf_counter()
+        if rank == 0:
+            ctx.set_image_device(img_t.data_ptr(), W, H)
+            ev[0].record(stream)
+            run(d_out)                                       # the root's first frames, under the fan-out
+            ev[1].record(stream)
+        ev[2].record()
+        img_full = hgdist.broadcast_source(img_t, rank, world, dist, verify=False)
+        ev[3].record()
+        torch.cuda.synchronize()
+        span_ms = (time.perf_counter() - t0) * 1e3
+        b_ms = ev[2].elapsed_time(ev[3])
+        s_ms = ev[0].elapsed_time(ev[1]) if rank == 0 else 0.0
+        ctx.sync()
+        img_t = img_full
+        hgdist.verify_replicas(img_t, dist)                 # untimed: every rank holds the same bytes, or this raises
+        ctx.set_image_device(img_t.data_ptr(), W, H)
+        bt = torch.tensor([b_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+        broadcast = {"broadcast_ms": round(float(bt.item()), 3), "root_first_step_ms": round(s_ms, 3), "root_span_ms": round(span_ms, 3),
+                     "broadcast_hidden_ms": round(max(0.0, min(b_ms, s_ms, b_ms + s_ms - span_ms)), 3) if rank == 0 else None,
+                     "image_bytes": int(W * H * 4)}
+    broadcast_ms = broadcast["broadcast_ms"] if broadcast else 0.0
     n_out = [g[2] * g[3] for g in geoms]
     px_per_step = float(sum(n_out))
 
@@ -288,13 +318,15 @@ def main():
         elapsed = time.perf_counter() - t0
         k_total_ms, k_launches = ctx.kernel_ms_stats()
         ctx.set_timing(False)
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed, k_total_ms / max(k_launches, 1), k_launches
+        k_ms = k_total_ms / max(k_launches, 1)
+        # MAX of the elapsed time over ranks, SUM of the pixels, min / max of the kernel time (homography.js_amd/dist.py; the same
+        # function runs over gloo in tests/test_dist_cpu.py)
+        agg = hgdist.aggregate_step_stats(dist, world, dev, elapsed, px_per_step, k_ms, True)
+        region_stats.append(agg)
+        return agg["elapsed_s"], k_ms, k_launches
 
     kernel_name = None
+    region_stats = []
 
     def roofline_block(k_ms, launches, sources):
         achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -495,7 +527,9 @@ def main():
                            "frames_per_gpu_per_step": F, "point_sets": pts_txt,
                            "output_pixels_per_step_per_gpu": int(px_per_step), "sources": primary,
                            "parallelism": f"frames sharded over {world} GPU(s); shared source broadcast once (scatter+all_gather over RCCL)",
-                           "broadcast_ms": round(broadcast_ms, 3)},
+                           "broadcast_ms": round(broadcast_ms, 3), "broadcast": broadcast, "gpus_on_node": n_devices,
+                           "kernel_ms_over_ranks": {"min": round(region_stats[0]["kernel_ms_min"], 5), "max": round(region_stats[0]["kernel_ms_max"], 5),
+                                                    "by_rank": [round(v, 5) for v in region_stats[0]["kernel_ms_by_rank"]]} if region_stats else None},
                 "verified": None if args.no_verify else verified, "checks": checks,
                 "roofline": roofline, "roofline_fresh": fresh, "roofline_distinct": res["distinct"][1] if "distinct" in res and primary != "distinct" else None,
                 "cpu_baseline": cpu}

@@ -288,6 +288,27 @@ extern "C" int hg_copy_to_host_async(hg_ctx *c, void *dst, const void *src, size
     return HG_OK;
 }
 
+// The same copy WITHOUT settling queued runs first: purely stream-ordered.  For callers that queue the copies of several devices
+// before waiting for any of them (hg_multi_*): frames a fused run only flagged are rewritten by the later hg_sync, after which
+// the caller copies them again (hg_redone_frames tells).
+extern "C" int hg_enqueue_copy_to_host(hg_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HG_TRY(bind(c));
+    if (!dst || !src) return fail(c, HG_ERR_INVALID, "NULL pointer");
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return HG_OK;
+}
+
+// Everything queued on the ctx stream after this call waits for `hip_event` (a hipEvent_t recorded on any stream of any
+// device): lets a caller order warps behind its own uploads / peer copies without blocking the host.
+extern "C" int hg_stream_wait_event(hg_ctx *c, void *hip_event)
+{
+    HG_TRY(bind(c));
+    if (!hip_event) return fail(c, HG_ERR_INVALID, "event is NULL");
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, static_cast<hipEvent_t>(hip_event), 0));
+    return HG_OK;
+}
+
 // Pinned (page-locked, portable across devices) host memory for frames that leave the GPU: DMA at full PCIe rate without
 // the runtime's staging copy, and no first-touch page faults once the buffer is being reused.
 extern "C" int hg_host_alloc(size_t bytes, void **p)
@@ -1346,6 +1367,7 @@ extern "C" int hg_warp_forward_geometric_batch_device(hg_ctx *c, int kind, const
     HG_TRY(bind(c));
     if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m || !geoms || n <= 0 || !d_out) return fail(c, HG_ERR_INVALID, "hg_warp_forward_geometric: bad arguments");
     if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    if (c->n_imgs > 1) return fail(c, HG_ERR_STATE, "the forward warps take ONE source image (hg_set_images_device with n_images > 1 serves the inverse warps only)");
     HG_TRY(forward_limits(c, c->W, c->H, "the source image"));
     std::vector<FrameDesc> fds;
     HG_TRY(fill_frames(c, fds, geoms, offs, n));
@@ -1456,6 +1478,7 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
     HG_TRY(bind(c));
     if (!dst_points || !geoms || n <= 0 || !d_out) return fail(c, HG_ERR_INVALID, "hg_warp_forward_piecewise: bad arguments");
     if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    if (c->n_imgs > 1) return fail(c, HG_ERR_STATE, "the forward warps take ONE source image (hg_set_images_device with n_images > 1 serves the inverse warps only)");
     if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
     const int64_t map_w = (int64_t)max_src_x - c->min_src_x, map_h = (int64_t)max_src_y - c->min_src_y;
     HG_TRY(forward_limits(c, map_w, map_h, "the source-point bounding box"));

@@ -15,6 +15,7 @@
 #include "../../include/hgwarp.h"
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -24,7 +25,9 @@ struct hg_multi {
         hg_ctx *ctx = nullptr;
         hipStream_t copy = nullptr;              // fan-out / gather stream of this device
         hipEvent_t have_slice = nullptr;         // this device's own slice of the source has arrived
+        hipEvent_t have_image = nullptr;         // the whole source has arrived on this device (its warps wait for this, the host does not)
         uint8_t *d_img = nullptr; size_t img_cap = 0;
+        uint8_t *d_imgs = nullptr; size_t imgs_cap = 0;   // per-frame sources of this device's block (hg_multi_*_images)
         uint8_t *d_out = nullptr; size_t out_cap = 0;
         int first = 0, count = 0;                // frames of the current batch
         std::vector<size_t> offs;                // their byte offsets in d_out
@@ -71,8 +74,10 @@ extern "C" void hg_multi_destroy(hg_multi *m)
             (void)hipSetDevice(d.id);
             if (d.copy) { (void)hipStreamSynchronize(d.copy); (void)hipStreamDestroy(d.copy); }
             if (d.have_slice) (void)hipEventDestroy(d.have_slice);
+            if (d.have_image) (void)hipEventDestroy(d.have_image);
             hg_destroy(d.ctx);                   // (drops its alias of d_img first)
             if (d.d_img) (void)hipFree(d.d_img);
+            if (d.d_imgs) (void)hipFree(d.d_imgs);
             if (d.d_out) (void)hipFree(d.d_out);
         }
     }
@@ -92,7 +97,8 @@ extern "C" int hg_multi_create(const int *device_ids, int n_devices, hg_multi **
         int rc = hg_create(d.id, &d.ctx);
         if (rc != HG_OK) { const std::string why = hg_last_error(nullptr); hg_multi_destroy(m); return mfail(nullptr, rc, why); }
         if (hipSetDevice(d.id) != hipSuccess || hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&d.have_slice, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&d.have_slice, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d.have_image, hipEventDisableTiming) != hipSuccess) {
             hg_multi_destroy(m);
             return mfail(nullptr, HG_ERR_HIP, "hg_multi_create: stream / event creation failed");
         }
@@ -148,10 +154,13 @@ extern "C" int hg_multi_set_image(hg_multi *m, const uint8_t *rgba, int w, int h
     auto &root = m->devs[0];
     MHIP(m, hipSetDevice(root.id));
     if (G == 1 || !m->peer) {
-        for (auto &d : m->devs) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipMemcpyAsync(d.d_img, rgba, bytes, hipMemcpyHostToDevice, d.copy)); }
+        for (auto &d : m->devs) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipMemcpyAsync(d.d_img, rgba, bytes, hipMemcpyHostToDevice, d.copy)); MHIP(m, hipEventRecord(d.have_image, d.copy)); }
+        // caller memory is not retained: every H2D has left the host buffer before this returns
+        for (auto &d : m->devs) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipStreamSynchronize(d.copy)); }
     } else {
         MHIP(m, hipMemcpyAsync(root.d_img, rgba, bytes, hipMemcpyHostToDevice, root.copy));
         MHIP(m, hipEventRecord(root.have_slice, root.copy));
+        MHIP(m, hipEventRecord(root.have_image, root.copy));
         // slices: 4-byte aligned, the last one takes the remainder
         const size_t slice = ((bytes / G) + 3) & ~(size_t)3;
         auto lo = [&](int k) { return std::min(bytes, slice * (size_t)k); };
@@ -175,10 +184,18 @@ extern "C" int hg_multi_set_image(hg_multi *m, const uint8_t *rgba, int w, int h
                 MHIP(m, hipStreamWaitEvent(dq.copy, dp.have_slice, 0));
                 MHIP(m, hipMemcpyPeerAsync(dq.d_img + lo(p), dq.id, dp.d_img + lo(p), dp.id, hi(p) - lo(p), dq.copy));
             }
+            MHIP(m, hipEventRecord(dq.have_image, dq.copy));
         }
+        // The host waits for the H2D only (caller memory is not retained).  The fan-out over xGMI keeps running: every
+        // device's warp stream waits for ITS have_image event, so the root's first frames overlap the scatter + all-gather
+        //  instead of queueing behind a host-side barrier.
+        MHIP(m, hipSetDevice(root.id));
+        MHIP(m, hipEventSynchronize(root.have_image));
     }
-    for (auto &d : m->devs) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipStreamSynchronize(d.copy)); }
-    for (auto &d : m->devs) MHG(m, d.ctx, hg_set_image_device(d.ctx, d.d_img, w, h));
+    for (auto &d : m->devs) {
+        MHG(m, d.ctx, hg_set_image_device(d.ctx, d.d_img, w, h));
+        MHG(m, d.ctx, hg_stream_wait_event(d.ctx, d.have_image));
+    }
     m->W = w; m->H = h;
     return HG_OK;
 }
@@ -195,25 +212,81 @@ extern "C" int hg_multi_piecewise_set_mesh(hg_multi *m, const float *src_points,
 // The caller loop for F frames over all devices: device i warps the contiguous block hg_multi_partition gives it, all
 // devices at once.  Frames stay resident (hg_multi_frame) unless out_host is given: then out_host[f] receives frame f
 // (4*obj_w*obj_h bytes; pinned memory from hg_host_alloc makes the copies of different devices overlap).
-static int multi_batch_impl(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host);
-
-extern "C" int hg_multi_warp_piecewise_batch(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
+static void reset_partition(hg_multi *m)
 {
-    const int rc = multi_batch_impl(m, dst_points, geoms, n_frames, out_host);
-    if (rc != HG_OK && m) {                                  // nothing may still be writing into the caller's buffers when an error is reported
-        const std::string why = m->err;
-        for (auto &d : m->devs) if (d.ctx) (void)hg_sync(d.ctx);
-        m->err = why; g_merr = why;
-    }
-    return rc;
+    for (auto &d : m->devs) { d.first = 0; d.count = 0; d.offs.assign(1, 0); }
+    m->geoms.clear();
 }
 
-static int multi_batch_impl(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
+// one source per frame ("replicas only", SURVEY.md §8e / README.md:121-137): device i receives the images of ITS block only
+static int upload_block_images(hg_multi *m, hg_multi::Dev &d, const uint8_t *const *images, int w, int h)
+{
+    const size_t bytes = (size_t)w * h * 4;
+    MHG(m, d.ctx, hg_sync(d.ctx));                           // queued warps still read the previous sources
+    if (bytes * (size_t)d.count > d.imgs_cap) {
+        MHIP(m, hipSetDevice(d.id));
+        void *q = nullptr;
+        if (hipMalloc(&q, bytes * (size_t)d.count) != hipSuccess) return mfail(m, HG_ERR_NOMEM, "hg_multi: hipMalloc of the per-frame sources failed");
+        const int rc = hg_set_images_device(d.ctx, q, w, h, d.count, bytes);     // the context's alias moves first
+        if (rc != HG_OK) { (void)hipFree(q); return mfail(m, rc, hg_last_error(d.ctx)); }
+        if (d.d_imgs) MHIP(m, hipFree(d.d_imgs));
+        d.d_imgs = static_cast<uint8_t *>(q); d.imgs_cap = bytes * (size_t)d.count;
+    }
+    MHIP(m, hipSetDevice(d.id));
+    for (int k = 0; k < d.count; k++) {
+        if (!images[d.first + k]) return mfail(m, HG_ERR_INVALID, "hg_multi: images[f] is NULL");
+        MHIP(m, hipMemcpyAsync(d.d_imgs + bytes * (size_t)k, images[d.first + k], bytes, hipMemcpyHostToDevice, d.copy));
+    }
+    MHIP(m, hipEventRecord(d.have_image, d.copy));
+    return HG_OK;
+}
+
+// frames leave the devices: the copies of EVERY device are queued (each behind its own kernels) before any device is waited
+// for; a device whose settlement then redid frames through the map path gets those frames copied again.
+static int drain_to_host(hg_multi *m, const hg_geom *geoms, uint8_t *const *out_host)
+{
+    std::vector<long> redone0(m->devs.size(), 0);
+    if (out_host) {
+        for (size_t i = 0; i < m->devs.size(); i++) {
+            auto &d = m->devs[i];
+            redone0[i] = hg_redone_frames(d.ctx);
+            for (int k = 0; k < d.count; k++) {
+                const hg_geom &g = geoms[d.first + k];
+                const size_t bytes = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h * 4 : 0;
+                if (!bytes) continue;
+                if (!out_host[d.first + k]) return mfail(m, HG_ERR_INVALID, "hg_multi: out_host[f] is NULL");
+                MHG(m, d.ctx, hg_enqueue_copy_to_host(d.ctx, out_host[d.first + k], d.d_out + d.offs[k], bytes));
+            }
+        }
+    }
+    for (size_t i = 0; i < m->devs.size(); i++) {
+        auto &d = m->devs[i];
+        if (!d.count) continue;
+        MHG(m, d.ctx, hg_sync(d.ctx));
+        if (out_host && hg_redone_frames(d.ctx) != redone0[i]) {         // rare: flagged frames were rewritten after their copy
+            for (int k = 0; k < d.count; k++) {
+                const hg_geom &g = geoms[d.first + k];
+                const size_t bytes = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h * 4 : 0;
+                if (bytes) MHG(m, d.ctx, hg_enqueue_copy_to_host(d.ctx, out_host[d.first + k], d.d_out + d.offs[k], bytes));
+            }
+            MHG(m, d.ctx, hg_sync(d.ctx));
+        }
+    }
+    return HG_OK;
+}
+
+// The caller loop for F frames over all devices: device i warps the contiguous block hg_multi_partition gives it, all
+// devices at once.  Frames stay resident (hg_multi_frame) unless out_host is given: then out_host[f] receives frame f
+// (4*obj_w*obj_h bytes; pinned memory from hg_host_alloc makes the copies of different devices overlap).
+// images != NULL: one source per frame, images[f] = width x height RGBA8 on the host; every device uploads its own block.
+static int multi_batch_impl(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, const uint8_t *const *images, int w, int h,
+                            uint8_t *const *out_host)
 {
     if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
+    reset_partition(m);                                      // (a failure below must not leave the previous batch's blocks behind)
     if (!dst_points || !geoms || n_frames <= 0) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_piecewise_batch: bad arguments");
     if (m->n_pts <= 0) return mfail(m, HG_ERR_STATE, "no mesh: call hg_multi_piecewise_set_mesh first");
-    if (m->W <= 0) return mfail(m, HG_ERR_STATE, "no source image: call hg_multi_set_image first");
+    if (images ? (w <= 0 || h <= 0) : m->W <= 0) return mfail(m, HG_ERR_STATE, images ? "bad per-frame image size" : "no source image: call hg_multi_set_image first");
     const int G = (int)m->devs.size();
     m->geoms.assign(geoms, geoms + n_frames);
     // 1. enqueue every device's share (asynchronous: all devices compute at the same time)
@@ -225,31 +298,53 @@ static int multi_batch_impl(hg_multi *m, const float *dst_points, const hg_geom 
         size_t total = 0;
         MHG(m, nullptr, hg_pack_offsets(geoms + d.first, d.count, d.offs.data(), &total));
         MHG(m, d.ctx, ensure_dev(m, d, d.d_out, d.out_cap, std::max<size_t>(total, 256)));
+        if (images) {
+            MHG(m, d.ctx, upload_block_images(m, d, images, w, h));
+            MHG(m, d.ctx, hg_set_images_device(d.ctx, d.d_imgs, w, h, d.count, (size_t)w * h * 4));
+            MHG(m, d.ctx, hg_stream_wait_event(d.ctx, d.have_image));
+        }
         MHG(m, d.ctx, hg_warp_inverse_piecewise_batch_device(d.ctx, dst_points + (size_t)d.first * m->n_pts * 2, geoms + d.first, d.offs.data(), d.count, d.d_out));
     }
-    // 2. frames leave the devices (each device's copies queue behind its own kernels; pinned destinations overlap)
-    if (out_host) {
-        for (auto &d : m->devs)
-            for (int k = 0; k < d.count; k++) {
-                const hg_geom &g = geoms[d.first + k];
-                const size_t bytes = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h * 4 : 0;
-                if (!bytes) continue;
-                if (!out_host[d.first + k]) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_piecewise_batch: out_host[f] is NULL");
-                MHG(m, d.ctx, hg_copy_to_host_async(d.ctx, out_host[d.first + k], d.d_out + d.offs[k], bytes));
-            }
+    if (images)                                              // caller memory is not retained: the H2D copies have left it
+        for (auto &d : m->devs) if (d.count) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipStreamSynchronize(d.copy)); }
+    // 2. + 3. frames leave the devices; settle (also redoes frames the fused path flagged)
+    return drain_to_host(m, geoms, out_host);
+}
+
+static int multi_fail_settle(hg_multi *m, int rc)
+{
+    if (rc != HG_OK && m) {                                  // nothing may still be writing into the caller's buffers when an error is reported
+        const std::string why = m->err;
+        for (auto &d : m->devs) if (d.ctx) (void)hg_sync(d.ctx);
+        reset_partition(m);
+        m->err = why; g_merr = why;
     }
-    // 3. settle (also redoes frames the fused path flagged, if frames stay resident)
-    for (auto &d : m->devs) if (d.count) MHG(m, d.ctx, hg_sync(d.ctx));
-    return HG_OK;
+    return rc;
+}
+
+extern "C" int hg_multi_warp_piecewise_batch(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
+{
+    return multi_fail_settle(m, multi_batch_impl(m, dst_points, geoms, n_frames, nullptr, 0, 0, out_host));
+}
+
+extern "C" int hg_multi_warp_piecewise_batch_images(hg_multi *m, const float *dst_points, const hg_geom *geoms, int n_frames,
+                                                    const uint8_t *const *images, int width, int height, uint8_t *const *out_host)
+{
+    if (!images) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_piecewise_batch_images: images is NULL");
+    const int rc = multi_fail_settle(m, multi_batch_impl(m, dst_points, geoms, n_frames, images, width, height, out_host));
+    if (m) { m->W = 0; m->H = 0; }                           // the shared image (hg_multi_set_image) is no longer what the contexts read
+    return rc;
 }
 
 // The same for affine / projective frames given as point sets (hg_geometric_set_frames_points: the per-frame solves run on each
 // device for its own block of frames).
-static int multi_geo_impl(hg_multi *m, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
+static int multi_geo_impl(hg_multi *m, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames,
+                          const uint8_t *const *images, int w, int h, uint8_t *const *out_host)
 {
     if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
+    reset_partition(m);
     if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !from || !to || !geoms || n_frames <= 0) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_geometric_batch: bad arguments");
-    if (m->W <= 0) return mfail(m, HG_ERR_STATE, "no source image: call hg_multi_set_image first");
+    if (images ? (w <= 0 || h <= 0) : m->W <= 0) return mfail(m, HG_ERR_STATE, images ? "bad per-frame image size" : "no source image: call hg_multi_set_image first");
     const int G = (int)m->devs.size();
     const size_t per = kind == HG_AFFINE ? 6 : 8;
     m->geoms.assign(geoms, geoms + n_frames);
@@ -261,37 +356,37 @@ static int multi_geo_impl(hg_multi *m, int kind, const float *from, const float 
         size_t total = 0;
         MHG(m, nullptr, hg_pack_offsets(geoms + d.first, d.count, d.offs.data(), &total));
         MHG(m, d.ctx, ensure_dev(m, d, d.d_out, d.out_cap, std::max<size_t>(total, 256)));
+        if (images) {
+            MHG(m, d.ctx, upload_block_images(m, d, images, w, h));
+            MHG(m, d.ctx, hg_set_images_device(d.ctx, d.d_imgs, w, h, d.count, (size_t)w * h * 4));
+            MHG(m, d.ctx, hg_stream_wait_event(d.ctx, d.have_image));
+        }
         MHG(m, d.ctx, hg_geometric_set_frames_points(d.ctx, kind, from + (size_t)d.first * per, to + (size_t)d.first * per, geoms + d.first, d.offs.data(), d.count));
         MHG(m, d.ctx, hg_warp_inverse_geometric_frames_device(d.ctx, d.d_out));
     }
-    if (out_host) {
-        for (auto &d : m->devs)
-            for (int k = 0; k < d.count; k++) {
-                const hg_geom &g = geoms[d.first + k];
-                const size_t bytes = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h * 4 : 0;
-                if (!bytes) continue;
-                if (!out_host[d.first + k]) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_geometric_batch: out_host[f] is NULL");
-                MHG(m, d.ctx, hg_copy_to_host_async(d.ctx, out_host[d.first + k], d.d_out + d.offs[k], bytes));
-            }
-    }
-    for (auto &d : m->devs) if (d.count) MHG(m, d.ctx, hg_sync(d.ctx));
-    return HG_OK;
+    if (images)
+        for (auto &d : m->devs) if (d.count) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipStreamSynchronize(d.copy)); }
+    return drain_to_host(m, geoms, out_host);
 }
 
 extern "C" int hg_multi_warp_geometric_batch(hg_multi *m, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames, uint8_t *const *out_host)
 {
-    const int rc = multi_geo_impl(m, kind, from, to, geoms, n_frames, out_host);
-    if (rc != HG_OK && m) {
-        const std::string why = m->err;
-        for (auto &d : m->devs) if (d.ctx) (void)hg_sync(d.ctx);
-        m->err = why; g_merr = why;
-    }
+    return multi_fail_settle(m, multi_geo_impl(m, kind, from, to, geoms, n_frames, nullptr, 0, 0, out_host));
+}
+
+extern "C" int hg_multi_warp_geometric_batch_images(hg_multi *m, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames,
+                                                    const uint8_t *const *images, int width, int height, uint8_t *const *out_host)
+{
+    if (!images) return mfail(m, HG_ERR_INVALID, "hg_multi_warp_geometric_batch_images: images is NULL");
+    const int rc = multi_fail_settle(m, multi_geo_impl(m, kind, from, to, geoms, n_frames, images, width, height, out_host));
+    if (m) { m->W = 0; m->H = 0; }
     return rc;
 }
 
 extern "C" int hg_multi_frame(hg_multi *m, int frame, int *device_index, void **d_ptr, size_t *bytes)
 {
     if (!m) return mfail(nullptr, HG_ERR_INVALID, "multi is NULL");
+    if (frame < 0 || (size_t)frame >= m->geoms.size()) return mfail(m, HG_ERR_INVALID, "hg_multi_frame: no such frame in the last batch");
     for (size_t i = 0; i < m->devs.size(); i++) {
         const auto &d = m->devs[i];
         if (frame >= d.first && frame < d.first + d.count) {

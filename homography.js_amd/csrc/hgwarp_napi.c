@@ -814,12 +814,43 @@ static napi_value fn_multi_set_mesh(napi_env env, napi_callback_info info)
     return NULL;
 }
 
-/* warpBatch over the device list: dst = F x 2N float32, geoms = Int32Array F x 4; returns an Array of F Uint8ClampedArray
+/* Optional per-frame sources of a multi-device batch: a JS array of n Uint8ClampedArray (width*height*4 each) -> F host pointers,
+ * frame f reads images[f % n] (the rule of setImages).  Returns 1 with *out = NULL when `v` is undefined / null (shared source). */
+static int get_frame_images(napi_env env, napi_value v, napi_value vw, napi_value vh, int F, const uint8_t ***out, int *w, int *hh)
+{
+    *out = NULL;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_undefined || t == napi_null) return 1;
+    bool is_arr = false; uint32_t n = 0;
+    if (napi_is_array(env, v, &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, v, &n) != napi_ok || n == 0) {
+        throw_str(env, "hgwarp: images must be a non-empty array of image data arrays"); return 0;
+    }
+    if (!get_i32(env, vw, w) || !get_i32(env, vh, hh)) return 0;
+    if (*w <= 0 || *hh <= 0) { throw_str(env, "hgwarp: bad image size"); return 0; }
+    const size_t bytes = (size_t)*w * (size_t)*hh * 4;
+    const uint8_t **ptrs = (const uint8_t **)calloc((size_t)F, sizeof *ptrs);
+    if (!ptrs) { throw_str(env, "hgwarp: out of memory"); return 0; }
+    for (int f = 0; f < F; f++) {
+        napi_value el; size_t len;
+        if (napi_get_element(env, v, (uint32_t)f % n, &el) != napi_ok) { free(ptrs); throw_str(env, "hgwarp: N-API call failed"); return 0; }
+        const uint8_t *px = (const uint8_t *)get_typed(env, el, napi_uint8_clamped_array, &len, "images[k]");
+        if (!px) { free(ptrs); return 0; }
+        if (len < bytes) { free(ptrs); throw_str(env, "hgwarp: an image is smaller than width*height*4"); return 0; }
+        ptrs[f] = px;
+    }
+    *out = ptrs;
+    return 1;
+}
+
+/* warpBatch over the device list: dst = F x 2N float32, geoms = Int32Array F x 4 [, images, width, height: one source per frame,
+ * every device uploads its own block]; returns an Array of F Uint8ClampedArray
  * (pooled pinned memory where possible, so that the D2H copies of different devices run at the same time). */
 static napi_value fn_multi_warp_batch(napi_env env, napi_callback_info info)
 {
-    napi_value a[3];
-    if (!get_args(env, info, 3, a)) return NULL;
+    napi_value a[6];
+    size_t argc = 6;
+    if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 3) return throw_str(env, "hgwarp: multiWarpBatch(multi, dstPoints, geoms[, images, width, height])");
     mhandle_t *h = get_mhandle(env, a[0]); if (!h) return NULL;
     size_t nd, ng;
     float *dst = (float *)get_typed(env, a[1], napi_float32_array, &nd, "dstPoints"); if (!dst) return NULL;
@@ -839,16 +870,20 @@ static napi_value fn_multi_warp_batch(napi_env env, napi_callback_info info)
         outs[f] = px ? (uint8_t *)out : &dummy;
         napi_set_element(env, arr, f, ta);
     }
-    int rc = hg_multi_warp_piecewise_batch(h->m, dst, (const hg_geom *)gv, F, outs);
-    free(outs);
-    if (rc != HG_OK) return throw_multi(env, h->m, "hg_multi_warp_piecewise_batch", rc);
+    const uint8_t **imgs = NULL; int iw = 0, ih = 0;
+    if (argc >= 6 && !get_frame_images(env, a[3], a[4], a[5], F, &imgs, &iw, &ih)) { free(outs); return NULL; }
+    int rc = imgs ? hg_multi_warp_piecewise_batch_images(h->m, dst, (const hg_geom *)gv, F, imgs, iw, ih, outs)
+                  : hg_multi_warp_piecewise_batch(h->m, dst, (const hg_geom *)gv, F, outs);
+    free(outs); free(imgs);
+    if (rc != HG_OK) return throw_multi(env, h->m, imgs ? "hg_multi_warp_piecewise_batch_images" : "hg_multi_warp_piecewise_batch", rc);
     return arr;
 }
 
 static napi_value fn_multi_warp_geometric_batch(napi_env env, napi_callback_info info)
 {
-    napi_value a[5];
-    if (!get_args(env, info, 5, a)) return NULL;
+    napi_value a[8];
+    size_t argc = 8;
+    if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 5) return throw_str(env, "hgwarp: multiWarpGeometricBatch(multi, kind, from, to, geoms[, images, width, height])");
     mhandle_t *h = get_mhandle(env, a[0]); if (!h) return NULL;
     int kind; size_t nf, nt, ng;
     if (!get_i32(env, a[1], &kind)) return NULL;
@@ -872,9 +907,12 @@ static napi_value fn_multi_warp_geometric_batch(napi_env env, napi_callback_info
         outs[f] = px ? (uint8_t *)out : &dummy;
         napi_set_element(env, arr, f, ta);
     }
-    int rc = hg_multi_warp_geometric_batch(h->m, kind, from, to, (const hg_geom *)gv, F, outs);
-    free(outs);
-    if (rc != HG_OK) return throw_multi(env, h->m, "hg_multi_warp_geometric_batch", rc);
+    const uint8_t **imgs = NULL; int iw = 0, ih = 0;
+    if (argc >= 8 && !get_frame_images(env, a[5], a[6], a[7], F, &imgs, &iw, &ih)) { free(outs); return NULL; }
+    int rc = imgs ? hg_multi_warp_geometric_batch_images(h->m, kind, from, to, (const hg_geom *)gv, F, imgs, iw, ih, outs)
+                  : hg_multi_warp_geometric_batch(h->m, kind, from, to, (const hg_geom *)gv, F, outs);
+    free(outs); free(imgs);
+    if (rc != HG_OK) return throw_multi(env, h->m, imgs ? "hg_multi_warp_geometric_batch_images" : "hg_multi_warp_geometric_batch", rc);
     return arr;
 }
 

@@ -68,3 +68,41 @@ def verify_replicas(t, dist):
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     if int(lo.item()) != int(hi.item()):
         raise RuntimeError("source broadcast: ranks hold different bytes")
+
+
+# ------------------------------------------------------------------ bench.py's N > 1 bookkeeping (pure functions + collectives on
+# whatever device the tensors live on: RCCL on the GPU box, gloo in tests/test_dist_cpu.py)
+
+def rank_frame_ids(rank, frames_per_rank):
+    """Weak scaling: every rank warps `frames_per_rank` frames of the config's sequence, rank r takes the r-th block."""
+    return [rank * frames_per_rank + f for f in range(frames_per_rank)]
+
+
+def check_launch(world, rank, local_rank, n_devices):
+    """A mis-launch must be loud: more ranks than GPUs on this node, or a local rank without a device, raise."""
+    if not (0 <= rank < world):
+        raise RuntimeError(f"RANK={rank} outside WORLD_SIZE={world}")
+    if world > n_devices:
+        raise RuntimeError(f"WORLD_SIZE={world} but this node shows {n_devices} GPU(s): one rank per GPU of ONE node")
+    if not (0 <= local_rank < n_devices):
+        raise RuntimeError(f"LOCAL_RANK={local_rank} has no device ({n_devices} visible)")
+
+
+def aggregate_step_stats(dist, world, device, elapsed_s, pixels_per_step, kernel_ms, verified):
+    """What rank 0 reports for a timed region: elapsed = MAX over ranks (the job is as slow as its slowest rank), pixels =
+    SUM over ranks (whole-job throughput), verified = AND over ranks, kernel_ms min / max over ranks (a straggler GPU shows)."""
+    import torch
+    if world == 1:
+        return {"elapsed_s": float(elapsed_s), "pixels_per_step": float(pixels_per_step), "verified": bool(verified),
+                "kernel_ms_min": float(kernel_ms), "kernel_ms_max": float(kernel_ms), "kernel_ms_by_rank": [float(kernel_ms)]}
+    mx = torch.tensor([elapsed_s, kernel_ms, 0.0 if verified else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    mn = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    sm = torch.tensor([pixels_per_step], dtype=torch.float64, device=device)
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return {"elapsed_s": float(mx[0].item()), "pixels_per_step": float(sm[0].item()), "verified": bool(mx[2].item() == 0.0),
+            "kernel_ms_min": float(mn[0].item()), "kernel_ms_max": float(mx[1].item()), "kernel_ms_by_rank": [float(t.item()) for t in parts]}

@@ -24,7 +24,8 @@ EXPORTS = [
     "hg_version", "hg_device_count", "hg_create", "hg_create_on_stream", "hg_destroy", "hg_last_error", "hg_sync",
     "hg_device_alloc", "hg_device_free", "hg_copy_to_host", "hg_copy_to_device", "hg_copy_to_host_async", "hg_host_alloc", "hg_host_free", "hg_ctx_device",
     "hg_multi_create", "hg_multi_destroy", "hg_multi_last_error", "hg_multi_device_count", "hg_multi_ctx", "hg_multi_partition", "hg_multi_set_image",
-    "hg_multi_piecewise_set_mesh", "hg_multi_warp_piecewise_batch", "hg_multi_warp_geometric_batch", "hg_multi_frame",
+    "hg_multi_piecewise_set_mesh", "hg_multi_warp_piecewise_batch", "hg_multi_warp_geometric_batch", "hg_multi_warp_piecewise_batch_images",
+    "hg_multi_warp_geometric_batch_images", "hg_multi_frame", "hg_enqueue_copy_to_host", "hg_stream_wait_event",
     "hg_solve_affine", "hg_invert_affine", "hg_solve_projective", "hg_transform_limits", "hg_minmax_xy", "hg_js_round",
     "hg_triangulate",
     "hg_set_image", "hg_set_image_device", "hg_set_images_device",
@@ -75,6 +76,9 @@ def lib():
         "hg_multi_warp_piecewise_batch": (i, [vp, f32p, C.POINTER(Geom), i, C.POINTER(vp)]),
         "hg_multi_warp_geometric_batch": (i, [vp, i, f32p, f32p, C.POINTER(Geom), i, C.POINTER(vp)]),
         "hg_multi_frame": (i, [vp, i, C.POINTER(i), C.POINTER(vp), C.POINTER(sz)]),
+        "hg_multi_warp_piecewise_batch_images": (i, [vp, f32p, C.POINTER(Geom), i, C.POINTER(vp), i, i, C.POINTER(vp)]),
+        "hg_multi_warp_geometric_batch_images": (i, [vp, i, f32p, f32p, C.POINTER(Geom), i, C.POINTER(vp), i, i, C.POINTER(vp)]),
+        "hg_enqueue_copy_to_host": (i, [vp, vp, vp, sz]), "hg_stream_wait_event": (i, [vp, vp]),
         "hg_solve_affine": (i, [f32p, f32p, f32p]), "hg_invert_affine": (i, [f32p, f32p]), "hg_solve_projective": (i, [f32p, f32p, f64p]),
         "hg_transform_limits": (i, [i, f64p, d, d, f64p]), "hg_minmax_xy": (i, [f32p, i, f64p]), "hg_js_round": (d, [d]),
         "hg_triangulate": (i, [f32p, i, C.POINTER(C.c_uint32), i, C.POINTER(i)]),
@@ -547,6 +551,30 @@ class Multi:
         ptrs = (C.c_void_p * len(geoms))(*[C.c_void_p(int(p)) for p in out_ptrs]) if out_ptrs is not None else None
         self._geoms = [tuple(int(v) for v in g) for g in geoms]
         self._c(lib().hg_multi_warp_piecewise_batch(self._h, dp, _geoms(geoms), len(geoms), ptrs))
+
+    @staticmethod
+    def _image_ptrs(images, n):
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        assert len(imgs) == n and all(im.shape == imgs[0].shape and im.ndim == 3 and im.shape[2] == 4 for im in imgs), "one H x W x 4 image per frame"
+        return imgs, (C.c_void_p * n)(*[C.c_void_p(im.ctypes.data) for im in imgs]), imgs[0].shape[1], imgs[0].shape[0]
+
+    def warp_piecewise_batch_images(self, dst_pts, geoms, images, out_ptrs=None):
+        """One source per frame (the video loop): images[f] is frame f's H x W x 4 uint8 source; every device uploads its own block."""
+        d, dp = _f32(dst_pts)
+        assert d.size == 2 * self._n_pts * len(geoms)
+        keep, iptrs, w, h = self._image_ptrs(images, len(geoms))
+        ptrs = (C.c_void_p * len(geoms))(*[C.c_void_p(int(p)) for p in out_ptrs]) if out_ptrs is not None else None
+        self._geoms = [tuple(int(v) for v in g) for g in geoms]
+        self._c(lib().hg_multi_warp_piecewise_batch_images(self._h, dp, _geoms(geoms), len(geoms), iptrs, w, h, ptrs))
+
+    def warp_geometric_batch_images(self, kind, from_pts, to_pts, geoms, images, out_ptrs=None):
+        per = 6 if int(kind) == 0 else 8
+        (a, ap), (b, bp) = _f32(from_pts), _f32(to_pts)
+        assert a.size == per * len(geoms) and b.size == per * len(geoms)
+        keep, iptrs, w, h = self._image_ptrs(images, len(geoms))
+        ptrs = (C.c_void_p * len(geoms))(*[C.c_void_p(int(p)) for p in out_ptrs]) if out_ptrs is not None else None
+        self._geoms = [tuple(int(v) for v in g) for g in geoms]
+        self._c(lib().hg_multi_warp_geometric_batch_images(self._h, int(kind), ap, bp, _geoms(geoms), len(geoms), iptrs, w, h, ptrs))
 
     def warp_geometric_batch(self, kind, from_pts, to_pts, geoms, out_ptrs=None):
         per = 6 if int(kind) == 0 else 8

@@ -255,17 +255,22 @@ class Homography {
         makeRoomFor(this._native, largest, F);
         let datas;
         if (options.devices !== undefined && options.devices !== null) {
-            if (options.images) throw ("hgwarp: warpBatch({devices, images}) is not supported: per-frame sources run on one device");
             // several GPUs of this node: device i of G warps a contiguous block of the frames (hg_multi_*: no collective on the
-            // data path; the shared source is fanned out once over xGMI peer copies)
+            // data path; the shared source is fanned out once over xGMI peer copies -- or, with {images}, every device uploads the
+            // sources of its own block and nothing is exchanged at all)
             const multi = this._multiFor(options.devices);
-            if (!(this.staticImage && this._multiImage === this._image)) {
-                this._native.multiSetImage(multi, this._image, this._width, this._height);
-                this._multiImage = this._image;
-            }
             const tris = this._triangles instanceof Uint32Array ? this._triangles : Uint32Array.from(this._triangles);
             this._native.multiSetMesh(multi, asF32(this._srcPoints), tris, this._minSrcX, this._minSrcY);
-            datas = this._native.multiWarpBatch(multi, all, geoms);
+            if (options.images) {
+                datas = this._native.multiWarpBatch(multi, all, geoms, this._checkedSources(options.images), this._width, this._height);
+                this._multiImage = null;                                                                 // (the devices now hold the per-frame sources)
+            } else {
+                if (!(this.staticImage && this._multiImage === this._image)) {
+                    this._native.multiSetImage(multi, this._image, this._width, this._height);
+                    this._multiImage = this._image;
+                }
+                datas = this._native.multiWarpBatch(multi, all, geoms);
+            }
         } else {
             this._uploadSources(options.images);
             this._uploadMesh();
@@ -301,13 +306,17 @@ class Homography {
         const kind = this.transform === 'affine' ? AFFINE : PROJECTIVE;
         let datas;
         if (options.devices !== undefined && options.devices !== null) {                              // frames spread over several GPUs
-            if (options.images) throw ("hgwarp: warpBatch({devices, images}) is not supported: per-frame sources run on one device");
             const multi = this._multiFor(options.devices);
-            if (!(this.staticImage && this._multiImage === this._image)) {
-                this._native.multiSetImage(multi, this._image, this._width, this._height);
-                this._multiImage = this._image;
+            if (options.images) {
+                datas = this._native.multiWarpGeometricBatch(multi, kind, from, to, geoms, this._checkedSources(options.images), this._width, this._height);
+                this._multiImage = null;
+            } else {
+                if (!(this.staticImage && this._multiImage === this._image)) {
+                    this._native.multiSetImage(multi, this._image, this._width, this._height);
+                    this._multiImage = this._image;
+                }
+                datas = this._native.multiWarpGeometricBatch(multi, kind, from, to, geoms);
             }
-            datas = this._native.multiWarpGeometricBatch(multi, kind, from, to, geoms);
         } else {
             this._uploadSources(options.images);
             datas = this._native.warpInverseGeometricBatch(this._ctx, kind, from, to, geoms);
@@ -457,14 +466,18 @@ class Homography {
 
     /** Source(s) of a batch: the instance's image, or `images` (one ImageData-shaped source per frame, all of the instance's size:
      *  the loop `warp(image_f)`; frame f reads images[f % images.length]). */
-    _uploadSources(images) {
-        if (images === undefined || images === null) return this._uploadImage();
+    _checkedSources(images) {
         if (!Array.isArray(images) || images.length === 0) throw ("hgwarp: warpBatch({images}) needs a non-empty array of ImageData-shaped sources");
         for (const im of images) {
             if (!im || !ArrayBuffer.isView(im.data) || im.width !== this._width || im.height !== this._height)
                 throw ("hgwarp: every image of warpBatch({images}) must be ImageData-shaped and of the size the instance was set up with");
         }
-        this._native.setImages(this._ctx, images.map((im) => im.data), this._width, this._height);
+        return images.map((im) => im.data);
+    }
+
+    _uploadSources(images) {
+        if (images === undefined || images === null) return this._uploadImage();
+        this._native.setImages(this._ctx, this._checkedSources(images), this._width, this._height);
         this._uploadedImage = null;                              // the next single-image warp uploads again
     }
 

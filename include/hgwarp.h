@@ -77,6 +77,13 @@ int hg_copy_to_device(hg_ctx *ctx, void *dst_device, const void *src_host, size_
 /* D2H queued on the ctx stream behind the warps issued so far; dst must stay alive until hg_sync().  A true asynchronous
  * DMA when dst is pinned memory from hg_host_alloc (page-locked, usable by every device). */
 int hg_copy_to_host_async(hg_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* The same without settling queued runs first (purely stream-ordered): for callers that queue the copies of several devices
+ * before waiting for any (hg_multi_*); frames a fused run only flagged are rewritten by the later hg_sync -- hg_redone_frames
+ * tells -- and must then be copied again. */
+int hg_enqueue_copy_to_host(hg_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* Everything queued on the ctx stream after this call waits for hip_event (a hipEvent_t recorded on any stream of any device):
+ * orders warps behind the caller's own uploads / peer copies without blocking the host. */
+int hg_stream_wait_event(hg_ctx *ctx, void *hip_event);
 int hg_host_alloc(size_t bytes, void **ptr);
 int hg_host_free(void *ptr);
 int hg_ctx_device(const hg_ctx *ctx);
@@ -114,7 +121,8 @@ int hg_set_image(hg_ctx *ctx, const uint8_t *rgba, int width, int height);
 int hg_set_image_device(hg_ctx *ctx, const void *d_rgba, int width, int height);
 /* The video case `for (f) { warp(frame_f) }` (README.md:121-137: every warp() gets its own image, setImage :290 per
  * frame): n_images sources of identical size, `stride_bytes` apart in GPU memory (aliased).  Frame f of a frame set
- * (hg_*_set_frames) then reads image f % n_images; n_images == 1 is hg_set_image_device. */
+ * (hg_*_set_frames) of the INVERSE warps then reads image f % n_images; n_images == 1 is hg_set_image_device.  The forward
+ * (scatter-semantics) entry points hg_warp_forward_* warp one source only: with n_images > 1 they return HG_ERR_STATE. */
 int hg_set_images_device(hg_ctx *ctx, const void *d_rgba, int width, int height, int n_images, size_t stride_bytes);
 
 /* ------------------------------------------------------------------------------------------------ affine / projective
@@ -221,6 +229,9 @@ int hg_multi_device_count(const hg_multi *multi);
 hg_ctx *hg_multi_ctx(hg_multi *multi, int index);                       /* the per-device context (options, taps) */
 /* Pure function: frames [*first, *first + *count) of n_frames belong to device `index` of n_devices (sizes differ by <= 1). */
 int hg_multi_partition(int n_frames, int n_devices, int index, int *first, int *count);
+/* Returns once the host buffer has been read (H2D into device 0, or one H2D per device without peer access).  The fan-out
+ * between the devices is NOT waited for: every device's warp stream waits for the event "whole image here", so device 0's
+ * first frames overlap the scatter + all-gather. */
 int hg_multi_set_image(hg_multi *multi, const uint8_t *rgba, int width, int height);
 int hg_multi_piecewise_set_mesh(hg_multi *multi, const float *src_points, int n_points, const uint32_t *triangles, int n_triangles,
                                 int min_src_x, int min_src_y);
@@ -231,6 +242,14 @@ int hg_multi_warp_piecewise_batch(hg_multi *multi, const float *dst_points, cons
  * from[f] -> to[f] (3 or 4 points each) and is solved on the device that warps the frame. */
 int hg_multi_warp_geometric_batch(hg_multi *multi, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames,
                                   uint8_t *const *out_host);
+/* One source per frame -- the video loop `for (f) { warp(frame_f) }` (README.md:121-137), SURVEY.md §8e's "replicas only" branch:
+ * images[f] = width x height RGBA8 in host memory for frame f; every device uploads the images of ITS block only, there is no
+ * exchange between devices at all.  Afterwards the contexts read those per-frame sources: call hg_multi_set_image again
+ * before the next shared-source batch. */
+int hg_multi_warp_piecewise_batch_images(hg_multi *multi, const float *dst_points, const hg_geom *geoms, int n_frames,
+                                         const uint8_t *const *images, int width, int height, uint8_t *const *out_host);
+int hg_multi_warp_geometric_batch_images(hg_multi *multi, int kind, const float *from, const float *to, const hg_geom *geoms, int n_frames,
+                                         const uint8_t *const *images, int width, int height, uint8_t *const *out_host);
 /* Where frame f of the last batch lives: index into the device list, device pointer, byte size (any of them may be NULL). */
 int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, size_t *bytes);
 

@@ -114,6 +114,16 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     let bad = false;
     try { vh.warpBatch(sets, { images: [lcgImage(W + 1, H, 1)] }); } catch (e) { bad = typeof e === 'string'; }
     ok(bad, 'an image of another size must be refused');
+    // ... and the same over a device list: every device uploads only the sources of its own block of frames (hg_multi_*_images)
+    for (const devices of [[0], [0, 0, 0]]) {
+        vh.warpBatch(sets, { images: ims, devices }).forEach((b, f) => ok(sha(b.data) === sha(loop[f].data), `per-frame sources over [${devices}]: frame ${f} differs`));
+        pv.warpBatch(ps, { images: [ims[1], ims[2]], devices }).forEach((b, f) => ok(sha(b.data) === sha(pl[f].data), `projective per-frame sources over [${devices}]: frame ${f} differs`));
+    }
+    // back to the instance's own image on the same device list
+    vh.warpBatch(sets, { devices: [0, 0] }).forEach((b, f) => {
+        vh.setDestinyPoints(sets[f], false);
+        ok(sha(b.data) === sha(vh.warp(null, false, true).data), `shared source after per-frame sources: frame ${f} differs`);
+    });
     vh.close(); pv.close();
 }
 {   // several GPUs behind one host thread: warpBatch(sets, {devices}).  This box has one GPU; listing it more than once puts

@@ -77,6 +77,59 @@ def test_broadcast_source_gloo_world2(shape):
     assert sorted(f for _, _, fr in res for f in fr) == list(range(11))
 
 
+def _bookkeeping_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = _load("hg_dist", "dist.py")
+        F = 5
+        ids = D.rank_frame_ids(rank, F)
+        # every rank reports its own numbers; rank 1 is the straggler and the one whose output check failed
+        agg = D.aggregate_step_stats(dist, world, torch.device("cpu"), elapsed_s=0.25 + 0.5 * rank, pixels_per_step=1000.0 * (rank + 1),
+                                     kernel_ms=0.5 + 0.125 * rank, verified=(rank == 0))
+        ok_all = D.aggregate_step_stats(dist, world, torch.device("cpu"), 0.5, 10.0, 1.0, True)
+        q.put((rank, ids, agg, ok_all["verified"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_bookkeeping_gloo_world2():
+    """bench.py's N > 1 bookkeeping on CPU tensors over gloo: frame ids per rank (weak scaling: disjoint blocks of the sequence),
+    elapsed = MAX over ranks, pixels = SUM, verified = AND, kernel ms min / max / by rank -- identical on every rank."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bookkeeping_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 1, 2, 3, 4] and res[1][1] == [5, 6, 7, 8, 9]
+    for _, _, agg, ok_all in res:
+        assert agg["elapsed_s"] == 0.75 and agg["pixels_per_step"] == 3000.0 and agg["verified"] is False
+        assert agg["kernel_ms_min"] == 0.5 and agg["kernel_ms_max"] == 0.625 and agg["kernel_ms_by_rank"] == [0.5, 0.625]
+        assert ok_all is True
+
+
+def test_check_launch_is_loud():
+    D = _load("hg_dist", "dist.py")
+    D.check_launch(1, 0, 0, 1)
+    D.check_launch(2, 1, 1, 8)                      # 2 of the 8 GPUs of a node: fine
+    D.check_launch(8, 7, 7, 8)
+    for bad in ((8, 0, 0, 4), (2, 2, 0, 8), (2, 1, 5, 4), (1, 0, -1, 1)):
+        with pytest.raises(RuntimeError):
+            D.check_launch(*bad)
+    # world 1 needs no process group at all
+    agg = D.aggregate_step_stats(None, 1, None, 0.5, 7.0, 0.25, True)
+    assert agg["elapsed_s"] == 0.5 and agg["kernel_ms_by_rank"] == [0.25] and agg["verified"] is True
+
+
 def test_bench_self_launch_command():
     """`python bench.py --gpus N` (what the driver runs) re-executes itself under torch.distributed.run: the dry run prints
     the exact command without needing a GPU."""

@@ -1084,3 +1084,44 @@ def test_multi_device_batch(devices):
         m.warp_piecewise_batch(np.concatenate(frames), geoms)
         for f in (0, F - 1):
             assert np.array_equal(m.frame_to_host(f), O.warp_inverse_piecewise(sp, frames[f], tris, img2, int(mm[0]), int(mm[1]), *geoms[f])), ("regrown", f)
+        # hg_multi_frame refuses frames outside the last batch, and a failed batch leaves no stale partition behind
+        with pytest.raises(HG.HgError):
+            m.frame(F)
+        with pytest.raises(HG.HgError):
+            m.frame(-1)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_multi_device_batch_with_one_source_per_frame(devices):
+    """SURVEY.md §8e's "replicas only" branch through hg_multi_*: every frame has its own source image (the video loop,
+    README.md:121-137); each device uploads only the images of its block, nothing is exchanged.  Piecewise and projective
+    frames, resident and to host, every frame against the oracle; then back to a shared source."""
+    W, H, nx, ny, F = 288, 176, 6, 4, 7
+    imgs = [G.lcg_image(W, H, 500 + f) for f in range(F)]
+    sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+    frames = [WL.sin_dst(sp, 3.0 + f, 8 + (f % 4)) for f in range(F)]
+    geoms = [WL.piecewise_geom(d) for d in frames]
+    mm = O.minmax_xy(sp)
+    want = [O.warp_inverse_piecewise(sp, frames[f], tris, imgs[f], int(mm[0]), int(mm[1]), *geoms[f]) for f in range(F)]
+    with HG.Multi(devices) as m:
+        m.piecewise_set_mesh(sp, tris, int(mm[0]), int(mm[1]))
+        m.warp_piecewise_batch_images(np.concatenate(frames), geoms, imgs)         # no hg_multi_set_image needed
+        for f in range(F):
+            assert np.array_equal(m.frame_to_host(f), want[f]), ("resident", f)
+        outs = [np.zeros_like(w) for w in want]
+        m.warp_piecewise_batch_images(np.concatenate(frames), geoms, imgs, [o.ctypes.data for o in outs])
+        for f in range(F):
+            assert np.array_equal(outs[f], want[f]), ("host", f)
+        s4 = WL.corners(W, H)
+        d4s = [WL.projective_dst(W, H, 0.03 * k) for k in range(5)]
+        pg = [tuple(int(v) for v in O.transform_limits(1, O.projective_from_squares(s4, d4), W, H)) for d4 in d4s]
+        m.warp_geometric_batch_images(1, np.concatenate(d4s), np.tile(s4, 5), pg, imgs[:5])
+        for k in range(5):
+            assert np.array_equal(m.frame_to_host(k), O.warp_inverse_geometric(1, HG.solve_projective(d4s[k], s4), imgs[k], *pg[k])), ("projective", k)
+        # the shared-source batch refuses to run on the leftovers of the per-frame sources ...
+        with pytest.raises(HG.HgError):
+            m.warp_piecewise_batch(np.concatenate(frames), geoms)
+        # ... and works again after hg_multi_set_image
+        m.set_image(imgs[2])
+        m.warp_piecewise_batch(np.concatenate(frames), geoms)
+        assert np.array_equal(m.frame_to_host(2), want[2])
