@@ -9,6 +9,12 @@
 // (compiled with -ffp-contract=off), with the orientation test as an exact-sign predicate (only its sign is used, as there).
 // js/delaunay.mjs is the same code in JavaScript; both return the identical list (tests/js/test_host.mjs).
 // None of the reference's tests pins delaunator's output, so this remains "triangulation parity unpinned" (SURVEY.md §8c).
+//
+// ATTRIBUTION.  This is a restatement (written from the published algorithm, not a copy of the source, which is absent from this
+// build environment) of third-party work; see THIRD_PARTY_NOTICES.md at the repository root:
+//   delaunator 5.0.0          Copyright (c) 2017, Mapbox -- ISC License                (https://github.com/mapbox/delaunator)
+//   robust-predicates 3.0.1   Vladimir Agafonkin -- The Unlicense (public domain); its orient2d is a port of Jonathan R. Shewchuk's
+//                             public-domain "Adaptive Precision Floating-Point Arithmetic and Fast Robust Geometric Predicates"
 #include <cmath>
 #include <cstdint>
 #include <limits>

@@ -113,65 +113,83 @@ static napi_value make_typed(napi_env env, napi_typedarray_type t, size_t n, siz
  * V8 clears it during the collection itself, so pin_acquire() can see synchronously that a frame is dead and reuse its
  * buffer long before the deferred finalizer runs (and the JS class asks for a collection when poolPressure() says the pool is
  * starving: see there).  release(typedArray) hands a frame back at once (its ArrayBuffer is detached). */
-typedef struct { void *ptr; size_t cap; int in_use; unsigned gen; napi_ref weak; } pin_t;
+typedef struct { void *ptr; size_t cap; int in_use; int zombie; unsigned gen; napi_ref weak; } pin_t;
 typedef struct { int idx; unsigned gen; } pin_ref_t;
 #define PIN_MAX 512
-static pin_t g_pins[PIN_MAX];
-static int g_npins = 0;
-static size_t g_pin_bytes = 0, g_pin_limit = (size_t)2 << 30;
-static const size_t PIN_MIN_FRAME = (size_t)1 << 20;
-static double g_stat_forced_gc = 0;
 #define PIN_GC_EVERY 32
-static int g_since_gc = 0;                                   /* pooled frames handed out since the last requested collection */
-static int g_pool_malloc = 0;                                /* _poolTestFrames(): plain malloc instead of pinned memory (no GPU needed) */
-static double g_stat_hit = 0, g_stat_new = 0, g_stat_fallback = 0, g_stat_reaped = 0, g_stat_finalized = 0;   /* poolStats() */
+static const size_t PIN_MIN_FRAME = (size_t)1 << 20;
+/* The pool is PER ENVIRONMENT (napi_set_instance_data): its napi_refs belong to one env and its buffers are handed out on that
+ * env's thread only, so a second env (worker_threads, or the addon loaded into two contexts) gets a pool of its own instead of
+ * racing on -- and dereferencing references of -- somebody else's. */
+typedef struct {
+    pin_t pins[PIN_MAX];
+    int npins;
+    size_t pin_bytes, pin_limit;
+    int since_gc;                                            /* pooled frames handed out since the last requested collection */
+    int pool_malloc;                                         /* _poolTestFrames(): plain malloc instead of pinned memory (no GPU needed) */
+    /* May a buffer whose ArrayBuffer is dead (weak reference cleared) or detached (release()) back a NEW external ArrayBuffer
+     * before the old one's finalizer has run?  Under Node 12 (V8 7.x) yes, and that is what lets a synchronous loop get frames
+     * back at all (finalizers only run from the event loop there).  From V8 8 on (Node >= 14) two ArrayBuffers over one backing
+     * pointer abort the process (nodejs/node#32463): there a buffer is recycled only once its finalizer HAS run. */
+    int early_reuse;
+    double stat_hit, stat_new, stat_fallback, stat_reaped, stat_finalized, stat_forced_gc;   /* poolStats() */
+} pool_t;
 
-static void pin_drop(int i)
+static pool_t *pool_of(napi_env env)
 {
-    if (g_pins[i].ptr) { if (g_pool_malloc) free(g_pins[i].ptr); else hg_host_free(g_pins[i].ptr); g_pin_bytes -= g_pins[i].cap; }
-    g_pins[i].ptr = NULL; g_pins[i].cap = 0; g_pins[i].in_use = 0;
+    void *p = NULL;
+    if (napi_get_instance_data(env, &p) != napi_ok || !p) { throw_str(env, "hgwarp: addon instance data is missing"); return NULL; }
+    return (pool_t *)p;
+}
+
+static void pin_drop(pool_t *P, int i)
+{
+    if (P->pins[i].ptr) { if (P->pool_malloc) free(P->pins[i].ptr); else hg_host_free(P->pins[i].ptr); P->pin_bytes -= P->pins[i].cap; }
+    P->pins[i].ptr = NULL; P->pins[i].cap = 0; P->pins[i].in_use = 0; P->pins[i].zombie = 0;
 }
 
 /* frames whose ArrayBuffer has been collected (weak reference cleared) although their finalizer has not run yet */
-static void pin_reap(napi_env env)
+static void pin_reap(napi_env env, pool_t *P)
 {
-    for (int i = 0; i < g_npins; i++) {
-        if (!g_pins[i].ptr || !g_pins[i].in_use || !g_pins[i].weak) continue;
+    for (int i = 0; i < P->npins; i++) {
+        if (!P->pins[i].ptr || !P->pins[i].in_use || !P->pins[i].weak) continue;
         napi_value v = NULL;
-        if (napi_get_reference_value(env, g_pins[i].weak, &v) == napi_ok && v == NULL) {
-            napi_delete_reference(env, g_pins[i].weak);
-            g_pins[i].weak = NULL; g_pins[i].in_use = 0; g_pins[i].gen++;      /* the late finalizer will not match */
-            g_stat_reaped++;
-            int64_t adj; napi_adjust_external_memory(env, -(int64_t)g_pins[i].cap, &adj);
+        if (napi_get_reference_value(env, P->pins[i].weak, &v) == napi_ok && v == NULL) {
+            napi_delete_reference(env, P->pins[i].weak);
+            P->pins[i].weak = NULL;
+            P->stat_reaped++;
+            int64_t adj; napi_adjust_external_memory(env, -(int64_t)P->pins[i].cap, &adj);
+            if (P->early_reuse) { P->pins[i].in_use = 0; P->pins[i].gen++; }   /* the late finalizer will not match */
+            else P->pins[i].zombie = 1;                                        /* V8 >= 8: stays out of circulation until pin_finalize */
         }
     }
 }
 
-static int pin_acquire(napi_env env, size_t bytes)
+static int pin_acquire(napi_env env, pool_t *P, size_t bytes)
 {
-    if (bytes < PIN_MIN_FRAME || g_pin_limit == 0) return -1;
+    if (bytes < PIN_MIN_FRAME || P->pin_limit == 0) return -1;
     int best = -1, empty = -1;
     for (int pass = 0; pass < 2 && best < 0; pass++) {
-        if (pass == 1) pin_reap(env);
-        for (int i = 0; i < g_npins; i++) {
-            if (!g_pins[i].ptr) continue;
-            if (!g_pins[i].in_use && g_pins[i].cap >= bytes && g_pins[i].cap <= bytes + bytes / 2 && (best < 0 || g_pins[i].cap < g_pins[best].cap)) best = i;
+        if (pass == 1) pin_reap(env, P);
+        for (int i = 0; i < P->npins; i++) {
+            if (!P->pins[i].ptr) continue;
+            if (!P->pins[i].in_use && P->pins[i].cap >= bytes && P->pins[i].cap <= bytes + bytes / 2 && (best < 0 || P->pins[i].cap < P->pins[best].cap)) best = i;
         }
     }
-    g_since_gc++;
-    if (best >= 0) { g_pins[best].in_use = 1; g_stat_hit++; return best; }
-    for (int i = 0; i < g_npins; i++) if (!g_pins[i].ptr) { empty = i; break; }
+    P->since_gc++;
+    if (best >= 0) { P->pins[best].in_use = 1; P->stat_hit++; return best; }
+    for (int i = 0; i < P->npins; i++) if (!P->pins[i].ptr) { empty = i; break; }
     /* make room: idle buffers of the wrong size go first */
-    for (int i = 0; i < g_npins && g_pin_bytes + bytes > g_pin_limit; i++) if (g_pins[i].ptr && !g_pins[i].in_use) { pin_drop(i); if (empty < 0) empty = i; }
-    if (g_pin_bytes + bytes > g_pin_limit) { g_stat_fallback++; return -1; }
-    if (empty < 0) { if (g_npins == PIN_MAX) { g_stat_fallback++; return -1; } empty = g_npins++; }
+    for (int i = 0; i < P->npins && P->pin_bytes + bytes > P->pin_limit; i++) if (P->pins[i].ptr && !P->pins[i].in_use) { pin_drop(P, i); if (empty < 0) empty = i; }
+    if (P->pin_bytes + bytes > P->pin_limit) { P->stat_fallback++; return -1; }
+    if (empty < 0) { if (P->npins == PIN_MAX) { P->stat_fallback++; return -1; } empty = P->npins++; }
     void *p = NULL;
-    if (g_pool_malloc) p = malloc(bytes);
+    if (P->pool_malloc) p = malloc(bytes);
     else if (hg_host_alloc(bytes, &p) != HG_OK) p = NULL;
-    if (!p) { g_stat_fallback++; return -1; }
-    g_stat_new++;
-    g_pins[empty].ptr = p; g_pins[empty].cap = bytes; g_pins[empty].in_use = 1; g_pins[empty].gen++;
-    g_pin_bytes += bytes;
+    if (!p) { P->stat_fallback++; return -1; }
+    P->stat_new++;
+    P->pins[empty].ptr = p; P->pins[empty].cap = bytes; P->pins[empty].in_use = 1; P->pins[empty].gen++;
+    P->pin_bytes += bytes;
     return empty;
 }
 
@@ -179,11 +197,14 @@ static void pin_finalize(napi_env env, void *data, void *hint)
 {
     (void)data;
     pin_ref_t *r = (pin_ref_t *)hint;
-    if (r && r->idx >= 0 && r->idx < g_npins && g_pins[r->idx].gen == r->gen && g_pins[r->idx].in_use) {
-        if (g_pins[r->idx].weak) { napi_delete_reference(env, g_pins[r->idx].weak); g_pins[r->idx].weak = NULL; }
-        g_stat_finalized++;
-        g_pins[r->idx].in_use = 0;
-        int64_t adj; napi_adjust_external_memory(env, -(int64_t)g_pins[r->idx].cap, &adj);
+    pool_t *P = NULL;
+    if (napi_get_instance_data(env, (void **)&P) != napi_ok || !P) { free(r); return; }      /* (the env is going away: pool_free owns the buffers) */
+    if (r && r->idx >= 0 && r->idx < P->npins && P->pins[r->idx].gen == r->gen && P->pins[r->idx].in_use) {
+        if (P->pins[r->idx].weak) { napi_delete_reference(env, P->pins[r->idx].weak); P->pins[r->idx].weak = NULL; }
+        P->stat_finalized++;
+        P->pins[r->idx].in_use = 0;
+        if (P->pins[r->idx].zombie) P->pins[r->idx].zombie = 0;               /* (its external-memory accounting went when it was reaped / released) */
+        else { int64_t adj; napi_adjust_external_memory(env, -(int64_t)P->pins[r->idx].cap, &adj); }
     }
     free(r);
 }
@@ -191,18 +212,20 @@ static void pin_finalize(napi_env env, void *data, void *hint)
 /* a Uint8ClampedArray of `bytes` bytes over a pooled pinned buffer, or NULL (pool exhausted / small frame) */
 static napi_value make_pinned(napi_env env, size_t bytes, void **data)
 {
-    const int i = pin_acquire(env, bytes);
+    pool_t *P = pool_of(env);
+    if (!P) return NULL;
+    const int i = pin_acquire(env, P, bytes);
     if (i < 0) return NULL;
     pin_ref_t *r = (pin_ref_t *)malloc(sizeof *r);
     napi_value ab, ta;
-    if (!r) { g_pins[i].in_use = 0; return NULL; }
-    r->idx = i; r->gen = g_pins[i].gen;
-    if (napi_create_external_arraybuffer(env, g_pins[i].ptr, bytes, pin_finalize, r, &ab) != napi_ok) { g_pins[i].in_use = 0; free(r); return NULL; }
-    int64_t adj; napi_adjust_external_memory(env, (int64_t)g_pins[i].cap, &adj);     /* V8 learns about the memory pressure */
-    g_pins[i].weak = NULL;
-    if (napi_create_reference(env, ab, 0, &g_pins[i].weak) != napi_ok) g_pins[i].weak = NULL;
+    if (!r) { P->pins[i].in_use = 0; return NULL; }
+    r->idx = i; r->gen = P->pins[i].gen;
+    if (napi_create_external_arraybuffer(env, P->pins[i].ptr, bytes, pin_finalize, r, &ab) != napi_ok) { P->pins[i].in_use = 0; free(r); return NULL; }
+    int64_t adj; napi_adjust_external_memory(env, (int64_t)P->pins[i].cap, &adj);     /* V8 learns about the memory pressure */
+    P->pins[i].weak = NULL;
+    if (napi_create_reference(env, ab, 0, &P->pins[i].weak) != napi_ok) P->pins[i].weak = NULL;
     if (napi_create_typedarray(env, napi_uint8_clamped_array, bytes, ab, 0, &ta) != napi_ok) return NULL;
-    *data = g_pins[i].ptr;
+    *data = P->pins[i].ptr;
     return ta;
 }
 
@@ -246,13 +269,15 @@ static napi_value fn_release(napi_env env, napi_callback_info info)
     bool is = false;
     napi_typedarray_type t; size_t n = 0, off = 0; void *p = NULL; napi_value ab;
     napi_value res; napi_get_boolean(env, false, &res);
+    pool_t *P = pool_of(env); if (!P) return NULL;
     if (napi_is_typedarray(env, a[0], &is) != napi_ok || !is || napi_get_typedarray_info(env, a[0], &t, &n, &p, &ab, &off) != napi_ok || !p) return res;
-    for (int i = 0; i < g_npins; i++)
-        if (g_pins[i].ptr == (char *)p - off && g_pins[i].in_use) {
+    for (int i = 0; i < P->npins; i++)
+        if (P->pins[i].ptr == (char *)p - off && P->pins[i].in_use) {
             if (napi_detach_arraybuffer(env, ab) != napi_ok) return res;
-            if (g_pins[i].weak) { napi_delete_reference(env, g_pins[i].weak); g_pins[i].weak = NULL; }
-            g_pins[i].in_use = 0; g_pins[i].gen++;                /* the pending finalizer of this ArrayBuffer no longer matches */
-            int64_t adj; napi_adjust_external_memory(env, -(int64_t)g_pins[i].cap, &adj);
+            if (P->pins[i].weak) { napi_delete_reference(env, P->pins[i].weak); P->pins[i].weak = NULL; }
+            if (P->early_reuse) { P->pins[i].in_use = 0; P->pins[i].gen++; }   /* the pending finalizer of this ArrayBuffer no longer matches */
+            else P->pins[i].zombie = 1;                                        /* V8 >= 8: recycled once the detached buffer's finalizer has run */
+            int64_t adj; napi_adjust_external_memory(env, -(int64_t)P->pins[i].cap, &adj);
             napi_get_boolean(env, true, &res);
             break;
         }
@@ -267,7 +292,8 @@ static napi_value fn_pool_test_frames(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 2, a)) return NULL;
     int n; double bytes;
     if (!get_i32(env, a[0], &n) || napi_get_value_double(env, a[1], &bytes) != napi_ok || n < 0 || !(bytes >= 0)) return throw_str(env, "hgwarp: _poolTestFrames(n, bytes)");
-    if (!g_pool_malloc) { for (int i = 0; i < g_npins; i++) if (g_pins[i].ptr && !g_pins[i].in_use) pin_drop(i); g_pool_malloc = 1; }
+    pool_t *P = pool_of(env); if (!P) return NULL;
+    if (!P->pool_malloc) { for (int i = 0; i < P->npins; i++) if (P->pins[i].ptr && !P->pins[i].in_use) pin_drop(P, i); P->pool_malloc = 1; }
     napi_value arr;
     NAPI_OK(napi_create_array_with_length(env, n, &arr));
     for (int f = 0; f < n; f++) {
@@ -293,29 +319,31 @@ static napi_value fn_pool_pressure(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 2, a)) return NULL;
     double bytes; int n;
     napi_get_boolean(env, false, &res);
+    pool_t *P = pool_of(env); if (!P) return NULL;
     if (napi_get_value_double(env, a[0], &bytes) != napi_ok || !get_i32(env, a[1], &n)) return res;
-    if (!(bytes >= (double)PIN_MIN_FRAME) || g_pin_limit == 0 || n <= 0) return res;
-    pin_reap(env);
+    if (!(bytes >= (double)PIN_MIN_FRAME) || P->pin_limit == 0 || n <= 0) return res;
+    pin_reap(env, P);
     int fit = 0, live = 0;
-    for (int i = 0; i < g_npins; i++) {
-        if (!g_pins[i].ptr) continue;
-        if (g_pins[i].in_use) live++;
-        else if (g_pins[i].cap >= (size_t)bytes && g_pins[i].cap <= (size_t)bytes + (size_t)bytes / 2) fit++;
+    for (int i = 0; i < P->npins; i++) {
+        if (!P->pins[i].ptr) continue;
+        if (P->pins[i].in_use) live++;
+        else if (P->pins[i].cap >= (size_t)bytes && P->pins[i].cap <= (size_t)bytes + (size_t)bytes / 2) fit++;
     }
     if (fit >= n) return res;
     (void)live;
-    if (g_since_gc >= PIN_GC_EVERY || (double)g_pin_bytes + (n - fit) * bytes > (double)g_pin_limit) napi_get_boolean(env, true, &res);
+    if (P->since_gc >= PIN_GC_EVERY || (double)P->pin_bytes + (n - fit) * bytes > (double)P->pin_limit) napi_get_boolean(env, true, &res);
     return res;
 }
 
 static napi_value fn_pool_collected(napi_env env, napi_callback_info info)
 {
     (void)info;
-    const double before = g_stat_reaped;
-    pin_reap(env);
-    g_since_gc = 0;
-    g_stat_forced_gc++;
-    napi_value v; NAPI_OK(napi_create_double(env, g_stat_reaped - before, &v));
+    pool_t *P = pool_of(env); if (!P) return NULL;
+    const double before = P->stat_reaped;
+    pin_reap(env, P);
+    P->since_gc = 0;
+    P->stat_forced_gc++;
+    napi_value v; NAPI_OK(napi_create_double(env, P->stat_reaped - before, &v));
     return v;
 }
 
@@ -324,11 +352,12 @@ static napi_value fn_pool_stats(napi_env env, napi_callback_info info)
 {
     (void)info;
     napi_value o, v;
+    pool_t *P = pool_of(env); if (!P) return NULL;
     NAPI_OK(napi_create_object(env, &o));
     int in_use = 0, total = 0;
-    for (int i = 0; i < g_npins; i++) if (g_pins[i].ptr) { total++; in_use += g_pins[i].in_use; }
-    const struct { const char *k; double x; } kv[] = { {"pinnedBytes", (double)g_pin_bytes}, {"buffers", total}, {"inUse", in_use}, {"reused", g_stat_hit},
-        {"allocated", g_stat_new}, {"fallbackToV8", g_stat_fallback}, {"reapedByWeakRef", g_stat_reaped}, {"forcedCollections", g_stat_forced_gc}, {"finalized", g_stat_finalized} };
+    for (int i = 0; i < P->npins; i++) if (P->pins[i].ptr) { total++; in_use += P->pins[i].in_use; }
+    const struct { const char *k; double x; } kv[] = { {"pinnedBytes", (double)P->pin_bytes}, {"buffers", total}, {"inUse", in_use}, {"reused", P->stat_hit},
+        {"allocated", P->stat_new}, {"fallbackToV8", P->stat_fallback}, {"reapedByWeakRef", P->stat_reaped}, {"forcedCollections", P->stat_forced_gc}, {"finalized", P->stat_finalized}, {"earlyReuse", P->early_reuse} };
     for (size_t i = 0; i < sizeof kv / sizeof kv[0]; i++) { NAPI_OK(napi_create_double(env, kv[i].x, &v)); NAPI_OK(napi_set_named_property(env, o, kv[i].k, v)); }
     return o;
 }
@@ -340,10 +369,11 @@ static napi_value fn_set_pinned_limit(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 1, a)) return NULL;
     double d;
     if (napi_get_value_double(env, a[0], &d) != napi_ok || !(d >= 0)) return throw_str(env, "hgwarp: setPinnedLimit needs a non-negative number of bytes");
-    g_pin_limit = d > 1e15 ? (size_t)1e15 : (size_t)d;
-    for (int i = 0; i < g_npins; i++) if (g_pins[i].ptr && !g_pins[i].in_use && g_pin_bytes > g_pin_limit) pin_drop(i);
+    pool_t *P = pool_of(env); if (!P) return NULL;
+    P->pin_limit = d > 1e15 ? (size_t)1e15 : (size_t)d;
+    for (int i = 0; i < P->npins; i++) if (P->pins[i].ptr && !P->pins[i].in_use && P->pin_bytes > P->pin_limit) pin_drop(P, i);
     napi_value v;
-    NAPI_OK(napi_create_double(env, (double)g_pin_bytes, &v));
+    NAPI_OK(napi_create_double(env, (double)P->pin_bytes, &v));
     return v;
 }
 
@@ -917,8 +947,25 @@ static napi_value fn_multi_warp_geometric_batch(napi_env env, napi_callback_info
 }
 
 /* ---------------------------------------------------------------- module */
+static void pool_free(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    pool_t *P = (pool_t *)data;
+    if (!P) return;
+    /* the env is gone and every ArrayBuffer with it: the buffers go back to the driver */
+    for (int i = 0; i < P->npins; i++) if (P->pins[i].ptr) { if (P->pool_malloc) free(P->pins[i].ptr); else hg_host_free(P->pins[i].ptr); }
+    free(P);
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
+    pool_t *P = (pool_t *)calloc(1, sizeof *P);
+    if (!P) return NULL;
+    P->pin_limit = (size_t)2 << 30;
+    const napi_node_version *nv = NULL;
+    P->early_reuse = (napi_get_node_version(env, &nv) == napi_ok && nv && nv->major <= 12) ? 1 : 0;
+    if (getenv("HGWARP_POOL_NO_EARLY_REUSE")) P->early_reuse = 0;           /* (tests: the V8 >= 8 life cycle under Node 12) */
+    if (napi_set_instance_data(env, P, pool_free, NULL) != napi_ok) { free(P); return NULL; }
     static const struct { const char *name; napi_callback fn; } fns[] = {
         { "create", fn_create }, { "destroy", fn_destroy }, { "deviceCount", fn_device_count },
         { "solveAffine", fn_solve_affine }, { "invertAffine", fn_invert_affine }, { "solveProjective", fn_solve_projective },

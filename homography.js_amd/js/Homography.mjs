@@ -45,20 +45,14 @@ function addon() {
     return native;
 }
 
-// A synchronous full collection for the moment the page-locked frame pool starves (hgwarp_napi.c: poolPressure): `gc` when
-// node runs with --expose-gc, else the function V8 hands out once the flag is switched on at run time.  null if neither works
-// (then frames simply fall back to plain V8 arrays until V8 collects by itself).
-let collector;
+// When the page-locked frame pool starves (hgwarp_napi.c: poolPressure) a full collection would hand its dead frames back at
+// once.  The library only ever asks for one when the USER started node with --expose-gc (global.gc exists); it never switches
+// V8 flags itself and never forces collections on a host application that did not opt in -- without the flag, frames simply
+// fall back to plain V8 arrays until V8 collects by itself (or the caller uses Homography.release(frame) / reuseOutput).
 function collectGarbage() {
-    if (collector === undefined) {
-        collector = null;
-        try {
-            if (typeof global.gc === 'function') collector = global.gc;
-            else { const v8 = require('v8'), vm = require('vm'); v8.setFlagsFromString('--expose-gc'); collector = vm.runInNewContext('gc'); }
-        } catch (e) { collector = null; }
-    }
-    if (collector) collector();
-    return collector !== null;
+    if (typeof global.gc !== 'function') return false;
+    global.gc();
+    return true;
 }
 function makeRoomFor(native, bytes, n) {
     if (bytes >= 1048576 && native.poolPressure(bytes, n) && collectGarbage()) native.poolCollected();

@@ -12,6 +12,12 @@
 // is used, as there).  Output: Uint32Array, 3 vertex ids per triangle, in delaunator's order.
 // No test of the reference pins delaunator's output, so this remains "triangulation parity unpinned" (SURVEY.md §8c);
 // hg_triangulate (csrc/hg_delaunay.cpp) is the same algorithm in C++ and returns the identical list.
+//
+// ATTRIBUTION.  This is a restatement (written from the published algorithm, not a copy of the source, which is absent from this
+// build environment) of third-party work; see THIRD_PARTY_NOTICES.md at the repository root:
+//   delaunator 5.0.0          Copyright (c) 2017, Mapbox -- ISC License                (https://github.com/mapbox/delaunator)
+//   robust-predicates 3.0.1   Vladimir Agafonkin -- The Unlicense (public domain); its orient2d is a port of Jonathan R. Shewchuk's
+//                             public-domain "Adaptive Precision Floating-Point Arithmetic and Fast Robust Geometric Predicates"
 
 const EPSILON = Math.pow(2, -52);
 const EDGE_STACK = new Uint32Array(512);

@@ -23,8 +23,9 @@ def _require_js_on_gpu():
     assert os.path.exists(ADDON), f"{ADDON} is missing: run `make -C homography.js_amd` (needs /usr/include/node/node_api.h)"
 
 
-def _node(script, *args, timeout=900):
-    p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+def _node(script, *args, timeout=900, env=None):
+    p = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", script), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                       env=dict(os.environ, **env) if env else None)
     line = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
     assert line, f"no JSON from {script}: rc={p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
     return p.returncode, json.loads(line[-1])
@@ -40,6 +41,14 @@ def test_state_machine_replay_matches_reference():
 @needs_js
 def test_host_side_javascript():
     rc, res = _node("test_host.mjs")
+    assert res["failures"] == [] and rc == 0
+
+
+@needs_js
+def test_frame_pool_never_shares_a_backing_store_under_the_v8_8_rule():
+    """Two ArrayBuffers over one backing pointer abort Node >= 14: with early reuse switched off (what the addon does by itself
+    there) a pooled buffer is recycled only after its previous ArrayBuffer's finalizer has run."""
+    rc, res = _node("test_pool_v8.mjs", env={"HGWARP_POOL_NO_EARLY_REUSE": "1"})
     assert res["failures"] == [] and rc == 0
 
 

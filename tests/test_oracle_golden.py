@@ -180,3 +180,48 @@ def test_js_oracle_pinned_to_goldens():
     p = subprocess.run([node, os.path.join(root, "oracle", "hg_oracle_js.mjs"), "check"], capture_output=True, text=True, timeout=600)
     res = json.loads(p.stdout.strip().splitlines()[-1])
     assert res["failures"] == [] and res["checked"] >= 30 and p.returncode == 0
+
+
+def test_seam_sensitivity_to_triangle_order_on_c4():
+    """What "triangulation parity unpinned" can cost: the triangle SET of a Delaunay triangulation is
+    unique for points in general position, the ORDER of the list is an implementation detail of delaunator -- and the reference's
+    map is last-writer-wins (:852-858), so order decides who owns every cell that two triangles both cover.  C4 frame 0
+    (68-landmark face mesh, 4K) through the oracle with the list as hg_triangulate returns it, reversed, and shuffled:
+      * the orbit as SURVEY.md §8d defines it moves every landmark on its own circle of radius 0.02 W (77 px, neighbours are ~270 px
+        apart): destination triangles overlap where the mesh folds, and there the order decides between two genuinely different
+        source regions -- a few percent of the window change owner and value;
+      * the same orbit at a tenth of the radius (no folds): NOTHING changes -- the half-open spans [round(x0), round(x1)) of
+        neighbouring triangles tile a row without overlap, so on an unfolded mesh the order of the list is immaterial and only
+        the triangle SET (the diagonal chosen for co-circular quads) matters.
+    Coverage (which cells have an owner at all) never depends on the order."""
+    from hgtest import workloads as WL
+    from hgtest import hip
+    HG = hip.load()
+    W, H = 3840, 2160
+    sp = WL.face_mesh(W, H, 68)
+    tris = HG.triangulate(sp).reshape(-1, 3)
+    ms = WL.src_min(sp)
+    img = G.lcg_image(W, H, 1)
+    dp0 = WL.face_frames(sp, W, 512)[0]
+    gentle = (sp.astype(np.float64) + 0.1 * (dp0.astype(np.float64) - sp.astype(np.float64))).astype(np.float32)
+    report = {}
+    for label, dp in (("orbit radius 0.02 W", dp0), ("orbit radius 0.002 W", gentle)):
+        geom = WL.piecewise_geom(dp)
+        base, bmap, _, _ = O.warp_inverse_piecewise(sp, dp, tris.ravel(), img, ms[0], ms[1], *geom, taps=True)
+        n = geom[2] * geom[3]
+        rng = np.random.default_rng(4)
+        worst_map = worst_px = 0
+        for order in (np.arange(len(tris))[::-1], rng.permutation(len(tris)), rng.permutation(len(tris))):
+            out, omap, _, _ = O.warp_inverse_piecewise(sp, dp, np.ascontiguousarray(tris[order]).ravel(), img, ms[0], ms[1], *geom, taps=True)
+            assert np.array_equal(omap >= 0, bmap >= 0)               # same coverage
+            inv = np.asarray(order)                                    # id in the permuted list -> id in the original list
+            same_owner = np.where(omap >= 0, inv[np.clip(omap, 0, None)], -1) == bmap
+            d_map = int(np.count_nonzero(~same_owner))
+            d_px = int(np.count_nonzero(np.any(out != base, axis=2)))
+            worst_map, worst_px = max(worst_map, d_map), max(worst_px, d_px)
+            assert d_px <= d_map                                       # pixels can only differ where the owner differs
+        report[label] = (geom, worst_map / n, worst_px / n)
+        print(f"C4 frame 0, {len(tris)} triangles, {label} (xOff {geom[0]}, {geom[2]}x{geom[3]}): up to {worst_map} of {n} map cells "
+              f"({100.0 * worst_map / n:.3f} %) change owner with the triangle order, {worst_px} pixels ({100.0 * worst_px / n:.3f} %) change value")
+    assert 0 < report["orbit radius 0.02 W"][1] <= 0.10 and report["orbit radius 0.02 W"][2] <= 0.10
+    assert report["orbit radius 0.002 W"][1] == 0 and report["orbit radius 0.002 W"][2] == 0
