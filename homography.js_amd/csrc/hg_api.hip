@@ -69,7 +69,7 @@ struct hg_ctx {
     bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
     long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
-    int opt_min_row_groups = 1536, opt_patch = -1, opt_phase = -1, opt_geo_nw = 4;   // hg_set_option()
+    int opt_min_row_groups = 1536, opt_patch = -1, opt_phase = -1, opt_geo_nw = 8;   // hg_set_option()
     int xcc_log2 = 3;                                          // log2(XCCs of the device): hipDeviceAttributeNumberOfXccs at hg_create, option "xcc"
     int opt_lds_pad = -1;                                       // KB of dynamic LDS padding per k_pw_rows workgroup (occupancy experiments)
     int opt_sgpr_cap = -1;                                     // -1 auto (shared source), 0 never, 1 always: k_pw_rows_s80
@@ -95,6 +95,9 @@ struct hg_ctx {
     int32_t *d_redo_status = nullptr; size_t redo_status_cap = 0;
     // layout of the row counters / status ring as of their last memset (a frame set with the same layout reuses them as they are)
     size_t rows_F = 0; int rows_stride = 0, rows_cap = 0;
+    int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
+    int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
+    int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
     // layout estimates of the last frame set, reused for the next set of the same shape (the kernels check the real counts)
     struct LayoutKey { int n = -1, n_tris = -1, max_w = -1, max_h = -1; uint64_t mesh_gen = 0; bool quick = false; } layout_key;
     uint64_t mesh_gen = 0; int layout_age = 0;
@@ -353,6 +356,8 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "geo_windows")) c->opt_geo_nw = value;
     else if (!std::strcmp(key, "hi_bounds")) c->opt_hi_bounds = value != 0;
     else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
+    else if (!std::strcmp(key, "rows1_threads")) c->opt_rows1_threads = (value == 128 || value == 256) ? value : -1;
+    else if (!std::strcmp(key, "col_split")) c->opt_col_split = (value == 1 || value == 2 || value == 4) ? value : -1;
     else if (!std::strcmp(key, "lds_pad")) c->opt_lds_pad = std::min(std::max(value, -1), 40);
     else if (!std::strcmp(key, "xcc")) {                      // block id -> XCD band mapping for `value` XCCs (a power of two <= 64); speed only
         if (value < 1 || value > 64 || (value & (value - 1))) return fail(c, HG_ERR_INVALID, "hg_set_option: xcc must be a power of two in 1..64");
@@ -954,17 +959,29 @@ static PwFrames frames_of(const hg_ctx *c)
     f.sgpr_cap = c->opt_sgpr_cap >= 0 ? (c->opt_sgpr_cap != 0) : (c->n_imgs <= 1);
     f.lds_pad_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : (c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0);
     f.lds_pad_patch_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : 0;
+    {   // small frame sets: split every row group's windows over 2 or 4 workgroups until the launch has ~4000 of them
+        int64_t groups = 0;
+        const int rg = c->pw_row_group == kRowGroup ? kRowGroup : 1;
+        for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + rg - 1) / rg;
+        f.col_split = c->opt_col_split > 0 ? c->opt_col_split : 1;
+        f.rows1_threads = c->opt_rows1_threads > 0 ? c->opt_rows1_threads : 256;
+        (void)groups;
+    }
     f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
+    f.patch_blocks = c->opt_phase > 0 ? c->opt_phase : 8;    // (k_pw_patch: measured best in both source layouts, hg_k_patch.hip)
     return f;
 }
 
 static RowLists rows_of(const hg_ctx *c)
 {
     RowLists r;
-    r.cnt = c->d_rowcnt; r.ent = c->d_rowent; r.cap = c->row_cap; r.compact = c->pw_compact ? 1 : 0;
+    r.ent = c->d_rowent; r.cap = c->row_cap; r.compact = c->pw_compact ? 1 : 0;
     int mh = 0;
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     r.row_stride = std::max(mh, 1);
+    const size_t set = c->pw_frames.size() * (size_t)r.row_stride;           // two counter sets, then the status ring
+    r.cnt = c->d_rowcnt ? c->d_rowcnt + (size_t)c->rows_parity * set : nullptr;
+    r.cnt_clear = c->d_rowcnt ? c->d_rowcnt + (size_t)(1 - c->rows_parity) * set : nullptr;
     return r;
 }
 
@@ -999,24 +1016,25 @@ static int run_setup(hg_ctx *c)
         const bool compact = patch_preferred(c, nullptr) || c->pw_cover > 56;
         if (compact != c->pw_compact) { c->pw_compact = compact; c->rows_clean = false; }
         RowLists rl = rows_of(c);
-        // Row counters + kStatusRing sets of per-frame status words share one allocation.  It is zeroed by a memset only
-        // for the first step after new frames (or after a setup whose warp never ran): k_pw_rows leaves the counters and
-        // the next status set zeroed for the step that follows it.
+        // Two sets of row counters (ping-pong) + kStatusRing sets of per-frame status words share one allocation.  It is zeroed by a
+        // memset only when the layout changes (or after a setup whose warp never ran): the warp kernel of a step zeroes the OTHER
+        // counter set -- the one the previous step consumed, the one the next step counts into -- and the next status set.
         const int32_t *before = c->d_rowcnt;
-        if (F * rl.row_stride + kStatusRing * F > c->rowcnt_cap ||
+        if (2 * F * rl.row_stride + kStatusRing * F > c->rowcnt_cap ||
             F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt)) > c->rowent_cap) HG_TRY(hg_sync(c));   // (queued runs flag into the old ring)
-        HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, F * rl.row_stride + kStatusRing * F));
+        HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, 2 * F * rl.row_stride + kStatusRing * F));
         HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt))));
         rl = rows_of(c);
         if (before != c->d_rowcnt || c->rows_F != F || c->rows_stride != rl.row_stride || c->rows_cap != rl.cap) c->rows_clean = false;
         c->rows_F = F; c->rows_stride = rl.row_stride; c->rows_cap = rl.cap;
-        if (c->rows_clean) c->status_slot = (c->status_slot + 1) % (int)kStatusRing;
+        if (c->rows_clean) { c->status_slot = (c->status_slot + 1) % (int)kStatusRing; c->rows_parity ^= 1; }
         else {
             HG_TRY(hg_sync(c));                              // (queued runs still own status sets)
-            c->status_slot = 0;
-            HIP_TRY(c, hipMemsetAsync(c->d_rowcnt, 0, sizeof(int32_t) * (F * rl.row_stride + kStatusRing * F), c->stream));
+            c->status_slot = 0; c->rows_parity = 0;
+            HIP_TRY(c, hipMemsetAsync(c->d_rowcnt, 0, sizeof(int32_t) * (2 * F * rl.row_stride + kStatusRing * F), c->stream));
         }
-        c->status_base = c->d_rowcnt + F * rl.row_stride;
+        rl = rows_of(c);                                     // (parity settled)
+        c->status_base = c->d_rowcnt + 2 * F * rl.row_stride;
         c->status_ptr = c->status_base + (size_t)c->status_slot * F;
         c->status_next = c->status_base + (size_t)((c->status_slot + 1) % (int)kStatusRing) * F;
         c->rows_clean = false;                               // dirty until the warp kernel has consumed them
@@ -1139,9 +1157,18 @@ extern "C" int hg_sync(hg_ctx *c)
         const int st0 = pending.front().stage;
         const size_t F = (st0 >= 0 && c->stage[st0].h) ? (size_t)c->stage[st0].n : c->pw_frames.size();
         if (c->status_base) HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
-        for (const hg_ctx::Pending &p : pending)
+        for (size_t i = 0; i < pending.size(); i++) {
+            const hg_ctx::Pending &p = pending[i];
+            // a later queued run into the SAME output allocation has overwritten this run's frames already (a caller that reuses one
+            // buffer step after step): redoing them now would put stale frames over newer ones
+            bool superseded = false;
+            for (size_t j = i + 1; j < pending.size() && !superseded; j++) superseded = pending[j].out == p.out;
             for (size_t f = 0; f < F; f++)
-                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; HG_TRY(redo_frame_staged(c, p.stage, (int)f, p.out)); }
+                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) {
+                    redo = true; c->pw_redone++;
+                    if (!superseded) HG_TRY(redo_frame_staged(c, p.stage, (int)f, p.out));
+                }
+        }
         if (redo) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->pw_used_patch) c->pw_patch_disabled = true;   // (its limits are tighter than k_pw_rows': do not pay the map path again)

@@ -172,10 +172,11 @@ void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double 
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     const bool fast = ((int64_t)H + 2) * W * 4 < ((int64_t)1 << 31) && hi_bounds_ok(0, W, 0, H) && max_w < (1 << 28);
     if (fast) {
-        const int NW = nw == 1 ? 1 : (nw == 2 ? 2 : 4);        // windows per wave (measured on C2, 1 -> 2 -> 4: 0.198 -> 0.177 -> 0.171 ms)
+        const int NW = nw == 1 ? 1 : (nw == 2 ? 2 : (nw >= 8 ? 8 : 4));        // windows per wave (measured on C2, 1 -> 2 -> 4: 0.198 -> 0.177 -> 0.171 ms; round 3, 4 -> 8: 0.162 -> 0.153, one source per frame 0.219 -> 0.199)
         dim3 grid((max_w + 256 * NW - 1) / (256 * NW), (max_h + 3) / 4, n_frames);
 #define HG_GEO(K) do { if (NW == 1) hipLaunchKernelGGL((k_geo_fast<K, 1>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); \
                        else if (NW == 4) hipLaunchKernelGGL((k_geo_fast<K, 4>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); \
+                       else if (NW == 8) hipLaunchKernelGGL((k_geo_fast<K, 8>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); \
                        else hipLaunchKernelGGL((k_geo_fast<K, 2>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); } while (0)
         if (kind == 1 && plain) HG_GEO(4);
         else if (kind == 1 && f32_exact) HG_GEO(3);

@@ -27,7 +27,7 @@ static_assert(kPatchHash * 4 <= kPatchRows * kPatchBins * kPatchBinSlots, "the h
 // resident) from global memory and widens it itself; the LDS then holds 4 x 512 spans (30.4 KB, five workgroups per CU).
 constexpr int kPatchCapDense = 512;
 
-template <bool GLOBALREC, bool HIB>
+template <bool GLOBALREC, bool HIB, int PB = 1>      // PB: column blocks whose gathers are in flight before the first is stored
 __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                   int groups_per_xcd, int32_t *__restrict__ status_next)
 {
@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * kPatchRows;
     const FrameDesc fd = fr.frames[f];
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;   // (see k_pw_rows)
+    // the OTHER counter set, every row of the frame's block: clean for the next step's k_tri_spans (ping-pong, see k_pw_rows)
+    if ((int)threadIdx.x < kPatchRows && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_rec[GLOBALREC ? 6 : (kPatchRecs + 1) * 6];   // {m0, m2, m4, m1, m3, m5} per triangle; last = NaN record
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     const int W = fd.obj_w;
     const int nbins = (W + 63) >> 6;
     const int nrows = min(kPatchRows, fd.obj_h - r0);
-    int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    const int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
     int cnts[kPatchRows], cmax = 0;
 #pragma unroll
     for (int j = 0; j < kPatchRows; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
@@ -60,7 +62,6 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     if (!GLOBALREC) for (int i = threadIdx.x; i < kPatchHash; i += 256) s_hash[i] = 0u;
     if (threadIdx.x == 0) { s_nrec = 0; s_fail = (cmax > rl.cap || cmax > CAPR - 1 || nbins > kPatchBins) ? 1 : 0; }
     __syncthreads();
-    if ((int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;                    // every wave has read the counters: clean for the next step
     const bool bad0 = s_fail != 0;
 
     // ---- phase 1: span lists -> LDS; each triangle of the group gets ONE matrix record (hash on the id: the thread that
@@ -224,12 +225,18 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
         }
         __builtin_amdgcn_wave_barrier();
     };
-    // This wave's column blocks cw = wave, wave + 4, ...  (Measured and dropped: two blocks per phase -- the gathers of block A
-    // in flight while block B is resolved -- 0.504 vs 0.503 ms on C5: the wait for a block's gathers is not what limits it.)
-    for (int cw = wave; cw < nbins; cw += 4) {
-        uint32_t px[4];
-        resolve_gather(cw, px);
-        transpose_store(cw, px);
+    // This wave's column blocks cw = wave, wave + 4, ..., PB of them per phase: all their gathers are in flight before the first
+    // block is transposed and stored (loads and stores share vmcnt, see k_pw_rows).  Round 2 measured 2 blocks per phase on C5
+    // with a shared source and found nothing (0.504 vs 0.503 ms); round 3, same box, blocks per phase 1 / 2 / 4 / 8 / 16:
+    // C5 shared 0.419 / 0.412 / 0.405 / 0.392-0.397 / 0.404 ms, C5 one source per frame 0.612 / 0.593 / 0.588 / 0.565-0.586 / 0.557,
+    // C3 one source per frame 0.924 / 0.871 / 0.847 / 0.819-0.823 / 0.828 -- 8 is the default (86 VGPRs: still the 5 workgroups
+    // per CU the LDS allows; 16 takes 128).
+    for (int cw = wave; cw < nbins; cw += 4 * PB) {
+        uint32_t px[PB][4];
+#pragma unroll
+        for (int b = 0; b < PB; b++) if (cw + 4 * b < nbins) resolve_gather(cw + 4 * b, px[b]);
+#pragma unroll
+        for (int b = 0; b < PB; b++) if (cw + 4 * b < nbins) transpose_store(cw + 4 * b, px[b]);
     }
 }
 
@@ -240,9 +247,13 @@ void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl,
     const int gpx = ((fr.max_obj_h + kPatchRows - 1) / kPatchRows + nx - 1) / nx;
     const dim3 grid((unsigned)gpx * (unsigned)nx * (unsigned)fr.n_frames);
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-#define HG_PATCH(G, HB) hipLaunchKernelGGL((k_pw_patch<G, HB>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, status_next)
-    if (global_records) { if (hib) HG_PATCH(true, true); else HG_PATCH(true, false); }
-    else                { if (hib) HG_PATCH(false, true); else HG_PATCH(false, false); }
+#define HG_PATCH(G, HB, PBV) hipLaunchKernelGGL((k_pw_patch<G, HB, PBV>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, status_next)
+    if (global_records) { if (hib) HG_PATCH(true, true, 1); else HG_PATCH(true, false, 1); }
+    else if (!hib) HG_PATCH(false, false, 1);
+    else if (fr.patch_blocks >= 8) HG_PATCH(false, true, 8);  // (option "phase" / the layout policy: blocks per phase)
+    else if (fr.patch_blocks >= 4) HG_PATCH(false, true, 4);
+    else if (fr.patch_blocks >= 2) HG_PATCH(false, true, 2);
+    else HG_PATCH(false, true, 1);
 #undef HG_PATCH
 }
 

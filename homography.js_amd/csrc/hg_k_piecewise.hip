@@ -270,13 +270,22 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // for dense meshes (there, rows that share source lines should run side by side in different workgroups).  1-D grid decoded so that XCD x (= block id % number of XCCs of the device -- hipDeviceAttributeNumberOfXccs, hg_create --, the observed
     // dispatch order; speed only, never correctness) walks a contiguous band of rows of one frame: vertically adjacent
     // output rows share source cache lines, which then stay in that XCD's L2 instead of being fetched by up to 8 of them.
-    const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1), bi = bid >> fr.xcc_log2;
+    // Small frame sets (a single 4K frame is 2239 one-row workgroups for 256 CUs, each a chain of two list round trips and ~4
+    // windows per wave): fr.col_split workgroups share a row group, each taking a contiguous range of its windows.
+    const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1);
+    int bi = bid >> fr.xcc_log2, seg = 0;
+    if (fr.col_split > 1) { seg = bi % fr.col_split; bi /= fr.col_split; }
     const int f = bi / groups_per_xcd;
     const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * rows_per_group;
     const FrameDesc fd = fr.frames[f];
-    // housekeeping for the NEXT step (saves its memset): the other parity's status words are cleared here, and below every
-    // workgroup zeroes the span counters of its rows once all its waves have read them
-    if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;
+    // housekeeping for the NEXT step (saves its memset): the next status set is cleared here, and every workgroup zeroes the
+    // span counters of its rows in the OTHER of the two counter sets -- the one the previous step consumed and the next step's
+    // k_tri_spans will count into (ping-pong: nobody reads it during this launch, so no ordering against this launch's readers)
+    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;       // 256 threads; 128 for one-row workgroups of small frame sets (launcher)
+    if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += nthreads) status_next[i] = 0;
+    // (every row of the frame's counter block, not only the rows of THIS step's window: the other set was filled under the
+    //  previous step's geometry, whose frame may have been a row taller)
+    if ((int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_m[CAP * 6];
@@ -288,20 +297,20 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     const int W = fd.obj_w;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: the window loop runs on the scalar unit
-    const int nwin = (W + 255) >> 8;
+    const int nwin_row = (W + 255) >> 8;
+    const int w_lo = fr.col_split > 1 ? (seg * nwin_row) / fr.col_split : 0;              // this workgroup's windows of each row
+    const int nwin = fr.col_split > 1 ? ((seg + 1) * nwin_row) / fr.col_split : nwin_row;   // (exclusive end)
     const int nrows = min(rows_per_group, fd.obj_h - r0);
 
     // ---- span counts of the group's rows.  Packed mode (every row has at most 63 spans: the common case): all four
     // lists are loaded at once, one barrier, then wave j walks row r0 + j alone -- the list-load latency is paid once per
     // four rows and a row's span scan is a single ballot.  Otherwise the rows are taken one after the other with the
     // whole LDS (up to CAP - 1 spans) and the windows of a row are dealt to the four waves.
-    int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    const int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
     int cnts[kRowGroup], cmax = 0;
 #pragma unroll
     for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
     if (cmax > rl.cap || cmax > CAP - 1) {
-        __syncthreads();                                    // every wave has read the counters before they are cleared
-        if ((int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;
         if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
         return;
     }
@@ -460,10 +469,9 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         const int row = packed ? wave : pass;               // everything below is wave-uniform (scalar registers)
         const int cnt = __builtin_amdgcn_readfirstlane(cnts[0] * (row == 0) + cnts[1] * (row == 1) + cnts[2] * (row == 2) + cnts[3] * (row == 3));
         const int base = packed ? wave * 64 : 0, nan_slot = packed ? 63 : CAP - 1;
-        load_row(row, cnt, base, nan_slot, packed ? lane : (int)threadIdx.x, packed ? 64 : 256);
+        load_row(row, cnt, base, nan_slot, packed ? lane : (int)threadIdx.x, packed ? 64 : nthreads);
         __syncthreads();
-        if (pass == 0 && (int)threadIdx.x < nrows) cntp[threadIdx.x] = 0;
-        if (row < nrows) do_row(row, cnt, base, nan_slot, packed ? 0 : wave, packed ? 1 : 4);
+        if (row < nrows) do_row(row, cnt, base, nan_slot, w_lo + (packed ? 0 : wave), packed ? 1 : nwaves);
         if (!packed) __syncthreads();                       // the next row overwrites the records
     }
 }
@@ -534,11 +542,14 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
     const int nx = 1 << fr.xcc_log2;                                            // XCCs of this device (partition mode), hg_create
     const int rpx = ((fr.max_obj_h + rg - 1) / rg + nx - 1) / nx;               // row groups per XCD band
-    dim3 grid((unsigned)rpx * (unsigned)nx * (unsigned)fr.n_frames);
+    dim3 grid((unsigned)rpx * (unsigned)nx * (unsigned)fr.n_frames * (unsigned)std::max(fr.col_split, 1));
     // bounds :1047 on the high dwords of the rounded coordinates (hg_dev.h) whenever the source window allows it; the fp64
     // compares otherwise (negative source minimum, sources beyond 2^20 pixels a side) and in the parity-tap instantiations
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-#define HG_ROWS(CAP, MAPF, PHV, CMP, HB) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB>), grid, dim3(256), (size_t)fr.lds_pad_kb * 1024, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
+    // one-row workgroups of a SMALL frame set run with 2 waves instead of 4: a single 4K frame is 2239 workgroups, 256 CUs hold 2048
+    // four-wave ones -- the rest waited for a second round -- but 4096 two-wave ones (measured round 3, F = 1: warp kernel 15.3 -> see DESIGN §4.2)
+    const dim3 block(rg == 1 && fr.rows1_threads == 128 ? 128 : 256);
+#define HG_ROWS(CAP, MAPF, PHV, CMP, HB) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB>), grid, block, (size_t)fr.lds_pad_kb * 1024, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
 #define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true); else HG_ROWS(CAP, false, 1, CMP, false); } while (0)
     if (rl.cap > kRowSpanCapFast) {                          // very dense meshes: 512 LDS slots per row (32 KB), one row per workgroup
         if (rl.compact) { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, true, false); else HG_ROWS_B(kRowSpanCapDense, 1, true); }
@@ -558,7 +569,7 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     switch (fr.phase) {
     case 4:  HG_ROWS_B(kRowSpanCapFast, 4, false); break;
     case 2:
-        if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true>), grid, dim3(256), (size_t)fr.lds_pad_kb * 1024, stream,
+        if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true>), grid, block, (size_t)fr.lds_pad_kb * 1024, stream,
                                                    mesh, fr, rl, out, map_out, rpx, rg, status_next);
         else HG_ROWS_B(kRowSpanCapFast, 2, false);
         break;

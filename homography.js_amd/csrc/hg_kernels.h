@@ -63,6 +63,9 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t tri_threads;            // k_tri_spans workgroup size: 128, or 64 when the triangles are short (one row per thread)
     int32_t phase;                  // k_pw_rows: windows whose gathers are issued before their stores (1, 2 or 4)
     int32_t xcc_log2;               // log2 of the device's XCC count (8 on an unpartitioned MI355X): block id -> XCD row band
+    int32_t patch_blocks;           // k_pw_patch: 64-pixel column blocks per gather / store phase (1, 2, 4, 8)
+    int32_t rows1_threads;          // k_pw_rows with one row per workgroup: 256 threads, or 128 for small frame sets (more workgroups resident)
+    int32_t col_split;              // k_pw_rows: workgroups per row group, each with a contiguous share of the windows (small frame sets)
     int32_t lds_pad_kb;             // option "lds_pad": KB of unused dynamic LDS per k_pw_rows workgroup (caps the workgroups resident per CU)
     int32_t lds_pad_patch_kb;       // the same for k_pw_patch (explicit option only: it loses with fewer workgroups)
     int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only
@@ -81,7 +84,8 @@ struct RowEnt { uint32_t lo_hi; int32_t id; float m[6]; };
 struct RowEnt8 { uint32_t lo_hi; int32_t id; };
 static_assert(sizeof(RowEnt) == 32 && sizeof(RowEnt8) == 8, "span entry sizes");
 struct RowLists {
-    int32_t *cnt;            // F x row_stride   (zeroed before every k_tri_spans launch)
+    int32_t *cnt;            // F x row_stride: this step's counters (k_tri_spans counts into them, the warp kernel reads them)
+    int32_t *cnt_clear;      // the other of the two counter sets, same layout: the warp kernel zeroes it for the NEXT step (ping-pong)
     void *ent;               // F x row_stride x cap entries of 32 (RowEnt) or 8 (RowEnt8) bytes
     int32_t compact;         // 1: RowEnt8
     int32_t row_stride;      // >= max obj_h

@@ -280,7 +280,7 @@ long hg_layout_walks(hg_ctx *ctx);
  *           global-record variant;
  *   "phase" (default -1 = 2 for a shared source -- 4 when the rows carry 3 or more spans per window --, 1 with one source per frame):
  *           windows per k_pw_rows gather/store phase, 1, 2 or 4;
- *   "geo_windows" (default 4): 256-pixel windows per wave of the affine / projective kernel, 1, 2 or 4;
+ *   "geo_windows" (default 8): 256-pixel windows per wave of the affine / projective kernel, 1, 2, 4 or 8;
  *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
  *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
  *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;

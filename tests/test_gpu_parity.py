@@ -20,7 +20,7 @@ GOLD = G.load()
 # ("hi_bounds": 0 keeps the fp64 form of the source-bounds tests, "xcc" changes the block id -> row band mapping: both are folded
 #  into the existing layouts so that every kernel runs under either form without multiplying the suite.)
 LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds": 0, "xcc": 4}, "rows1": {"min_row_groups": 1 << 30, "patch": 0, "xcc": 1},
-           "patch": {"min_row_groups": 0, "patch": 1}, "patch_global": {"min_row_groups": 0, "patch": 2, "hi_bounds": 0, "xcc": 2},
+           "patch": {"min_row_groups": 0, "patch": 1, "phase": 2}, "patch_global": {"min_row_groups": 0, "patch": 2, "hi_bounds": 0, "xcc": 2},
            "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0},
            "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16}}
 
@@ -740,9 +740,66 @@ def test_fresh_point_sets_queue_without_settling_and_redo_from_their_own_set(ctx
                 want = O.warp_inverse_piecewise(sp, sets[s][f], tris, img, ms[0], ms[1], *g)
                 got = ctx.to_host(outs[s], g[2] * g[3] * 4, packs[s][0][f]).reshape(g[3], g[2], 4)
                 assert np.array_equal(got, want), (s, f)
+        # many steps alternating between windows of different heights: the two counter sets stay clean (nothing is flagged, nothing redone)
+        tall = [WL.sin_dst(sp, 9.0, 8 + f) for f in range(3)]
+        gt = [WL.piecewise_geom(d) for d in tall]
+        pt = HG.pack_offsets(gt)
+        assert any(a[3] != b[3] for a, b in zip(gt, geoms[0]))
+        big = ctx.alloc(max(pt[1], packs[0][1]))
+        try:
+            ctx.sync()
+            r1 = ctx.redone_frames()
+            for it in range(120):
+                which = (it % 3) != 0
+                ctx.piecewise_set_frames(np.concatenate(tall if which else sets[0]), gt if which else geoms[0], pt[0] if which else packs[0][0])
+                ctx.warp_inverse_piecewise_frames_device(big)
+            ctx.sync()
+            assert ctx.redone_frames() == r1, "frames were flagged: a counter set was left dirty"
+            for f, g in enumerate(gt):                         # the last step (it = 119) warped the tall set
+                want = O.warp_inverse_piecewise(sp, tall[f], tris, img, ms[0], ms[1], *g)
+                assert np.array_equal(ctx.to_host(big, g[2] * g[3] * 4, pt[0][f]).reshape(g[3], g[2], 4), want), ("alternating", f)
+        finally:
+            ctx.free(big)
     finally:
         for o in outs:
             ctx.free(o)
+
+
+def test_redo_of_an_earlier_step_never_lands_on_a_later_steps_frames():
+    """One output buffer reused step after step (bench.py --points fresh): step 1 warps a mesh whose rows carry 1100 spans (always
+    beyond the row lists: flagged, to be redone through the map path at hg_sync), step 2 -- queued before any sync -- warps a
+    degenerate point set (every x equal: no spans, a blank frame) into the SAME buffer.  The deferred redo of step 1 must not
+    put its frame over step 2's."""
+    n, W2, H2 = 1100, 2400, 8
+    img2 = G.lcg_image(W2, H2, 10)
+    xs = np.linspace(0, W2, n + 1)
+    sp2 = np.stack([np.repeat(xs, 2), np.tile([0.0, H2], n + 1)], 1).astype(np.float32).ravel()
+    tr2 = np.array([[2 * i, 2 * i + 2, 2 * i + 1] for i in range(n)], np.uint32).ravel()
+    dp_a = sp2.copy(); dp_a[1::2] *= 1.5
+    dp_b = dp_a.copy(); dp_b[0::2] = 5.0
+    mm, md = O.minmax_xy(sp2), O.minmax_xy(dp_a)
+    g = (int(md[0]), int(md[1]), int(md[2] - md[0]), int(md[3] - md[1]))
+    want_a = O.warp_inverse_piecewise(sp2, dp_a, tr2, img2, int(mm[0]), int(mm[1]), *g)
+    want_b = O.warp_inverse_piecewise(sp2, dp_b, tr2, img2, int(mm[0]), int(mm[1]), *g)
+    assert want_a.any() and not want_b.any()
+    c = HG.Context(0)
+    try:
+        c.set_image(img2)
+        c.piecewise_set_mesh(sp2, tr2, int(mm[0]), int(mm[1]))
+        d_out = c.alloc(g[2] * g[3] * 4)
+        c.piecewise_set_frames(dp_a, [g], [0]); c.warp_inverse_piecewise_frames_device(d_out)
+        c.piecewise_set_frames(dp_b, [g], [0]); c.warp_inverse_piecewise_frames_device(d_out)
+        c.sync()
+        assert c.redone_frames() >= 1                         # step 1 WAS flagged ...
+        assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4).reshape(g[3], g[2], 4), want_b)     # ... and step 2's frame stands
+        # the other order: the flagged step is the last one into the buffer, so its redo is what the buffer must hold
+        c.piecewise_set_frames(dp_b, [g], [0]); c.warp_inverse_piecewise_frames_device(d_out)
+        c.piecewise_set_frames(dp_a, [g], [0]); c.warp_inverse_piecewise_frames_device(d_out)
+        c.sync()
+        assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4).reshape(g[3], g[2], 4), want_a)
+        c.free(d_out)
+    finally:
+        c.close()
 
 
 def test_empty_and_degenerate_inputs(ctx):

@@ -24,7 +24,7 @@ for t in range(trials):
     ctx.set_option("phase", int(rng.choice([-1, 1, 2, 4])))
     ctx.set_option("patch", int(rng.choice([-1, -1, 0, 1, 2])))
     ctx.set_option("min_row_groups", int(rng.choice([1536, 0, 1 << 30])))
-    ctx.set_option("geo_windows", int(rng.choice([1, 2, 4])))
+    ctx.set_option("geo_windows", int(rng.choice([1, 2, 4, 8])))
     ctx.set_option("fwd_tiles", int(rng.choice([-1, 0, 1, 1])))
     ctx.set_option("hi_bounds", int(rng.choice([1, 1, 0])))
     ctx.set_option("xcc", int(rng.choice([8, 8, 1, 2, 4, 16])))
