@@ -50,11 +50,11 @@ static bool launch_tri_spans_ablated(const PwMesh &mesh, const PwFrames &fr, con
     }
 }
 
-static bool launch_pw_rows_ablated(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int rpx, int rg,
+static bool launch_pw_rows_ablated(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, const TriTable &tb, uint8_t *out, int16_t *map_out, int rpx, int rg,
                                    int32_t *status_next, dim3 grid, hipStream_t stream)
 {
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;
-#define HG_ABL(N) case N: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, Ablate<N>, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return true
+#define HG_ABL(N) case N: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, Ablate<N>, false>), grid, dim3(256), 0, stream, mesh, fr, rl, tb, out, map_out, rpx, rg, status_next); return true
     switch (abl) {
     HG_ABL(1); HG_ABL(2); HG_ABL(4); HG_ABL(6); HG_ABL(8); HG_ABL(14); HG_ABL(16);
     default: return false;

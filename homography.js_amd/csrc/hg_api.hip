@@ -95,6 +95,14 @@ struct hg_ctx {
     int32_t *d_redo_status = nullptr; size_t redo_status_cap = 0;
     // layout of the row counters / status ring as of their last memset (a frame set with the same layout reuses them as they are)
     size_t rows_F = 0; int rows_stride = 0, rows_cap = 0;
+    // table path (k_tri_table -> k_pw_rows<TBL>, hg_kernels.h): spans per (frame, triangle, source row), no row lists
+    int2 *d_tbl = nullptr; size_t tbl_cap = 0;
+    int tbl_stride = 0;                                        // entries per triangle (>= the tallest triangle of the frame set; doubles after an overflow)
+    int pw_tri_rows_max = 0;                                   // tallest triangle of the uploaded frames, in rows (host estimate)
+    bool pw_table = false;                                     // the current step uses the table path
+    bool pw_table_disabled = false;                            // it overflowed twice: row lists from now on
+    int pw_table_grown = 0;
+    int opt_table = -1;                                        // -1 auto, 0 never, 1 whenever eligible
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
     int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
     int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
@@ -238,7 +246,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
-    void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent,
+    void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent, c->d_tbl,
                      c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -343,6 +351,7 @@ extern "C" int hg_copy_to_device(hg_ctx *c, void *dst, const void *src, size_t b
 extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kernel : 0; }
 extern "C" int hg_last_forward_kernel(hg_ctx *c) { return c ? c->fwd_last_kernel : 0; }
 
+extern "C" int hg_last_piecewise_table(hg_ctx *c) { return c && c->pw_table ? 1 : 0; }
 extern "C" long hg_redone_frames(hg_ctx *c) { return c ? c->pw_redone : 0; }
 extern "C" long hg_layout_walks(hg_ctx *c) { return c ? c->pw_layout_walks : 0; }
 
@@ -356,6 +365,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "geo_windows")) c->opt_geo_nw = value;
     else if (!std::strcmp(key, "hi_bounds")) c->opt_hi_bounds = value != 0;
     else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
+    else if (!std::strcmp(key, "table")) { c->opt_table = value; c->pw_table_disabled = false; }
     else if (!std::strcmp(key, "rows1_threads")) c->opt_rows1_threads = (value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "col_split")) c->opt_col_split = (value == 1 || value == 2 || value == 4) ? value : -1;
     else if (!std::strcmp(key, "lds_pad")) c->opt_lds_pad = std::min(std::max(value, -1), 40);
@@ -727,8 +737,9 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
 // Largest number of triangles whose fillTriangle row range (:1113-1120) covers one output row, over the uploaded frames:
 // an estimate of the longest per-row span list, used ONLY to pick k_pw_rows' layout (4 rows per workgroup with 64 LDS
 // slots each, or 1 row with all 256); the kernel checks the real counts and is exact either way.
-static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_rows, int *max_group_tris, double *mean_shear)
+static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_rows, int *max_group_tris, double *mean_shear, int *max_tri_rows)
 {
+    double tallest = 0.0;
     int worst = 0, worst_group = 0;
     double rows_total = 0.0, tris_total = 0.0, shear_total = 0.0, shear_n = 0.0;
     std::vector<int> diff, tdiff, starts;
@@ -768,6 +779,7 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
             if (!(a < b)) continue;
             diff[(size_t)a] += 1; diff[(size_t)b] -= 1;
             rows_total += b - a; tris_total += 1.0;
+            tallest = std::max(tallest, std::min(std::ceil(hi) - std::trunc(lo), 1.0e6));       // rows of fillTriangle's loop :1113-1120
             // tighter, for the triangles-per-group estimate: a triangle has spans on the integer rows inside [minY, maxY]
             // (:1179; triangles that only touch a row at a vertex between two integers do not count), plus the spill row when
             // the window is offset in x
@@ -787,6 +799,7 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
     *mean_tri_rows = tris_total > 0 ? rows_total / tris_total : 0.0;
     *max_group_tris = worst_group;
     *mean_shear = shear_n > 0 ? shear_total / shear_n : 0.0;
+    *max_tri_rows = (int)tallest;
     return worst;
 }
 
@@ -856,7 +869,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     c->pw_frames.swap(fresh);
     c->stage_cur = slot;
     double tri_rows = 0.0, shear = 0.0;
-    int group_tris = 0, max_w = 0, cover = 0;
+    int group_tris = 0, max_w = 0, cover = 0, tall = 0;
     int64_t total_px = 0;
     for (const FrameDesc &d : c->pw_frames) { max_w = std::max(max_w, d.obj_w); if (d.obj_w > 0 && d.obj_h > 0) total_px += (int64_t)d.obj_w * d.obj_h; }
     int max_h = 0;
@@ -873,7 +886,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
                             std::abs(ok.max_w - key.max_w) * 16 <= ok.max_w && std::abs(ok.max_h - key.max_h) * 16 <= ok.max_h &&
                             c->layout_age < 256;
     if (same_shape) {
-        cover = c->pw_cover; tri_rows = c->pw_tri_rows; group_tris = c->pw_group_tris; shear = c->pw_shear;
+        cover = c->pw_cover; tri_rows = c->pw_tri_rows; group_tris = c->pw_group_tris; shear = c->pw_shear; tall = c->pw_tri_rows_max;
         c->layout_age++;
     } else if (quick) {
         // small frames of a dense mesh (the README's 400x400 / 23 000-triangle benchmark): walking every triangle on the host
@@ -881,12 +894,13 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
         cover = (int)(2.5 * std::sqrt((double)c->n_tris));
         group_tris = 1 << 30;                               // (no k_pw_patch without the real estimate)
         tri_rows = 64.0;
+        tall = 0;                                           // (unknown: no table path without the walk)
     } else {
-        cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear);
+        cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear, &tall);
         c->pw_layout_walks++;
     }
     if (!same_shape) { c->layout_key = key; c->layout_age = 0; }
-    c->pw_tri_rows = tri_rows; c->pw_group_tris = group_tris;
+    c->pw_tri_rows = tri_rows; c->pw_group_tris = group_tris; c->pw_tri_rows_max = tall;
     c->pw_cover = cover;
     c->pw_spans_per_window = max_w > 0 ? (double)cover * 256.0 / (double)max_w : 0.0;
     c->pw_row_group = cover <= 56 ? kRowGroup : 1;
@@ -950,7 +964,7 @@ static PwFrames frames_of(const hg_ctx *c)
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     f.max_obj_h = mh;
     f.row_group = c->pw_row_group;
-    f.tri_threads = c->pw_tri_threads;
+    f.tri_threads = c->pw_table ? (c->pw_tri_rows_max <= 64 ? 64 : (c->pw_tri_rows_max <= 160 ? 128 : 256)) : c->pw_tri_threads;
     // Windows per phase, measured (C3 / C4, 64 frames): shared (cache-resident) source: 2, or 4 when a window holds
     // several spans (C4's face mesh ~4.5, C3 1.5: the longer span walk then overlaps four windows' gathers); one source per
     // frame (HBM-bound): 4 windows per phase AND fewer, deeper waves -- 12-16 KB of idle LDS per workgroup leave 5 of them on a
@@ -1015,15 +1029,27 @@ static int run_setup(hg_ctx *c)
         // entry format of the span lists (hg_kernels.h): 8 bytes for dense rows and whenever k_pw_patch will read them
         const bool compact = patch_preferred(c, nullptr) || c->pw_cover > 56;
         if (compact != c->pw_compact) { c->pw_compact = compact; c->rows_clean = false; }
+        // Table path (k_tri_table -> k_pw_rows<TBL>): sparse meshes -- where the row lists would carry 32-byte entries -- whose
+        // triangles a workgroup can afford to scan (every 4-row group tests all of them); the tallest triangle sizes the table.
+        // Layout choice only: what does not fit (a taller triangle, more spans per row than a packed block holds) flags its frame.
+        const size_t T = (size_t)std::max(c->n_tris, 1);
+        c->pw_table = !compact && !c->pw_table_disabled && c->opt_table != 0 && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 &&
+                      c->pw_tri_rows_max > 0 && c->pw_tri_rows_max <= 8192 && (c->pw_row_group == 1 || c->pw_cover <= 56);
+        if (c->pw_table) {
+            const int want = ((c->pw_tri_rows_max + 8 + 15) / 16) * 16 << c->pw_table_grown;
+            if (want > c->tbl_stride) c->tbl_stride = want;
+            if (F * T * (size_t)c->tbl_stride > ((size_t)1 << 28)) c->pw_table = false;          // (2 GiB of table: not this path)
+        }
+        if (c->pw_table) HG_TRY(ensure(c, c->d_tbl, c->tbl_cap, F * T * (size_t)c->tbl_stride));
         RowLists rl = rows_of(c);
         // Two sets of row counters (ping-pong) + kStatusRing sets of per-frame status words share one allocation.  It is zeroed by a
         // memset only when the layout changes (or after a setup whose warp never ran): the warp kernel of a step zeroes the OTHER
         // counter set -- the one the previous step consumed, the one the next step counts into -- and the next status set.
         const int32_t *before = c->d_rowcnt;
-        if (2 * F * rl.row_stride + kStatusRing * F > c->rowcnt_cap ||
-            F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt)) > c->rowent_cap) HG_TRY(hg_sync(c));   // (queued runs flag into the old ring)
+        const size_t ent_bytes = c->pw_table ? 0 : F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt));
+        if (2 * F * rl.row_stride + kStatusRing * F > c->rowcnt_cap || ent_bytes > c->rowent_cap) HG_TRY(hg_sync(c));   // (queued runs flag into the old ring)
         HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, 2 * F * rl.row_stride + kStatusRing * F));
-        HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt))));
+        HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, ent_bytes));
         rl = rows_of(c);
         if (before != c->d_rowcnt || c->rows_F != F || c->rows_stride != rl.row_stride || c->rows_cap != rl.cap) c->rows_clean = false;
         c->rows_F = F; c->rows_stride = rl.row_stride; c->rows_cap = rl.cap;
@@ -1037,8 +1063,14 @@ static int run_setup(hg_ctx *c)
         c->status_base = c->d_rowcnt + 2 * F * rl.row_stride;
         c->status_ptr = c->status_base + (size_t)c->status_slot * F;
         c->status_next = c->status_base + (size_t)((c->status_slot + 1) % (int)kStatusRing) * F;
-        c->rows_clean = false;                               // dirty until the warp kernel has consumed them
-        launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
+        if (c->pw_table) {                                   // (the counters stay untouched: clean for whichever path runs next)
+            c->rows_clean = true;
+            TriTable tb; tb.ent = c->d_tbl; tb.stride = c->tbl_stride;
+            launch_tri_table(mesh_of(c), frames_of(c), tb, c->stream);
+        } else {
+            c->rows_clean = false;                           // dirty until the warp kernel has consumed them
+            launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
+        }
     } else {
         HG_TRY(hg_sync(c));                                  // (queued fast-path runs are settled against their own status ring first)
         c->status_ptr = c->d_status;
@@ -1057,7 +1089,10 @@ static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
     c->pw_used_patch = patch;
     c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
     if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
-    else if (c->pw_fast) { launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true; }
+    else if (c->pw_fast) {
+        TriTable tb; tb.ent = c->pw_table ? c->d_tbl : nullptr; tb.stride = c->tbl_stride;
+        launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), tb, d_out, map_out, c->status_next, c->stream); c->rows_clean = true;
+    }
     else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
 }
 
@@ -1175,6 +1210,9 @@ extern "C" int hg_sync(hg_ctx *c)
             if (c->pw_fast && c->row_cap < kRowSpanCapDense)      // denser mesh than assumed: larger lists next time
                 c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
             c->layout_age = 1 << 30;                             // ... and a fresh layout estimate for the next frame set
+            if (c->pw_table) {                                   // the table path flagged: taller triangles than estimated (or denser rows): once more with twice the stride, then row lists
+                if (c->pw_table_grown >= 1) c->pw_table_disabled = true; else c->pw_table_grown++;
+            }
         }
     }
     if (c->fwd_pending.n > 0) {

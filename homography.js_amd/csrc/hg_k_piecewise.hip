@@ -261,8 +261,82 @@ __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
     }
 }
 
-template <int CAP, class X, bool MAP, int PH, bool COMPACT, bool HIB>
-__device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *__restrict__ out,
+
+// ------------------------------------------------------------------------------------------------ k_tri_table (round 3)
+// The same work as k_tri_spans -- per (frame, triangle): solves, edge equations, one thread per source row y evaluating
+// predictXLimits + the two flat fill() indices exactly -- but the result is NOT filed under output rows.  Row y's cells
+// [k, fin) (after TypedArray.fill's index rules) go to  tbl[frame][triangle][y - y_first]  as two int32: consecutive threads
+// write consecutive 8-byte entries and nobody needs a slot, so the 3.2 M returning atomics + scattered 32-byte stores that are
+// 35 of k_tri_spans' 48 us on C3 (ablation, round 3: neither 13 us) disappear.  Which triangles (and which of their rows) reach
+// an output row is decided by the consumer from the per-triangle TriRange {y_first, y_stop, a, b} written here (k_pw_rows<TBL>):
+// row y's cells lie in output rows (y - yOff) + b .. (y - yOff) + a, or objH further down when fill() wrapped a negative
+// index -- the enumeration k_pw_fused has always used.  A triangle with more rows than the table stride, or one the bounds
+// cannot describe (non-finite / absurd coordinates, wider than the whole map), flags the frame: redone through the map path.
+__global__ __launch_bounds__(256, 6) void k_tri_table(PwMesh mesh, PwFrames fr, TriTable tb)
+{
+    const int t = blockIdx.x, f = blockIdx.y;
+    const FrameDesc fd = fr.frames[f];
+    const float *dp = fr.dst_pts + (size_t)f * mesh.n_pts * 2;
+    float s[6], d[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t v = mesh.tris[3 * (size_t)t + k];
+        if (v < (uint32_t)mesh.n_pts) {
+            s[2 * k] = mesh.src_pts[2 * (size_t)v]; s[2 * k + 1] = mesh.src_pts[2 * (size_t)v + 1];
+            d[2 * k] = dp[2 * (size_t)v];           d[2 * k + 1] = dp[2 * (size_t)v + 1];
+        } else {
+            s[2 * k] = s[2 * k + 1] = d[2 * k] = d[2 * k + 1] = NAN;
+        }
+    }
+    Seg seg[3];
+    define_seg(d[0], d[1], d[2], d[3], seg[0]);     // p0->p1
+    define_seg(d[0], d[1], d[4], d[5], seg[1]);     // p0->p2
+    define_seg(d[2], d[3], d[4], d[5], seg[2]);     // p1->p2
+    int32_t y_min, y_end;
+    tri_rows(d[1], d[3], d[5], y_min, y_end);
+    const size_t ft = (size_t)f * mesh.n_tris + t;
+    const int W = fd.obj_w;
+    const int64_t len = (int64_t)W * fd.obj_h;
+    int64_t y_first = y_min, y_stop = y_end;
+    if (W > 0 && fd.obj_h > 0) clamp_rows(y_first, y_stop, fd.y_off, W, len);     // rows that cannot write a cell are skipped (hg_math.h)
+    else y_stop = y_first;
+    if (threadIdx.x == 0) {                        // matrices (taps, map path, the consumer's records) + the triangle's row / column reach
+        float fwd[6], inv[6];
+        solve_affine(s, d, fwd);                   // once per triangle: the row threads below need the edge equations only
+        invert_affine(fwd, inv);
+#pragma unroll
+        for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
+        fr.segs[ft * 3] = seg[0]; fr.segs[ft * 3 + 1] = seg[1]; fr.segs[ft * 3 + 2] = seg[2];
+        TriRange tr; tr.y_min = (int32_t)y_first; tr.y_end = (int32_t)y_stop; tr.a = 0; tr.b = 0;
+        if (y_stop > y_first) {
+            // cells of a row y lie in [(y - yOff) W + lo, (y - yOff) W + hi): intersections are between the vertex x's (+-1 for
+            // the rounding); same bounds and the same "irregular" rule as k_tri_setup
+            const double x0 = d[0], x1 = d[2], x2 = d[4];
+            const bool finite = fabs(x0) < 1.0e9 && fabs(x1) < 1.0e9 && fabs(x2) < 1.0e9;
+            bool irregular = !finite;
+            if (!irregular) {
+                const int64_t lo = (int64_t)floor(fmin(fmin(x0, x1), x2)) - 1, hi = (int64_t)ceil(fmax(fmax(x0, x1), x2)) + 1;
+                if (hi - lo >= len) irregular = true;
+                else { tr.a = (int32_t)floordiv64(hi - 1, W); tr.b = (int32_t)floordiv64(lo, W); }
+            }
+            if (irregular) atomicOr(&fr.status[f], FRAME_IRREGULAR);
+            if (y_stop - y_first > tb.stride) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);      // table stride too small: the host grows it
+        }
+        fr.trir[ft] = tr;
+    }
+    int2 *__restrict__ row = tb.ent + ft * (size_t)tb.stride;
+    const int64_t n = y_stop - y_first < tb.stride ? y_stop - y_first : tb.stride;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        int64_t k, fin;
+        span_cells(seg, (double)(y_first + i), (double)fd.y_off, (double)W, len, k, fin);
+        row[i] = k < fin ? make_int2((int)k, (int)fin) : make_int2(0, 0);          // (len < 2^31: fill_frames)
+    }
+}
+
+template <int CAP, class X, bool MAP, int PH, bool COMPACT, bool HIB, bool TBL>
+__device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, const TriTable &tb, uint8_t *__restrict__ out,
                                              int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
                                              int32_t *__restrict__ status_next)
 {
@@ -285,7 +359,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += nthreads) status_next[i] = 0;
     // (every row of the frame's counter block, not only the rows of THIS step's window: the other set was filled under the
     //  previous step's geometry, whose frame may have been a row taller)
-    if ((int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
+    if (!TBL && (int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_m[CAP * 6];
@@ -306,15 +380,21 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // lists are loaded at once, one barrier, then wave j walks row r0 + j alone -- the list-load latency is paid once per
     // four rows and a row's span scan is a single ballot.  Otherwise the rows are taken one after the other with the
     // whole LDS (up to CAP - 1 spans) and the windows of a row are dealt to the four waves.
-    const int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    // TBL (k_tri_table produced the spans, hg_kernels.h): no row lists exist; the counts come out of the table prologue below,
+    // which files the spans straight into the LDS blocks (4-row groups are always "packed", one-row groups use the whole LDS).
+    __shared__ int s_cnt[kRowGroup], s_ncand;
+    __shared__ int s_cand[TBL ? 256 : 1], s_cand_y[TBL ? 256 : 1], s_cand_n[TBL ? 256 : 1];
     int cnts[kRowGroup], cmax = 0;
+    if (!TBL) {
+        const int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
 #pragma unroll
-    for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
-    if (cmax > rl.cap || cmax > CAP - 1) {
-        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
-        return;
+        for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
+        if (cmax > rl.cap || cmax > CAP - 1) {
+            if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+            return;
+        }
     }
-    const bool packed = rows_per_group == kRowGroup && __builtin_amdgcn_readfirstlane(cmax) <= 63;
+    const bool packed = TBL ? rows_per_group == kRowGroup : (rows_per_group == kRowGroup && __builtin_amdgcn_readfirstlane(cmax) <= 63);
 
     // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
     // from the hardware range check == the JS `undefined` -> 0 of :1051.
@@ -359,6 +439,90 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
             mrec[2] = make_double2(m3 * y, m5);
         }
         if (t0 < 3) reinterpret_cast<double2 *>(s_m + (base + nan_slot) * 6)[t0] = make_double2(NAN, NAN);
+    };
+
+    // TBL prologue: (1) every thread tests triangles t = tid, tid + nthreads, ... : can a row of t write into this group's output
+    // rows?  Row y's cells lie in output rows (y - yOff) + b .. + a (k_tri_table), objH further down when fill() wrapped a negative
+    // index ("image" 1); hits go to a candidate list in LDS.  (2) one thread per candidate loads the <= 8 table entries of its
+    // source rows (one round trip, with the triangle's inverse matrix) and files every piece that falls into a row of the group
+    // into that row's LDS block, exactly what load_row copies from a list.  Spans arrive in arbitrary order, like from the lists.
+    auto table_prologue = [&]() -> bool {
+        if ((int)threadIdx.x < kRowGroup) s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s_ncand = 0;
+        if ((int)threadIdx.x < 3 * nrows) {                 // the NaN record of every row block ("no triangle")
+            const int row = threadIdx.x / 3, part = threadIdx.x - 3 * row;
+            const int slot = packed ? row * 64 + 63 : CAP - 1;
+            reinterpret_cast<double2 *>(s_m + slot * 6)[part] = make_double2(NAN, NAN);
+        }
+        __syncthreads();
+        const int T = mesh.n_tris;
+        const TriRange *__restrict__ trir = fr.trir + (size_t)f * T;
+        const int64_t g_lo = r0, g_hi = r0 + nrows - 1;
+        for (int t0 = threadIdx.x; t0 < T; t0 += 4 * nthreads) {       // four triangles per thread and round: their ranges are requested together
+            TriRange trs[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int t = t0 + q * nthreads;
+                trs[q] = t < T ? trir[t] : TriRange{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const TriRange tr = trs[q];
+                if (tr.y_end <= tr.y_min) continue;
+#pragma unroll
+                for (int image = 0; image < 2; image++) {
+                    const int64_t shift = image ? fd.obj_h : 0;
+                    int64_t ylo = g_lo - tr.a - shift + fd.y_off, yhi = g_hi - tr.b - shift + fd.y_off;
+                    if (ylo < tr.y_min) ylo = tr.y_min;
+                    if (yhi > (int64_t)tr.y_end - 1) yhi = (int64_t)tr.y_end - 1;
+                    if (ylo > yhi) continue;
+                    const int slot = atomicAdd(&s_ncand, 1);
+                    if (slot < 256) { s_cand[slot] = t0 + q * nthreads; s_cand_y[slot] = (int)ylo; s_cand_n[slot] = (int)(yhi - ylo + 1); }
+                }
+            }
+        }
+        __syncthreads();
+        const int nc = s_ncand;
+        if (nc > 256) return false;
+        const int capr = packed ? 63 : CAP - 1;
+        for (int c = threadIdx.x; c < nc; c += nthreads) {
+            const int t = s_cand[c], y0 = s_cand_y[c], n = s_cand_n[c];
+            const TriRange tr = trir[t];
+            const size_t ft = (size_t)f * T + t;
+            const int2 *__restrict__ erow = tb.ent + ft * (size_t)tb.stride + (y0 - tr.y_min);
+            const int avail = tb.stride - (y0 - tr.y_min);   // (a taller triangle flagged the frame in k_tri_table: never read past its block)
+            const float4 ma = *reinterpret_cast<const float4 *>(ginv + (size_t)t * kInvStride);
+            const float2 mb = *reinterpret_cast<const float2 *>(ginv + (size_t)t * kInvStride + 4);
+            for (int j0 = 0; j0 < n; j0 += 8) {
+                int2 e[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) e[j] = (j0 + j < n && j0 + j < avail) ? erow[j0 + j] : make_int2(0, 0);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (e[j].x >= e[j].y) continue;
+                    const int64_t k = e[j].x, fin = e[j].y;
+                    for (int row = 0; row < nrows; row++) {
+                        const int64_t rb = (int64_t)(r0 + row) * W;
+                        const int64_t lo = (k > rb ? k : rb) - rb, hi = (fin < rb + W ? fin : rb + W) - rb;
+                        if (lo >= hi) continue;
+                        const int slot = atomicAdd(&s_cnt[row], 1);
+                        if (slot >= capr) continue;
+                        const int at = (packed ? row * 64 : 0) + slot;
+                        const double y = (double)(r0 + row + fd.y_off);
+                        s_lo[at] = (int)lo; s_hi[at] = (int)hi; s_len[at] = (int)(hi - lo); s_key[at] = (t << KS) | (at * 48);
+                        double2 *mrec = reinterpret_cast<double2 *>(s_m + at * 6);
+                        mrec[0] = make_double2((double)ma.x, (double)ma.z * y);      // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
+                        mrec[1] = make_double2((double)mb.x, (double)ma.y);
+                        mrec[2] = make_double2((double)ma.w * y, (double)mb.y);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? s_cnt[j] : 0; ok = ok && cnts[j] <= capr; }
+        return ok;
     };
 
     // All 256-pixel windows w0, w0 + wstep, ... of one row whose spans sit in LDS slots [base, base + cnt).
@@ -464,6 +628,16 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // One window per wave iteration.  Measured alternatives: two windows in flight per wave (74 VGPRs, 6
     // waves/SIMD) and a phased variant (4 windows resolved, then 16 gathers, then 16 stores) are both ~4 % slower: with
     // 8 waves/SIMD the other waves already cover a window's memory latency, and reads + writes together run at ~5.2 TB/s.
+    if (TBL) {
+        if (!table_prologue()) {                             // more candidates / spans than the LDS holds: the host redoes the frame through the map
+            if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+            return;
+        }
+        const int row = packed ? wave : 0;
+        const int cnt = __builtin_amdgcn_readfirstlane(cnts[0] * (row == 0) + cnts[1] * (row == 1) + cnts[2] * (row == 2) + cnts[3] * (row == 3));
+        if (row < nrows) do_row(row, cnt, packed ? wave * 64 : 0, packed ? 63 : CAP - 1, w_lo + (packed ? 0 : wave), packed ? 1 : nwaves);
+        return;
+    }
     const int npass = packed ? 1 : nrows;
     for (int pass = 0; pass < npass; pass++) {
         const int row = packed ? wave : pass;               // everything below is wave-uniform (scalar registers)
@@ -476,11 +650,11 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     }
 }
 
-template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false>
-__global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int16_t *__restrict__ map_out,
+template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, bool TBL = false>
+__global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, TriTable tb, uint8_t *__restrict__ out, int16_t *__restrict__ map_out,
                                                  int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
 {
-    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
+    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, TBL>(mesh, fr, rl, tb, out, map_out, groups_per_xcd, rows_per_group, status_next);
 }
 
 // The same kernel held to 80 SGPRs.  A 256-thread workgroup puts one wave on each SIMD and a SIMD has 800 SGPRs, allocated in
@@ -488,11 +662,11 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
 // 8; capped, ~20 scalars move into VGPR lanes and 8 workgroups fit.  Measured on one box (round 3): with a shared,
 // cache-resident source (instruction-bound) 2 windows per phase 0.555 -> 0.543 ms on C3; with one source per frame (HBM-bound) the
 // extra waves LOSE 1-3 %, and C4's 4-windows-per-phase layout loses 6 % -- so only the shared-source PH = 2 layout takes it.
-template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_pw_rows_s80(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
+template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, bool TBL = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_pw_rows_s80(PwMesh mesh, PwFrames fr, RowLists rl, TriTable tb, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
 {
-    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
+    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, TBL>(mesh, fr, rl, tb, out, map_out, groups_per_xcd, rows_per_group, status_next);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -536,7 +710,14 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
     else            hipLaunchKernelGGL((k_tri_spans<NoExperiment, false>), grid, block, 0, stream, mesh, fr, rl);
 }
 
-void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
+void launch_tri_table(const PwMesh &mesh, const PwFrames &fr, const TriTable &tb, hipStream_t stream)
+{
+    if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
+    const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads >= 256 ? 256 : (fr.tri_threads == 64 ? 64 : 128));
+    hipLaunchKernelGGL(k_tri_table, grid, block, 0, stream, mesh, fr, tb);
+}
+
+void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, const TriTable &tb, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
 {
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
     const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
@@ -546,17 +727,31 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     // bounds :1047 on the high dwords of the rounded coordinates (hg_dev.h) whenever the source window allows it; the fp64
     // compares otherwise (negative source minimum, sources beyond 2^20 pixels a side) and in the parity-tap instantiations
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-    // one-row workgroups of a SMALL frame set run with 2 waves instead of 4: a single 4K frame is 2239 workgroups, 256 CUs hold 2048
-    // four-wave ones -- the rest waited for a second round -- but 4096 two-wave ones (measured round 3, F = 1: warp kernel 15.3 -> see DESIGN §4.2)
+    // one-row workgroups of a SMALL frame set may run with 2 waves instead of 4 (option rows1_threads; measured round 3: no gain)
     const dim3 block(rg == 1 && fr.rows1_threads == 128 ? 128 : 256);
-#define HG_ROWS(CAP, MAPF, PHV, CMP, HB) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB>), grid, block, (size_t)fr.lds_pad_kb * 1024, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
-#define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true); else HG_ROWS(CAP, false, 1, CMP, false); } while (0)
-    if (rl.cap > kRowSpanCapFast) {                          // very dense meshes: 512 LDS slots per row (32 KB), one row per workgroup
-        if (rl.compact) { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, true, false); else HG_ROWS_B(kRowSpanCapDense, 1, true); }
-        else            { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, false, false); else HG_ROWS_B(kRowSpanCapDense, 1, false); }
+    const size_t pad = (size_t)fr.lds_pad_kb * 1024;
+#define HG_ROWS(CAP, MAPF, PHV, CMP, HB, TB) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB, TB>), grid, block, pad, stream, mesh, fr, rl, tb, out, map_out, rpx, rg, status_next)
+#define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true, false); else HG_ROWS(CAP, false, 1, CMP, false, false); } while (0)
+    if (tb.ent) {                                            // spans from k_tri_table (sparse meshes, 32-byte-entry territory: CAP 256, no row lists)
+        if (map_out) { HG_ROWS(kRowSpanCapFast, true, 1, false, false, true); return; }
+        if (!hib) { HG_ROWS(kRowSpanCapFast, false, 1, false, false, true); return; }
+        switch (fr.phase) {
+        case 4:  HG_ROWS(kRowSpanCapFast, false, 4, false, true, true); break;
+        case 2:
+            if (fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true, true>), grid, block, pad, stream,
+                                                mesh, fr, rl, tb, out, map_out, rpx, rg, status_next);
+            else HG_ROWS(kRowSpanCapFast, false, 2, false, true, true);
+            break;
+        default: HG_ROWS(kRowSpanCapFast, false, 1, false, true, true); break;
+        }
         return;
     }
-    if (map_out) { if (rl.compact) HG_ROWS(kRowSpanCapFast, true, 1, true, false); else HG_ROWS(kRowSpanCapFast, true, 1, false, false); return; }
+    if (rl.cap > kRowSpanCapFast) {                          // very dense meshes: 512 LDS slots per row (32 KB), one row per workgroup
+        if (rl.compact) { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, true, false, false); else HG_ROWS_B(kRowSpanCapDense, 1, true); }
+        else            { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, false, false, false); else HG_ROWS_B(kRowSpanCapDense, 1, false); }
+        return;
+    }
+    if (map_out) { if (rl.compact) HG_ROWS(kRowSpanCapFast, true, 1, true, false, false); else HG_ROWS(kRowSpanCapFast, true, 1, false, false, false); return; }
     if (rl.compact) {                                        // dense rows: 8-byte entries
         if (fr.phase >= 2) HG_ROWS_B(kRowSpanCapFast, 2, true); else HG_ROWS_B(kRowSpanCapFast, 1, true);     // (no 4-window instantiation here)
         return;
@@ -564,13 +759,13 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
 #ifdef HG_EXPERIMENTS
     // Timing experiments of DESIGN.md §6 (ablated variants produce WRONG pixels): only in the separate experiments build
     // (`make experiments` -> lib/libhgwarp_exp.so); the shipped library has neither the instantiations nor the switch.
-    if (launch_pw_rows_ablated(mesh, fr, rl, out, map_out, rpx, rg, status_next, grid, stream)) return;     // experiments/hg_ablate.h
+    if (launch_pw_rows_ablated(mesh, fr, rl, tb, out, map_out, rpx, rg, status_next, grid, stream)) return;     // experiments/hg_ablate.h
 #endif
     switch (fr.phase) {
     case 4:  HG_ROWS_B(kRowSpanCapFast, 4, false); break;
     case 2:
-        if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true>), grid, block, (size_t)fr.lds_pad_kb * 1024, stream,
-                                                   mesh, fr, rl, out, map_out, rpx, rg, status_next);
+        if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true, false>), grid, block, pad, stream,
+                                                   mesh, fr, rl, tb, out, map_out, rpx, rg, status_next);
         else HG_ROWS_B(kRowSpanCapFast, 2, false);
         break;
     default: HG_ROWS_B(kRowSpanCapFast, 1, false); break;

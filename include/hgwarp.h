@@ -256,6 +256,8 @@ int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, 
 /* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
  * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general). */
 int hg_last_piecewise_kernel(hg_ctx *ctx);
+/* 1 if that run took its spans from the per-triangle span table (k_tri_table: no row lists, no slot atomics), 0 if from row lists. */
+int hg_last_piecewise_table(hg_ctx *ctx);
 /* Which kernels ran the last forward warp: 0 = none yet, 1 = scatter (atomicMax on a winner buffer) + gather, 2 = the
  * tile-binned gather (output tiles gather their source pixels, winners resolved in LDS, one or two launches for the whole
  * batch): k_fwd_tiles for affine / projective matrices that pass the admissibility bounds, k_fwd_pw_bins + k_fwd_pw_tiles
@@ -281,6 +283,9 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "phase" (default -1 = 2 for a shared source -- 4 when the rows carry 3 or more spans per window --, 1 with one source per frame):
  *           windows per k_pw_rows gather/store phase, 1, 2 or 4;
  *   "geo_windows" (default 8): 256-pixel windows per wave of the affine / projective kernel, 1, 2, 4 or 8;
+ *   "table" (default -1 = sparse meshes of up to 1024 triangles): 0 never / 1 whenever eligible: the producer kernel writes every
+ *           triangle's row spans into a per-triangle table (coalesced, no atomics) and the warp kernel's workgroups pick the
+ *           triangles that reach their rows from the per-triangle row / column reach, instead of per-output-row span lists;
  *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
  *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
  *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;
