@@ -37,6 +37,7 @@ struct Ablate : NoExperiment {
     __device__ static __forceinline__ bool skip_store(const uint32_t *px) { return (ABL & 4) && (px[0] ^ px[1] ^ px[2] ^ px[3]) != 0x9e3779b9u; }
     __device__ static __forceinline__ int slot(int32_t *cnt, int t, int64_t y) { return (ABL & 32) ? (int)((t * 7 + (int)y) & 31) : atomicAdd(cnt, 1); }
     static constexpr bool store_entries = !(ABL & 64);
+    static constexpr bool tri_solve = !(ABL & 128);
 };
 
 static bool launch_tri_spans_ablated(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, dim3 grid, dim3 block, hipStream_t stream)
@@ -46,6 +47,17 @@ static bool launch_tri_spans_ablated(const PwMesh &mesh, const PwFrames &fr, con
     case 32: hipLaunchKernelGGL((k_tri_spans<Ablate<32>, false>), grid, block, 0, stream, mesh, fr, rl); return true;
     case 64: hipLaunchKernelGGL((k_tri_spans<Ablate<64>, false>), grid, block, 0, stream, mesh, fr, rl); return true;
     case 96: hipLaunchKernelGGL((k_tri_spans<Ablate<96>, false>), grid, block, 0, stream, mesh, fr, rl); return true;
+    default: return false;
+    }
+}
+
+static bool launch_tri_table_ablated(const PwMesh &mesh, const PwFrames &fr, const TriTable &tb, dim3 grid, dim3 block, hipStream_t stream)
+{
+    static const int abl = getenv("HG_ABLATE_TRI") ? atoi(getenv("HG_ABLATE_TRI")) : 0;
+    switch (abl) {
+    case 64:  hipLaunchKernelGGL(k_tri_table<Ablate<64>>, grid, block, 0, stream, mesh, fr, tb); return true;
+    case 128: hipLaunchKernelGGL(k_tri_table<Ablate<128>>, grid, block, 0, stream, mesh, fr, tb); return true;
+    case 192: hipLaunchKernelGGL(k_tri_table<Ablate<192>>, grid, block, 0, stream, mesh, fr, tb); return true;
     default: return false;
     }
 }

@@ -102,7 +102,7 @@ struct hg_ctx {
     bool pw_table = false;                                     // the current step uses the table path
     bool pw_table_disabled = false;                            // it overflowed twice: row lists from now on
     int pw_table_grown = 0;
-    int opt_table = -1;                                        // -1 auto, 0 never, 1 whenever eligible
+    int opt_table = -1;                                        // 1: the table path whenever eligible; -1 / 0: row lists (the default, see run_setup)
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
     int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
     int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
@@ -964,7 +964,7 @@ static PwFrames frames_of(const hg_ctx *c)
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     f.max_obj_h = mh;
     f.row_group = c->pw_row_group;
-    f.tri_threads = c->pw_table ? (c->pw_tri_rows_max <= 64 ? 64 : (c->pw_tri_rows_max <= 160 ? 128 : 256)) : c->pw_tri_threads;
+    f.tri_threads = c->pw_table ? (c->pw_tri_rows_max <= 64 ? 64 : 128) : c->pw_tri_threads;
     // Windows per phase, measured (C3 / C4, 64 frames): shared (cache-resident) source: 2, or 4 when a window holds
     // several spans (C4's face mesh ~4.5, C3 1.5: the longer span walk then overlaps four windows' gathers); one source per
     // frame (HBM-bound): 4 windows per phase AND fewer, deeper waves -- 12-16 KB of idle LDS per workgroup leave 5 of them on a
@@ -1029,11 +1029,14 @@ static int run_setup(hg_ctx *c)
         // entry format of the span lists (hg_kernels.h): 8 bytes for dense rows and whenever k_pw_patch will read them
         const bool compact = patch_preferred(c, nullptr) || c->pw_cover > 56;
         if (compact != c->pw_compact) { c->pw_compact = compact; c->rows_clean = false; }
-        // Table path (k_tri_table -> k_pw_rows<TBL>): sparse meshes -- where the row lists would carry 32-byte entries -- whose
-        // triangles a workgroup can afford to scan (every 4-row group tests all of them); the tallest triangle sizes the table.
-        // Layout choice only: what does not fit (a taller triangle, more spans per row than a packed block holds) flags its frame.
+        // Table path (k_tri_table -> k_pw_rows<TBL>), option "table" = 1 only: sparse meshes -- where the row lists would carry
+        // 32-byte entries -- whose triangles a workgroup can afford to scan (every 4-row group tests all of them); the tallest
+        // triangle sizes the table.  Layout choice only: what does not fit (a taller triangle, more spans per row than a packed
+        // block holds) flags its frame.  NOT the default: measured round 3 (same box, 64 frames): the producer gets faster (C3
+        // k_tri_spans 42 -> k_tri_table 35 us; without its table stores 22) but the consumer's prologue -- scan, candidate list,
+        // two more barriers -- costs more than that (C3 warp kernel 583 -> 604 us, C4 244 -> 249, F = 1 step 23.4 -> 24.9 us).
         const size_t T = (size_t)std::max(c->n_tris, 1);
-        c->pw_table = !compact && !c->pw_table_disabled && c->opt_table != 0 && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 &&
+        c->pw_table = !compact && !c->pw_table_disabled && c->opt_table == 1 && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 &&
                       c->pw_tri_rows_max > 0 && c->pw_tri_rows_max <= 8192 && (c->pw_row_group == 1 || c->pw_cover <= 56);
         if (c->pw_table) {
             const int want = ((c->pw_tri_rows_max + 8 + 15) / 16) * 16 << c->pw_table_grown;

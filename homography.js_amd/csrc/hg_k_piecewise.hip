@@ -272,21 +272,18 @@ __global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
 // row y's cells lie in output rows (y - yOff) + b .. (y - yOff) + a, or objH further down when fill() wrapped a negative
 // index -- the enumeration k_pw_fused has always used.  A triangle with more rows than the table stride, or one the bounds
 // cannot describe (non-finite / absurd coordinates, wider than the whole map), flags the frame: redone through the map path.
-__global__ __launch_bounds__(256, 6) void k_tri_table(PwMesh mesh, PwFrames fr, TriTable tb)
+template <class X>
+__global__ __launch_bounds__(128) void k_tri_table(PwMesh mesh, PwFrames fr, TriTable tb)
 {
     const int t = blockIdx.x, f = blockIdx.y;
     const FrameDesc fd = fr.frames[f];
     const float *dp = fr.dst_pts + (size_t)f * mesh.n_pts * 2;
-    float s[6], d[6];
+    float d[6];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const uint32_t v = mesh.tris[3 * (size_t)t + k];
-        if (v < (uint32_t)mesh.n_pts) {
-            s[2 * k] = mesh.src_pts[2 * (size_t)v]; s[2 * k + 1] = mesh.src_pts[2 * (size_t)v + 1];
-            d[2 * k] = dp[2 * (size_t)v];           d[2 * k + 1] = dp[2 * (size_t)v + 1];
-        } else {
-            s[2 * k] = s[2 * k + 1] = d[2 * k] = d[2 * k + 1] = NAN;
-        }
+        if (v < (uint32_t)mesh.n_pts) { d[2 * k] = dp[2 * (size_t)v]; d[2 * k + 1] = dp[2 * (size_t)v + 1]; }
+        else d[2 * k] = d[2 * k + 1] = NAN;         // typed-array read past the end: undefined -> NaN in the Float32Array(6)
     }
     Seg seg[3];
     define_seg(d[0], d[1], d[2], d[3], seg[0]);     // p0->p1
@@ -300,14 +297,35 @@ __global__ __launch_bounds__(256, 6) void k_tri_table(PwMesh mesh, PwFrames fr, 
     int64_t y_first = y_min, y_stop = y_end;
     if (W > 0 && fd.obj_h > 0) clamp_rows(y_first, y_stop, fd.y_off, W, len);     // rows that cannot write a cell are skipped (hg_math.h)
     else y_stop = y_first;
-    if (threadIdx.x == 0) {                        // matrices (taps, map path, the consumer's records) + the triangle's row / column reach
-        float fwd[6], inv[6];
-        solve_affine(s, d, fwd);                   // once per triangle: the row threads below need the edge equations only
-        invert_affine(fwd, inv);
+    // The matrices (forward :1265-1306, inverse :1345-1365: taps, map path, the consumer's records) are solved one triangle per
+    // THREAD by the first ceil(T / blockDim) workgroups of every frame, before their own row work: ~400 dependent fp64
+    // instructions on a single lane of every workgroup cost 17 of the kernel's 42 us on C3 (ablation, round 3), spread over
+    // all lanes of two workgroups per frame they cost nothing measurable.
+    if (X::tri_solve && blockIdx.x * blockDim.x < (unsigned)mesh.n_tris) {
+        const int ts = blockIdx.x * blockDim.x + threadIdx.x;
+        if (ts < mesh.n_tris) {
+            float ss[6], dd[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];
-        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
-        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
+            for (int k = 0; k < 3; k++) {
+                const uint32_t v = mesh.tris[3 * (size_t)ts + k];
+                if (v < (uint32_t)mesh.n_pts) {
+                    ss[2 * k] = mesh.src_pts[2 * (size_t)v]; ss[2 * k + 1] = mesh.src_pts[2 * (size_t)v + 1];
+                    dd[2 * k] = dp[2 * (size_t)v];           dd[2 * k + 1] = dp[2 * (size_t)v + 1];
+                } else {
+                    ss[2 * k] = ss[2 * k + 1] = dd[2 * k] = dd[2 * k + 1] = NAN;
+                }
+            }
+            float fwd[6], inv[6];
+            solve_affine(ss, dd, fwd);
+            invert_affine(fwd, inv);
+            const size_t fs = (size_t)f * mesh.n_tris + ts;
+#pragma unroll
+            for (int k = 0; k < 6; k++) fr.fwd[fs * 6 + k] = fwd[k];
+            *reinterpret_cast<float4 *>(fr.inv + fs * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+            *reinterpret_cast<float4 *>(fr.inv + fs * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
+        }
+    }
+    if (threadIdx.x == 0) {                        // edge equations (map path) + the triangle's row / column reach (the consumer's candidate test)
         fr.segs[ft * 3] = seg[0]; fr.segs[ft * 3 + 1] = seg[1]; fr.segs[ft * 3 + 2] = seg[2];
         TriRange tr; tr.y_min = (int32_t)y_first; tr.y_end = (int32_t)y_stop; tr.a = 0; tr.b = 0;
         if (y_stop > y_first) {
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(256, 6) void k_tri_table(PwMesh mesh, PwFrames fr, 
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
         int64_t k, fin;
         span_cells(seg, (double)(y_first + i), (double)fd.y_off, (double)W, len, k, fin);
-        row[i] = k < fin ? make_int2((int)k, (int)fin) : make_int2(0, 0);          // (len < 2^31: fill_frames)
+        if (X::store_entries || k == 0x7fffffffffffffffll) row[i] = k < fin ? make_int2((int)k, (int)fin) : make_int2(0, 0);          // (len < 2^31: fill_frames)
     }
 }
 
@@ -477,7 +495,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     if (yhi > (int64_t)tr.y_end - 1) yhi = (int64_t)tr.y_end - 1;
                     if (ylo > yhi) continue;
                     const int slot = atomicAdd(&s_ncand, 1);
-                    if (slot < 256) { s_cand[slot] = t0 + q * nthreads; s_cand_y[slot] = (int)ylo; s_cand_n[slot] = (int)(yhi - ylo + 1); }
+                    if (slot < 256) { s_cand[slot] = t0 + q * nthreads; s_cand_y[slot] = (int)(ylo - tr.y_min); s_cand_n[slot] = (int)(yhi - ylo + 1); }
                 }
             }
         }
@@ -485,36 +503,34 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         const int nc = s_ncand;
         if (nc > 256) return false;
         const int capr = packed ? 63 : CAP - 1;
-        for (int c = threadIdx.x; c < nc; c += nthreads) {
-            const int t = s_cand[c], y0 = s_cand_y[c], n = s_cand_n[c];
-            const TriRange tr = trir[t];
+        // eight threads per candidate, one source row each (a candidate has nrows + a - b rows: 4 or 5 as a rule; more are taken in
+        // rounds): every thread's single table entry and the triangle's matrix are requested at once
+        for (int c0 = 0; c0 < nc; c0 += nthreads >> 3) {
+            const int c = c0 + ((int)threadIdx.x >> 3), jj = threadIdx.x & 7;
+            if (c >= nc) continue;
+            const int t = s_cand[c], i0 = s_cand_y[c], n = s_cand_n[c];      // i0: the first candidate row's index in the triangle's table block
             const size_t ft = (size_t)f * T + t;
-            const int2 *__restrict__ erow = tb.ent + ft * (size_t)tb.stride + (y0 - tr.y_min);
-            const int avail = tb.stride - (y0 - tr.y_min);   // (a taller triangle flagged the frame in k_tri_table: never read past its block)
+            const int2 *__restrict__ erow = tb.ent + ft * (size_t)tb.stride + i0;
+            const int avail = tb.stride - i0;                // (a taller triangle flagged the frame in k_tri_table: never read past its block)
             const float4 ma = *reinterpret_cast<const float4 *>(ginv + (size_t)t * kInvStride);
             const float2 mb = *reinterpret_cast<const float2 *>(ginv + (size_t)t * kInvStride + 4);
-            for (int j0 = 0; j0 < n; j0 += 8) {
-                int2 e[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) e[j] = (j0 + j < n && j0 + j < avail) ? erow[j0 + j] : make_int2(0, 0);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    if (e[j].x >= e[j].y) continue;
-                    const int64_t k = e[j].x, fin = e[j].y;
-                    for (int row = 0; row < nrows; row++) {
-                        const int64_t rb = (int64_t)(r0 + row) * W;
-                        const int64_t lo = (k > rb ? k : rb) - rb, hi = (fin < rb + W ? fin : rb + W) - rb;
-                        if (lo >= hi) continue;
-                        const int slot = atomicAdd(&s_cnt[row], 1);
-                        if (slot >= capr) continue;
-                        const int at = (packed ? row * 64 : 0) + slot;
-                        const double y = (double)(r0 + row + fd.y_off);
-                        s_lo[at] = (int)lo; s_hi[at] = (int)hi; s_len[at] = (int)(hi - lo); s_key[at] = (t << KS) | (at * 48);
-                        double2 *mrec = reinterpret_cast<double2 *>(s_m + at * 6);
-                        mrec[0] = make_double2((double)ma.x, (double)ma.z * y);      // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
-                        mrec[1] = make_double2((double)mb.x, (double)ma.y);
-                        mrec[2] = make_double2((double)ma.w * y, (double)mb.y);
-                    }
+            for (int j = jj; j < n && j < avail; j += 8) {
+                const int2 e = erow[j];
+                if (e.x >= e.y) continue;
+                const int64_t k = e.x, fin = e.y;
+                for (int row = 0; row < nrows; row++) {
+                    const int64_t rb = (int64_t)(r0 + row) * W;
+                    const int64_t lo = (k > rb ? k : rb) - rb, hi = (fin < rb + W ? fin : rb + W) - rb;
+                    if (lo >= hi) continue;
+                    const int slot = atomicAdd(&s_cnt[row], 1);
+                    if (slot >= capr) continue;
+                    const int at = (packed ? row * 64 : 0) + slot;
+                    const double y = (double)(r0 + row + fd.y_off);
+                    s_lo[at] = (int)lo; s_hi[at] = (int)hi; s_len[at] = (int)(hi - lo); s_key[at] = (t << KS) | (at * 48);
+                    double2 *mrec = reinterpret_cast<double2 *>(s_m + at * 6);
+                    mrec[0] = make_double2((double)ma.x, (double)ma.z * y);      // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
+                    mrec[1] = make_double2((double)mb.x, (double)ma.y);
+                    mrec[2] = make_double2((double)ma.w * y, (double)mb.y);
                 }
             }
         }
@@ -713,8 +729,11 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
 void launch_tri_table(const PwMesh &mesh, const PwFrames &fr, const TriTable &tb, hipStream_t stream)
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
-    const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads >= 256 ? 256 : (fr.tri_threads == 64 ? 64 : 128));
-    hipLaunchKernelGGL(k_tri_table, grid, block, 0, stream, mesh, fr, tb);
+    const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads == 64 ? 64 : 128);
+#ifdef HG_EXPERIMENTS
+    if (launch_tri_table_ablated(mesh, fr, tb, grid, block, stream)) return;
+#endif
+    hipLaunchKernelGGL(k_tri_table<NoExperiment>, grid, block, 0, stream, mesh, fr, tb);
 }
 
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, const TriTable &tb, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)

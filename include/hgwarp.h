@@ -283,9 +283,10 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "phase" (default -1 = 2 for a shared source -- 4 when the rows carry 3 or more spans per window --, 1 with one source per frame):
  *           windows per k_pw_rows gather/store phase, 1, 2 or 4;
  *   "geo_windows" (default 8): 256-pixel windows per wave of the affine / projective kernel, 1, 2, 4 or 8;
- *   "table" (default -1 = sparse meshes of up to 1024 triangles): 0 never / 1 whenever eligible: the producer kernel writes every
- *           triangle's row spans into a per-triangle table (coalesced, no atomics) and the warp kernel's workgroups pick the
- *           triangles that reach their rows from the per-triangle row / column reach, instead of per-output-row span lists;
+ *   "table" (default off; 1 = whenever eligible: sparse meshes of up to 1024 triangles): the producer kernel writes every
+ *           triangle's row spans into a per-triangle table (coalesced stores, no slot atomics: k_tri_table) and the warp kernel's
+ *           workgroups pick the triangles that reach their rows from the per-triangle row / column reach, instead of reading
+ *           per-output-row span lists.  Bit-identical; measured slower end to end on this part, kept as an option;
  *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
  *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
  *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;
