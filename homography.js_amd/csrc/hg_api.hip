@@ -63,6 +63,8 @@ struct hg_ctx {
     int pw_tri_threads = 128;                                  // k_tri_spans workgroup size
     bool pw_patch = false;                                     // dense mesh that fits k_pw_patch (4-row groups, 2-D gather patches)
     bool pw_patch_fits = false;                                // ... the frame set is within k_pw_patch's limits (it may be preferred later: one source per frame)
+    double pw_fill = 1.0;                                      // heaviest XCD row band / mean band (span counts per row), 1 = even rows
+    int opt_xcc_rotate = -1;                                   // -1 by estimate, 0 / 1
     double pw_shear = 0.0;                                     // mean |d(source row) / d(output x)| of the uploaded frames (layout heuristic)
     bool pw_patch_dense = false;                               // ... only in its global-record variant (up to 511 spans per row)
     bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
@@ -365,6 +367,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "geo_windows")) c->opt_geo_nw = value;
     else if (!std::strcmp(key, "hi_bounds")) c->opt_hi_bounds = value != 0;
     else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
+    else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
     else if (!std::strcmp(key, "table")) { c->opt_table = value; c->pw_table_disabled = false; }
     else if (!std::strcmp(key, "rows1_threads")) c->opt_rows1_threads = (value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "col_split")) c->opt_col_split = (value == 1 || value == 2 || value == 4) ? value : -1;
@@ -661,7 +664,9 @@ extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
     HG_TRY(time_begin(c));
     launch_geo(c->geo_kind, c->geo_f32_exact, c->d_geo_frames, c->d_mats, (int)c->geo_frames.size(), mw, mh, c->d_img, c->W, c->H,
                c->n_imgs, (uint64_t)c->img_stride, static_cast<uint8_t *>(d_out),
-               (c->geo_from_points && c->geo_kind == HG_PROJECTIVE) ? c->d_geo_plain : nullptr, c->opt_geo_nw, c->stream);
+               (c->geo_from_points && c->geo_kind == HG_PROJECTIVE) ? c->d_geo_plain : nullptr, c->opt_geo_nw,
+               c->n_imgs > 1 ? 0 : c->xcc_log2,              // (one source per frame: plain block order measured faster, 0.234 -> 0.199 ms on C2)
+               c->stream);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
     return HG_OK;
@@ -737,9 +742,11 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
 // Largest number of triangles whose fillTriangle row range (:1113-1120) covers one output row, over the uploaded frames:
 // an estimate of the longest per-row span list, used ONLY to pick k_pw_rows' layout (4 rows per workgroup with 64 LDS
 // slots each, or 1 row with all 256); the kernel checks the real counts and is exact either way.
-static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_rows, int *max_group_tris, double *mean_shear, int *max_tri_rows)
+static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_rows, int *max_group_tris, double *mean_shear, int *max_tri_rows, double *fill)
 {
-    double tallest = 0.0;
+    double tallest = 0.0, band_worst = 1.0;
+    const int nb = 1 << c->xcc_log2;
+    std::vector<double> band((size_t)nb, 0.0);
     int worst = 0, worst_group = 0;
     double rows_total = 0.0, tris_total = 0.0, shear_total = 0.0, shear_n = 0.0;
     std::vector<int> diff, tdiff, starts;
@@ -780,6 +787,7 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
             diff[(size_t)a] += 1; diff[(size_t)b] -= 1;
             rows_total += b - a; tris_total += 1.0;
             tallest = std::max(tallest, std::min(std::ceil(hi) - std::trunc(lo), 1.0e6));       // rows of fillTriangle's loop :1113-1120
+
             // tighter, for the triangles-per-group estimate: a triangle has spans on the integer rows inside [minY, maxY]
             // (:1179; triangles that only touch a row at a vertex between two integers do not count), plus the spill row when
             // the window is offset in x
@@ -788,18 +796,24 @@ static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_row
         }
         int run = 0, trun = 0;
         int group = 0;                                       // triangles with spans in the 4-row group the row belongs to
+        std::fill(band.begin(), band.end(), 0.0);
         for (int r = 0; r < fd.obj_h; r++) {
             run += diff[r];
             trun += tdiff[r];
             worst = std::max(worst, run);
+            band[(size_t)((int64_t)r * nb / fd.obj_h)] += 2.0 + run;          // a row's cost ~ a constant + its spans (layout heuristic only)
             group = (r % kRowGroup == 0) ? trun : group + starts[r];
             worst_group = std::max(worst_group, group);
         }
+        double bsum = 0.0, bmax = 0.0;
+        for (double v : band) { bsum += v; bmax = std::max(bmax, v); }
+        if (bsum > 0) band_worst = std::max(band_worst, bmax * nb / bsum);
     }
     *mean_tri_rows = tris_total > 0 ? rows_total / tris_total : 0.0;
     *max_group_tris = worst_group;
     *mean_shear = shear_n > 0 ? shear_total / shear_n : 0.0;
     *max_tri_rows = (int)tallest;
+    *fill = band_worst;                                      // heaviest XCD band / mean band, over the frames (1 = even rows)
     return worst;
 }
 
@@ -870,6 +884,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     c->stage_cur = slot;
     double tri_rows = 0.0, shear = 0.0;
     int group_tris = 0, max_w = 0, cover = 0, tall = 0;
+    double fill = 1.0;
     int64_t total_px = 0;
     for (const FrameDesc &d : c->pw_frames) { max_w = std::max(max_w, d.obj_w); if (d.obj_w > 0 && d.obj_h > 0) total_px += (int64_t)d.obj_w * d.obj_h; }
     int max_h = 0;
@@ -886,7 +901,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
                             std::abs(ok.max_w - key.max_w) * 16 <= ok.max_w && std::abs(ok.max_h - key.max_h) * 16 <= ok.max_h &&
                             c->layout_age < 256;
     if (same_shape) {
-        cover = c->pw_cover; tri_rows = c->pw_tri_rows; group_tris = c->pw_group_tris; shear = c->pw_shear; tall = c->pw_tri_rows_max;
+        cover = c->pw_cover; tri_rows = c->pw_tri_rows; group_tris = c->pw_group_tris; shear = c->pw_shear; tall = c->pw_tri_rows_max; fill = c->pw_fill;
         c->layout_age++;
     } else if (quick) {
         // small frames of a dense mesh (the README's 400x400 / 23 000-triangle benchmark): walking every triangle on the host
@@ -896,11 +911,11 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
         tri_rows = 64.0;
         tall = 0;                                           // (unknown: no table path without the walk)
     } else {
-        cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear, &tall);
+        cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear, &tall, &fill);
         c->pw_layout_walks++;
     }
     if (!same_shape) { c->layout_key = key; c->layout_age = 0; }
-    c->pw_tri_rows = tri_rows; c->pw_group_tris = group_tris; c->pw_tri_rows_max = tall;
+    c->pw_tri_rows = tri_rows; c->pw_group_tris = group_tris; c->pw_tri_rows_max = tall; c->pw_fill = fill;
     c->pw_cover = cover;
     c->pw_spans_per_window = max_w > 0 ? (double)cover * 256.0 / (double)max_w : 0.0;
     c->pw_row_group = cover <= 56 ? kRowGroup : 1;
@@ -969,6 +984,9 @@ static PwFrames frames_of(const hg_ctx *c)
     // several spans (C4's face mesh ~4.5, C3 1.5: the longer span walk then overlaps four windows' gathers); one source per
     // frame (HBM-bound): 4 windows per phase AND fewer, deeper waves -- 12-16 KB of idle LDS per workgroup leave 5 of them on a
     // CU instead of 7 (round 3, same box: C3 0.934 -> 0.910 ms, C4 0.406 -> 0.371), where k_pw_patch does not take the frame set anyway.
+    // XCD bands: fixed per XCD when every frame reads the same source and the mesh fills its window (the band's source rows then
+    // stay in that XCD's L2 from frame to frame), rotating with the frame otherwise (even load; measured in hg_k_piecewise.hip)
+    f.xcc_rotate = c->opt_xcc_rotate >= 0 ? (c->opt_xcc_rotate != 0) : (c->n_imgs > 1 || c->pw_fill > 1.08);
     f.xcc_log2 = c->xcc_log2; f.no_hi_bounds = c->opt_hi_bounds ? 0 : 1;
     f.sgpr_cap = c->opt_sgpr_cap >= 0 ? (c->opt_sgpr_cap != 0) : (c->n_imgs <= 1);
     f.lds_pad_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : (c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0);

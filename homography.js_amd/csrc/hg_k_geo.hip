@@ -100,19 +100,25 @@ __global__ void k_selftest_division(uint64_t seed, uint64_t n_per_thread, unsign
 template <int KIND, int NW>
 __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ frames, const double *__restrict__ mats,
                                                   const uint8_t *__restrict__ img0, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *__restrict__ out,
-                                                  const int32_t *__restrict__ plain)
+                                                  const int32_t *__restrict__ plain, int xcc_log2, int groups_per_xcd, int chunks)
 {
-    const FrameDesc fd = frames[blockIdx.z];
-    const uint8_t *__restrict__ img = n_imgs > 1 ? img0 + (uint64_t)(blockIdx.z % n_imgs) * img_stride : img0;
+    // 1-D grid decoded like k_pw_rows': XCD x (= block id % number of XCCs) walks a contiguous band of 4-row groups of one frame, so
+    // that vertically adjacent output rows -- which share source cache lines wherever the map is not an exact row copy -- meet in
+    // ONE L2 instead of being fetched by up to 8 of them (round 3: fabric reads of C2 with one source per frame 1.39 x algorithmic before).
+    const int bid = blockIdx.x, xcd = bid & ((1 << xcc_log2) - 1), bi = bid >> xcc_log2;
+    const int chunk = bi % chunks, bj = bi / chunks;
+    const int fz = bj / groups_per_xcd, rgroup = xcd * groups_per_xcd + (bj - fz * groups_per_xcd);
+    const FrameDesc fd = frames[fz];
+    const uint8_t *__restrict__ img = n_imgs > 1 ? img0 + (uint64_t)(fz % n_imgs) * img_stride : img0;
     // one wave per row of the block.  threadIdx.y is the same in all 64 lanes of a wave, but the compiler cannot know: made scalar
     // explicitly, or the row's output descriptor counts as divergent and every buffer_store below is wrapped in a waterfall
     // loop (v_readfirstlane x 4, two 64-bit compares, exec save / restore per store: a sixth of the kernel's instructions)
-    const int r = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const int r = rgroup * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
     const int lane = threadIdx.x;
-    const int cb = blockIdx.x * (256 * NW);                // this wave's NW consecutive 256-pixel windows of the row
+    const int cb = chunk * (256 * NW);                     // this wave's NW consecutive 256-pixel windows of the row
     const int OW = fd.obj_w;
     if (r >= fd.obj_h || cb >= OW) return;
-    const double *__restrict__ mp = mats + (size_t)blockIdx.z * 8;
+    const double *__restrict__ mp = mats + (size_t)fz * 8;
     double m[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) m[k] = mp[k];
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
     // row constants, once per wave: fl(m2*y), fl(m3*y) (affine) / fl(m1*y), fl(m4*y), fl(m7*y) (projective)   :1383-1384 / :1402-1403
     const double cx = (KIND == 0 || KIND == 2) ? m[2] * y : m[1] * y, cy = (KIND == 0 || KIND == 2) ? m[3] * y : m[4] * y, ad = m[7] * y;
     // KIND 4: matrices solved on the device (k_solve_frames), which also proved (or not) the plain range per frame
-    const bool use_plain = KIND == 4 && __builtin_amdgcn_readfirstlane(plain[blockIdx.z]) != 0;
+    const bool use_plain = KIND == 4 && __builtin_amdgcn_readfirstlane(plain[fz]) != 0;
     // NW windows per wave, gathers of all of them issued before the first store (see k_pw_rows: loads and stores share vmcnt)
     uint32_t px[NW][4];
 #pragma unroll
@@ -167,17 +173,18 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
 }
 
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
-                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, hipStream_t stream)
+                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, int xcc_log2, hipStream_t stream)
 {
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     const bool fast = ((int64_t)H + 2) * W * 4 < ((int64_t)1 << 31) && hi_bounds_ok(0, W, 0, H) && max_w < (1 << 28);
     if (fast) {
         const int NW = nw == 1 ? 1 : (nw == 2 ? 2 : (nw >= 8 ? 8 : 4));        // windows per wave (measured on C2, 1 -> 2 -> 4: 0.198 -> 0.177 -> 0.171 ms; round 3, 4 -> 8: 0.162 -> 0.153, one source per frame 0.219 -> 0.199)
-        dim3 grid((max_w + 256 * NW - 1) / (256 * NW), (max_h + 3) / 4, n_frames);
-#define HG_GEO(K) do { if (NW == 1) hipLaunchKernelGGL((k_geo_fast<K, 1>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); \
-                       else if (NW == 4) hipLaunchKernelGGL((k_geo_fast<K, 4>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); \
-                       else if (NW == 8) hipLaunchKernelGGL((k_geo_fast<K, 8>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); \
-                       else hipLaunchKernelGGL((k_geo_fast<K, 2>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain); } while (0)
+        const int nx = 1 << xcc_log2, chunks = (max_w + 256 * NW - 1) / (256 * NW), gpx = ((max_h + 3) / 4 + nx - 1) / nx;
+        dim3 grid((unsigned)chunks * (unsigned)gpx * (unsigned)nx * (unsigned)n_frames);
+#define HG_GEO(K) do { if (NW == 1) hipLaunchKernelGGL((k_geo_fast<K, 1>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks); \
+                       else if (NW == 4) hipLaunchKernelGGL((k_geo_fast<K, 4>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks); \
+                       else if (NW == 8) hipLaunchKernelGGL((k_geo_fast<K, 8>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks); \
+                       else hipLaunchKernelGGL((k_geo_fast<K, 2>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks); } while (0)
         if (kind == 1 && plain) HG_GEO(4);
         else if (kind == 1 && f32_exact) HG_GEO(3);
         else if (kind == 1) HG_GEO(1);

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     using slot_t = typename std::conditional<GLOBALREC, uint16_t, uint8_t>::type;
     const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1), bi = bid >> fr.xcc_log2;
     const int f = bi / groups_per_xcd;
-    const int r0 = (xcd * groups_per_xcd + (bi - f * groups_per_xcd)) * kPatchRows;
+    const int band = (xcd + (fr.xcc_rotate ? f : 0)) & ((1 << fr.xcc_log2) - 1);  // (rotates with the frame: see k_pw_rows)
+    const int r0 = (band * groups_per_xcd + (bi - f * groups_per_xcd)) * kPatchRows;
     const FrameDesc fd = fr.frames[f];
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;   // (see k_pw_rows)
     // the OTHER counter set, every row of the frame's block: clean for the next step's k_tri_spans (ping-pong, see k_pw_rows)

@@ -62,6 +62,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t row_group;              // output rows per k_pw_rows workgroup: kRowGroup (sparse rows) or 1 (dense meshes)
     int32_t tri_threads;            // k_tri_spans workgroup size: 128, or 64 when the triangles are short (one row per thread)
     int32_t phase;                  // k_pw_rows: windows whose gathers are issued before their stores (1, 2 or 4)
+    int32_t xcc_rotate;             // 1: XCD x takes band (x + frame) mod XCCs instead of band x (uneven rows, or no source shared between frames)
     int32_t xcc_log2;               // log2 of the device's XCC count (8 on an unpartitioned MI355X): block id -> XCD row band
     int32_t patch_blocks;           // k_pw_patch: 64-pixel column blocks per gather / store phase (1, 2, 4, 8)
     int32_t rows1_threads;          // k_pw_rows with one row per workgroup: 256 threads, or 128 for small frame sets (more workgroups resident)
@@ -131,7 +132,7 @@ void launch_fill_i32(int32_t *p, size_t n, int32_t v, hipStream_t stream);      
 // f32_exact: every affine matrix entry is a float value and |x| < 2^28 (lets the kernel use an exact-product fma).
 // n_imgs / img_stride: frame f reads the source at img + (f % n_imgs) * img_stride.
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
-                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, hipStream_t stream);
+                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, int xcc_log2, hipStream_t stream);
 // Per-frame matrix solves on the device (one lane per frame): kind 1 = projective 8x8 DLT in numeric.js' LU order, 4 points
 // per set; kind 0 = affine closed form, 3 points per set.  mats = F x 8 doubles; plain[f] = 1 where the projective frame's
 // window stays in the plain division range (launch_geo then takes the per-frame flag instead of a host proof).

@@ -290,6 +290,8 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
  *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
  *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;
+ *   "xcc_rotate" (default -1 = by estimate): 1: XCD x walks row band (x + frame) mod XCCs instead of band x -- even load where
+ *           rows differ in cost or the frames share no source; 0: fixed bands (a shared source's band stays in that XCD's L2);
  *   "xcc" (default: hipDeviceAttributeNumberOfXccs of the device, 8 on an unpartitioned MI355X): number of XCCs the
  *           block id -> row band mapping of the warp kernels assumes; a power of two in 1..64. */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);
