@@ -234,6 +234,14 @@ def main():
             o_k, t_k = hg.pack_offsets(g_k)
             fresh_sets.append({"frames": fr_k, "geoms": g_k, "offs": o_k, "total": t_k, "args": ctx.frame_set_args(np.concatenate(fr_k), g_k, o_k)})
         total = max([total] + [fs["total"] for fs in fresh_sets])
+    elif not piecewise and args.points in ("both", "fresh") and args.sources != "distinct":
+        fresh_sets = []                                      # projective: the corner sets of the sequence shifted by k frames
+        for k in range(8):
+            d_k = [wl.projective_dst(W, H, 0.0125 * ((i + k) % 10)) for i in frame_ids]
+            g_k = [tuple(int(v) for v in hg.transform_limits(1, hg.solve_projective(s4, d4), W, H)) for d4 in d_k]
+            o_k, t_k = hg.pack_offsets(g_k)
+            fresh_sets.append({"geoms": g_k, "offs": o_k, "total": t_k, "args": ctx.geometric_points_args(1, np.concatenate(d_k), np.tile(s4, F), g_k, o_k)})
+        total = max([total] + [fs["total"] for fs in fresh_sets])
     out_t = torch.empty(total, dtype=torch.uint8, device=dev)
     d_out = out_t.data_ptr()
 
@@ -386,9 +394,14 @@ def main():
         def run_fresh(d):
             fs = fresh_sets[step_i[0] % len(fresh_sets)]
             step_i[0] += 1
-            ctx.piecewise_set_frames_prepared(fs["args"])
-            ctx.warp_inverse_piecewise_frames_device(d)
+            if piecewise:
+                ctx.piecewise_set_frames_prepared(fs["args"])
+                ctx.warp_inverse_piecewise_frames_device(d)
+            else:
+                ctx.geometric_set_frames_points_prepared(fs["args"])
+                ctx.warp_inverse_geometric_frames_device(d)
         walks0, redone0 = ctx.layout_walks(), ctx.redone_frames()
+        n_pts_txt = f"{sp.size // 2} points" if piecewise else "2 x 4 corner points"
         elapsed_f, k_ms_f, k_launches_f = timed_region(run_fresh)
         k_last = (step_i[0] - 1) % len(fresh_sets)
         fs = fresh_sets[k_last]
@@ -396,12 +409,12 @@ def main():
                  "value_mpixels_per_s": round(px_all * args.steps / elapsed_f / 1e6, 1),
                  "vs_resident_ms_per_step": round(elapsed_f / res["shared"][0], 4),
                  "layout_walks_in_region": ctx.layout_walks() - walks0, "frames_redone_in_region": ctx.redone_frames() - redone0,
-                 "point_sets": f"ring of {len(fresh_sets)} sets (the config's sequence shifted by k frames), one hg_piecewise_set_frames per step: "
-                               f"{F} frames x {sp.size // 2} points copied to page-locked staging and uploaded stream-ordered, no GPU wait"}
+                 "point_sets": f"ring of {len(fresh_sets)} sets (the config's sequence shifted by k frames), one hg_{'piecewise_set_frames' if piecewise else 'geometric_set_frames_points'} per step: "
+                               f"{F} frames x {n_pts_txt} copied to page-locked staging and uploaded stream-ordered, no GPU wait"}
         if not args.no_verify and shared_copy is not None:
             ok, n_cmp = True, 0
             for f in range(F):
-                fp = ((f + k_last) % 4) if cfg["kind"] != "face" else f + k_last      # resident frame with the same point set
+                fp = f + k_last if cfg["kind"] == "face" else ((f + k_last) % (4 if piecewise else 10))     # resident frame with the same point set
                 if fp >= F or fs["geoms"][f] != tuple(geoms[fp]):
                     continue
                 nb = n_out[fp] * 4
@@ -409,8 +422,12 @@ def main():
                 if not torch.equal(out_t[fs["offs"][f]: fs["offs"][f] + nb], shared_copy[offs[fp]: offs[fp] + nb]):
                     ok = False
                     break
-            check(f"fresh-points step (set {k_last}): {n_cmp} frames == the resident-points frames with the same point set", ok and n_cmp > 0)
-        ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)          # back to the resident set
+            if n_cmp > 0:
+                check(f"fresh-points step (set {k_last}): {n_cmp} frames == the resident-points frames with the same point set", ok)
+        if piecewise:                                        # back to the resident set
+            ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+        else:
+            ctx.geometric_set_frames_points(1, np.concatenate(d4s), np.tile(s4, F), geoms, offs)
 
     # ---------------------------------------------------------------- distinct sources: one 4*W*H source per frame (video case)
     if do_distinct:

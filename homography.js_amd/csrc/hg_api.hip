@@ -114,6 +114,11 @@ struct hg_ctx {
     double pw_tri_rows = 0.0; int pw_group_tris = 0;
     long pw_layout_walks = 0;                                  // host walks over the triangles (hg_layout_walks(): tests / bench)
 
+    // geometric frame sets arrive like the piecewise ones: copied into page-locked staging, uploaded stream-ordered, no GPU wait
+    // (nothing refers back to a staged geometric set, so a slot is simply reused once its own upload has completed)
+    struct GeoStage { uint8_t *h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+    GeoStage geo_stage[8];
+    int geo_stage_cur = -1;
     // geometric frames
     int geo_kind = 0;
     bool geo_f32_exact = false;                                // affine matrices hold float values, |x| < 2^28
@@ -253,6 +258,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (hg_ctx::Stage &st : c->stage) if (st.h) (void)hipHostFree(st.h);
+    for (hg_ctx::GeoStage &gs : c->geo_stage) { if (gs.h) (void)hipHostFree(gs.h); if (gs.done) (void)hipEventDestroy(gs.done); }
     { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status };
       for (void *q : rp) if (q) (void)hipFree(q); }
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
@@ -584,21 +590,45 @@ extern "C" int hg_selftest_division(hg_ctx *c, uint64_t samples, uint64_t seed, 
     return HG_OK;
 }
 
+// Next staging slot with room for `bytes` (waits only if the upload that last used this slot -- eight sets ago -- is still queued).
+static int geo_stage_slot(hg_ctx *c, size_t bytes, hg_ctx::GeoStage **out)
+{
+    const int slot = (c->geo_stage_cur + 1) % 8;
+    hg_ctx::GeoStage &gs = c->geo_stage[slot];
+    if (!gs.done) HIP_TRY(c, hipEventCreateWithFlags(&gs.done, hipEventDisableTiming));
+    if (gs.used) HIP_TRY(c, hipEventSynchronize(gs.done));
+    if (bytes > gs.cap) {
+        if (gs.h) { HIP_TRY(c, hipHostFree(gs.h)); gs.h = nullptr; gs.cap = 0; }
+        void *q = nullptr;
+        hipError_t e = hipHostMalloc(&q, bytes + bytes / 4, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipHostMalloc (frame-set staging): ") + hipGetErrorString(e));
+        gs.h = static_cast<uint8_t *>(q); gs.cap = bytes + bytes / 4;
+    }
+    c->geo_stage_cur = slot;
+    *out = &gs;
+    return HG_OK;
+}
+
 extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, const hg_geom *geoms, const size_t *offs, int n)
 {
     HG_TRY(bind(c));
     if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m || !geoms || n <= 0) return fail(c, HG_ERR_INVALID, "hg_geometric_set_frames: bad arguments");
     // Transactional: the live frame set is dropped first and the new one only becomes visible once validation, every
-    // allocation and the uploads have succeeded; after a failure the next *_frames_device call returns HG_ERR_STATE
-    // instead of launching F new frames against buffers sized for the old set.
+    // allocation and the uploads have been queued; after a failure the next *_frames_device call returns HG_ERR_STATE
+    // instead of launching F new frames against buffers sized for the old set.  No GPU wait (see hg_piecewise_set_frames).
     c->geo_frames.clear();
     std::vector<FrameDesc> fresh;
     HG_TRY(fill_frames(c, fresh, geoms, offs, n));
     HG_TRY(ensure(c, c->d_geo_frames, c->geo_frames_cap, (size_t)n));
     HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)n * 8));
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, fresh.data(), sizeof(FrameDesc) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_mats, m, sizeof(double) * 8 * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t fd_bytes = sizeof(FrameDesc) * (size_t)n, m_bytes = sizeof(double) * 8 * (size_t)n;
+    hg_ctx::GeoStage *gs = nullptr;
+    HG_TRY(geo_stage_slot(c, fd_bytes + m_bytes, &gs));
+    std::memcpy(gs->h, fresh.data(), fd_bytes);
+    std::memcpy(gs->h + fd_bytes, m, m_bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, gs->h, fd_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mats, gs->h + fd_bytes, m_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(gs->done, c->stream)); gs->used = true;
     c->geo_frames.swap(fresh);
     c->geo_kind = kind; c->geo_from_points = false;
     bool exact = kind == HG_AFFINE;
@@ -626,10 +656,16 @@ extern "C" int hg_geometric_set_frames_points(hg_ctx *c, int kind, const float *
     HG_TRY(ensure(c, c->d_mats, c->mats_cap, (size_t)n * 8));
     HG_TRY(ensure(c, c->d_geo_pts, c->geo_pts_cap, (size_t)n * 16));
     HG_TRY(ensure(c, c->d_geo_plain, c->geo_plain_cap, (size_t)n));
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, fresh.data(), sizeof(FrameDesc) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_pts, from, sizeof(float) * per * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_pts + (size_t)n * 8, to, sizeof(float) * per * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t fd_bytes = sizeof(FrameDesc) * (size_t)n, p_bytes = sizeof(float) * per * (size_t)n;
+    hg_ctx::GeoStage *gs = nullptr;
+    HG_TRY(geo_stage_slot(c, fd_bytes + 2 * p_bytes, &gs));
+    std::memcpy(gs->h, fresh.data(), fd_bytes);
+    std::memcpy(gs->h + fd_bytes, from, p_bytes);
+    std::memcpy(gs->h + fd_bytes + p_bytes, to, p_bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, gs->h, fd_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_pts, gs->h + fd_bytes, p_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_geo_pts + (size_t)n * 8, gs->h + fd_bytes + p_bytes, p_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(gs->done, c->stream)); gs->used = true;
     c->geo_frames.swap(fresh);
     c->geo_kind = kind; c->geo_from_points = true;
     bool exact = kind == HG_AFFINE;                          // affine: the solve stores float32 values; x stays below 2^28?

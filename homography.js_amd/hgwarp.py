@@ -394,6 +394,17 @@ class Context:
         offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
         self._c(lib().hg_geometric_set_frames_points(self._h, int(kind), ap, bp, _geoms(geoms), offs, len(geoms)))
 
+    def geometric_points_args(self, kind, from_pts, to_pts, geoms, offsets=None):
+        """The ctypes arguments of geometric_set_frames_points, built once (bench.py --points fresh)."""
+        per = 6 if int(kind) == 0 else 8
+        (a, ap), (b, bp) = _f32(from_pts), _f32(to_pts)
+        assert a.size == per * len(geoms) and b.size == per * len(geoms)
+        offs = (C.c_size_t * len(geoms))(*offsets) if offsets is not None else None
+        return (a, b, int(kind), ap, bp, _geoms(geoms), offs, len(geoms))
+
+    def geometric_set_frames_points_prepared(self, args):
+        self._c(lib().hg_geometric_set_frames_points(self._h, args[2], args[3], args[4], args[5], args[6], args[7]))
+
     def get_geometric_matrices(self, n_frames):
         out = np.empty((int(n_frames), 8), np.float64)
         self._c(lib().hg_get_geometric_matrices(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), int(n_frames)))

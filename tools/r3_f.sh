@@ -1,23 +1,16 @@
 #!/bin/bash
 export TMPDIR=/tmp
 o=$PWD/gpurun_out/r3f; rm -rf $o; mkdir -p $o
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fresh_point or fall_back or patch_kernel_limits or full_size_batches" > $o/pytest.log 2>&1; echo "pytest rc=$?" >> $o/pytest.log
-tail -15 $o/pytest.log
-timeout 600 python bench.py --no-cpu-baseline > $o/bench.json 2> $o/bench.err; echo "bench rc=$?"; tail -3 $o/bench.err
-python - <<'PY'
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_rccl.py -x -q -m gpu -k "geometric or device_side or rccl or torchrun or projective" > $o/pytest.log 2>&1; echo "pytest rc=$?" >> $o/pytest.log
+tail -3 $o/pytest.log
+for c in C2 C4; do
+timeout 600 python bench.py --no-cpu-baseline --config $c > $o/bench_$c.json 2> $o/bench_$c.err; echo "bench $c rc=$?"
+python - <<PY
 import json
-d=json.loads(open("gpurun_out/r3f/bench.json").read().strip().splitlines()[-1])
+d=json.loads(open("gpurun_out/r3f/bench_$c.json").read().strip().splitlines()[-1])
 print(d["value"], d["ms_per_step"], d["verified"], [c for c in d["checks"] if not c["ok"]])
-print("roofline", {k:d["roofline"][k] for k in ("frac","kernel_ms","hbm_compulsory_frac")})
-print("fresh", d["roofline_fresh"])
-print("distinct", {k:d["roofline_distinct"][k] for k in ("kernel","frac","kernel_ms","ms_per_step")})
+print("roofline", {k:d["roofline"][k] for k in ("frac","kernel_ms","traffic")})
+print("fresh", {k:d["roofline_fresh"][k] for k in ("ms_per_step","vs_resident_ms_per_step","layout_walks_in_region","frames_redone_in_region")})
+print("distinct", {k:d["roofline_distinct"][k] for k in ("kernel","frac","kernel_ms","ms_per_step","traffic")})
 PY
-timeout 600 python bench.py --no-cpu-baseline --config C5 --frames 8 > $o/bench_C5.json 2> $o/bench_C5.err; echo "bench C5 rc=$?"
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r3f/bench_C5.json").read().strip().splitlines()[-1])
-print(d["value"], d["ms_per_step"], d["verified"], [c for c in d["checks"] if not c["ok"]])
-print("roofline", {k:d["roofline"][k] for k in ("frac","kernel_ms","hbm_compulsory_frac")})
-print("fresh", d["roofline_fresh"])
-print("distinct", {k:d["roofline_distinct"][k] for k in ("kernel","frac","kernel_ms","ms_per_step")})
-PY
+done
