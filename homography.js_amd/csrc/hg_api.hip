@@ -106,6 +106,7 @@ struct hg_ctx {
     int pw_table_grown = 0;
     int opt_table = -1;                                        // 1: the table path whenever eligible; -1 / 0: row lists (the default, see run_setup)
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
+    int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate
     int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
     int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
     // layout estimates of the last frame set, reused for the next set of the same shape (the kernels check the real counts)
@@ -375,6 +376,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
     else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
     else if (!std::strcmp(key, "table")) { c->opt_table = value; c->pw_table_disabled = false; }
+    else if (!std::strcmp(key, "tri_threads")) c->opt_tri_threads = (value == 64 || value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "rows1_threads")) c->opt_rows1_threads = (value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "col_split")) c->opt_col_split = (value == 1 || value == 2 || value == 4) ? value : -1;
     else if (!std::strcmp(key, "lds_pad")) c->opt_lds_pad = std::min(std::max(value, -1), 40);
@@ -982,7 +984,10 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     c->pw_patch_dense = !c->pw_patch && cover > kPatchMaxRowSpans && cover <= kPatchMaxRowSpansDense && max_w <= kPatchMaxW &&
                         (int64_t)cover * 64 <= (int64_t)8 * max_w && !c->pw_patch_disabled;
     if (c->pw_patch_dense) c->pw_patch = true;
-    c->pw_tri_threads = tri_rows <= 192.0 ? 64 : 128;       // k_tri_spans: one thread per triangle row, one or two waves
+    // k_tri_spans: one thread per triangle row and round.  Measured round 3 (step ms, 64 / 128 / 256 threads): C5 (~150 rows per
+    // triangle, 8 frames) 0.475 / 0.463 / 0.489, C3 (~300 rows, 64 frames) 0.612 / 0.589 / 0.603; a single 4K frame 25.4 / 23.4 / 22.6 us
+    c->pw_tri_threads = tri_rows <= 96.0 ? 64 : ((int64_t)F * c->n_tris <= 2048 && tri_rows > 128.0 ? 256 : 128);
+    if (c->opt_tri_threads > 0) c->pw_tri_threads = c->opt_tri_threads;
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
     if (cover > 200 && c->row_cap < kRowSpanCapDense) c->row_cap = kRowSpanCapDense;
     // (the row counters and the status ring are reused as they are when their layout -- frame count, rows per frame, list

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
 
 
 template <class X, bool COMPACT>      // X: experiment hooks (hg_dev.h); the product only instantiates NoExperiment
-__global__ __launch_bounds__(128) void k_tri_spans(PwMesh mesh, PwFrames fr, RowLists rl)
+__global__ __launch_bounds__(256) void k_tri_spans(PwMesh mesh, PwFrames fr, RowLists rl)
 {
     const int t = blockIdx.x, f = blockIdx.y;
     const FrameDesc fd = fr.frames[f];
@@ -723,7 +723,7 @@ bool pw_fast_ok(const PwMesh &mesh, int max_obj_w)
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream)
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
-    const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads == 64 ? 64 : 128);
+    const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads == 64 ? 64 : (fr.tri_threads >= 256 ? 256 : 128));
 #ifdef HG_EXPERIMENTS
     if (launch_tri_spans_ablated(mesh, fr, rl, grid, block, stream)) return;      // experiments/hg_ablate.h
 #endif

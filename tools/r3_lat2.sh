@@ -1,6 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-o=$PWD/gpurun_out/r3lat; rm -rf $o; mkdir -p $o
-for t in 256 128; do for mg in 1536 6000; do
-  echo "rows1_threads=$t min_row_groups=$mg"; python tools/latency_f.py rows1_threads=$t min_row_groups=$mg 2>&1 | grep "^{"
-done; done
+for t in 64 128 256; do echo "tri_threads=$t"; python tools/latency_f.py tri_threads=$t 2>&1 | grep "^{"; done
+python tools/sweep.py C3,C4 tri_threads=64,128,256 --sources shared 2>&1 | grep "config" | awk '{print $2, $6, $8, $10, $12, $14,$16}'
+python tools/sweep.py C5 tri_threads=64,128,256 --sources shared 2>&1 | grep "config" | awk '{print $2, $6, $8, $10, $12, $14,$16}'
