@@ -882,6 +882,9 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     // Queued runs are NOT waited for: the uploads below are ordered behind them on the stream, and each of them keeps its own
     // staged copy of the set it warped (deferred redo, hg_sync).  Only a staging slot that a queued run still refers to forces a
     // settlement first (a caller that uploads 64 sets per run).
+    // A queued FORWARD batch is different: its redo reads the context's current frame arrays (no staged copy), so it is settled
+    // before they are replaced.
+    if (c->fwd_pending.n > 0) HG_TRY(hg_sync(c));
     const size_t T = (size_t)std::max(c->n_tris, 1), F = (size_t)n;
     const int slot = (c->stage_cur + 1) % (int)kStatusRing;
     for (const hg_ctx::Pending &pd : c->pw_pending_out) if (pd.stage == slot) { HG_TRY(hg_sync(c)); break; }
