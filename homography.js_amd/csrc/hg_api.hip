@@ -12,6 +12,7 @@
 
 using namespace hg;
 
+constexpr size_t kFwdStatusRing = 16;   // tile-binned forward piecewise batches that may be queued before their status words are checked
 constexpr size_t kStatusRing = 64;      // fused piecewise runs that may be queued before their status words are checked
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -39,8 +40,9 @@ struct hg_ctx {
 
     // piecewise frames
     std::vector<FrameDesc> pw_frames;          // host copy
-    FrameDesc *d_pw_frames = nullptr; size_t pw_frames_cap = 0;
-    float *d_dst = nullptr; size_t dst_cap = 0;
+    uint8_t *d_set = nullptr; size_t set_cap = 0;             // the frame set in ONE block: F frame records, then F x n_pts x 2 destiny floats (one upload)
+    FrameDesc *d_pw_frames = nullptr;                         // = d_set
+    float *d_dst = nullptr;                                   // = d_set + F * sizeof(FrameDesc)
     TriRange *d_trir = nullptr; size_t trir_cap = 0;
     Seg *d_segs = nullptr; size_t segs_cap = 0;
     float *d_fwd = nullptr; size_t fwd_cap = 0;
@@ -140,13 +142,17 @@ struct hg_ctx {
     uint32_t *d_frowoff = nullptr; size_t frowoff_cap = 0;     // ... offset of its per-row extents
     int32_t *d_frowext = nullptr; size_t frowext_cap = 0;      // ... {min mx, max mx} per (matrix index, map row of its bbox)
     bool fwd_rowext_ok = false;
-    int32_t *d_ftile_cnt = nullptr; size_t ftile_cnt_cap = 0;  // F x tiles counters, then F status words
+    int32_t *d_ftile_cnt = nullptr; size_t ftile_cnt_cap = 0;  // F x tiles counters (zero between calls)
+    int32_t *d_fwd_status = nullptr; size_t fwd_status_cap = 0, fwd_status_stride = 0;   // kFwdStatusRing sets of `stride` status words of tile-binned forward piecewise batches (zero between calls)
     int32_t *d_ftile_ent = nullptr; size_t ftile_ent_cap = 0;  // F x tiles x fwd_pw_cap entries
     double pw_spans_per_window = 0.0;                          // longest row's span count per 256-pixel window (layout heuristic)
     bool pw_quick_layout = false;                              // set around the forward paths' hg_piecewise_set_frames calls
     int fwd_pw_cap = 64;                                       // entries per tile (doubles after an overflow, up to kFwdPwCapMax)
     bool fwd_pw_tiles_disabled = false;                        // overflowed at the largest capacity once: stay with the scatter path for this mesh
-    struct FwdPending { uint8_t *out = nullptr; int n = 0; int32_t *status = nullptr; int max_src_x = 0, max_src_y = 0; } fwd_pending;
+    // queued tile-binned forward piecewise batches: status set `slot` of the forward status ring, frame set in staging slot `stage`
+    struct FwdPending { uint8_t *out = nullptr; int n = 0; int slot = 0; int stage = -1; int max_src_x = 0, max_src_y = 0; };
+    std::vector<FwdPending> fwd_pending;
+    int fwd_slot = 0;
     int opt_fwd_tiles = -1;                                    // forward paths: -1 auto, 0 scatter + gather, 1 tiles whenever admissible
     int fwd_last_kernel = 0;                                   // 1 scatter + gather, 2 k_fwd_tiles (hg_last_kernel-style tap for the tests)
     int16_t *d_map16 = nullptr; size_t map16_cap = 0;
@@ -254,8 +260,8 @@ extern "C" void hg_destroy(hg_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
-    void *ptrs[] = { c->d_src, c->d_tris, c->d_pw_frames, c->d_dst, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent, c->d_tbl,
-                     c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
+    void *ptrs[] = { c->d_src, c->d_tris, c->d_set, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent, c->d_tbl,
+                     c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_fwd_status, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (hg_ctx::Stage &st : c->stage) if (st.h) (void)hipHostFree(st.h);
@@ -303,7 +309,7 @@ extern "C" int hg_copy_to_host_async(hg_ctx *c, void *dst, const void *src, size
 {
     HG_TRY(bind(c));
     if (!dst || !src) return fail(c, HG_ERR_INVALID, "NULL pointer");
-    if (!c->pw_pending_out.empty() || c->fwd_pending.n > 0) HG_TRY(hg_sync(c));
+    if (!c->pw_pending_out.empty() || !c->fwd_pending.empty()) HG_TRY(hg_sync(c));
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     return HG_OK;
 }
@@ -882,16 +888,13 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     // Queued runs are NOT waited for: the uploads below are ordered behind them on the stream, and each of them keeps its own
     // staged copy of the set it warped (deferred redo, hg_sync).  Only a staging slot that a queued run still refers to forces a
     // settlement first (a caller that uploads 64 sets per run).
-    // A queued FORWARD batch is different: its redo reads the context's current frame arrays (no staged copy), so it is settled
-    // before they are replaced.
-    if (c->fwd_pending.n > 0) HG_TRY(hg_sync(c));
     const size_t T = (size_t)std::max(c->n_tris, 1), F = (size_t)n;
     const int slot = (c->stage_cur + 1) % (int)kStatusRing;
     for (const hg_ctx::Pending &pd : c->pw_pending_out) if (pd.stage == slot) { HG_TRY(hg_sync(c)); break; }
+    for (const hg_ctx::FwdPending &pd : c->fwd_pending) if (pd.stage == slot) { HG_TRY(hg_sync(c)); break; }   // (their redo reads the staged set too)
     std::vector<FrameDesc> fresh;
     HG_TRY(fill_frames(c, fresh, geoms, offs, n));
-    HG_TRY(ensure(c, c->d_pw_frames, c->pw_frames_cap, F));
-    HG_TRY(ensure(c, c->d_dst, c->dst_cap, F * c->n_pts * 2));
+    HG_TRY(ensure(c, c->d_set, c->set_cap, sizeof(FrameDesc) * F + sizeof(float) * 2 * c->n_pts * F));
     HG_TRY(ensure(c, c->d_trir, c->trir_cap, F * T));
     HG_TRY(ensure(c, c->d_segs, c->segs_cap, F * T * 3));
     HG_TRY(ensure(c, c->d_fwd, c->fwd_cap, F * T * 6));
@@ -919,8 +922,9 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     std::memcpy(st.h, fresh.data(), fd_bytes);
     std::memcpy(st.h + fd_bytes, dst, pt_bytes);
     st.n = n; st.n_pts = c->n_pts;
-    HIP_TRY(c, hipMemcpyAsync(c->d_pw_frames, st.h, fd_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_dst, st.h + fd_bytes, pt_bytes, hipMemcpyHostToDevice, c->stream));
+    static_assert(sizeof(FrameDesc) % 8 == 0, "the destiny points follow the frame records in the same block");
+    c->d_pw_frames = reinterpret_cast<FrameDesc *>(c->d_set); c->d_dst = reinterpret_cast<float *>(c->d_set + fd_bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->d_set, st.h, fd_bytes + pt_bytes, hipMemcpyHostToDevice, c->stream));    // (one DMA: the staged block has the device layout)
     c->pw_frames.swap(fresh);
     c->stage_cur = slot;
     double tri_rows = 0.0, shear = 0.0;
@@ -1220,12 +1224,44 @@ static int redo_frame_staged(hg_ctx *c, int stage, int f, uint8_t *d_out)
     return HG_OK;
 }
 
+// The forward counterpart: frame f of the staged set through k_fwd_scatter_pw + k_fwd_gather with its own matrices (solved in the
+// one-frame scratch), over the context's forward map.
+static int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int max_src_y, uint8_t *d_out)
+{
+    if (stage < 0 || !c->fmap_valid) return fail(c, HG_ERR_STATE, "deferred forward redo: the staged frame set is gone");
+    const hg_ctx::Stage &st = c->stage[stage];
+    if (!st.h || f >= st.n || st.n_pts != c->n_pts) return fail(c, HG_ERR_STATE, "deferred forward redo: the staged frame set is gone");
+    const FrameDesc fd = reinterpret_cast<const FrameDesc *>(st.h)[f];
+    const size_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h : 0;
+    if (n == 0) return HG_OK;
+    const size_t T = (size_t)std::max(c->n_tris, 1);
+    HG_TRY(ensure(c, c->d_redo_frame, c->redo_frame_cap, (size_t)1));
+    HG_TRY(ensure(c, c->d_redo_dst, c->redo_dst_cap, (size_t)c->n_pts * 2));
+    HG_TRY(ensure(c, c->d_redo_trir, c->redo_trir_cap, T));
+    HG_TRY(ensure(c, c->d_redo_segs, c->redo_segs_cap, T * 3));
+    HG_TRY(ensure(c, c->d_redo_fwd, c->redo_fwd_cap, T * 6));
+    HG_TRY(ensure(c, c->d_redo_inv, c->redo_inv_cap, T * kInvStride));
+    HG_TRY(ensure(c, c->d_redo_status, c->redo_status_cap, (size_t)1));
+    HG_TRY(ensure(c, c->d_win32, c->win32_cap, n));
+    const float *pts = reinterpret_cast<const float *>(st.h + sizeof(FrameDesc) * (size_t)st.n) + (size_t)f * c->n_pts * 2;
+    HIP_TRY(c, hipMemcpyAsync(c->d_redo_frame, st.h + sizeof(FrameDesc) * (size_t)f, sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_redo_dst, pts, sizeof(float) * 2 * c->n_pts, hipMemcpyHostToDevice, c->stream));
+    PwFrames fr = frames_of(c);
+    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
+    fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
+    launch_tri_setup(mesh_of(c), fr, c->stream);
+    launch_fwd_pw(c->d_fmap, c->d_redo_fwd, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, max_src_x - c->min_src_x, max_src_y - c->min_src_y,
+                  fd, c->d_win32, d_out, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
 extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
 {
     HG_TRY(bind(c));
     if (!d_out) return fail(c, HG_ERR_INVALID, "d_out is NULL");
     HG_TRY(check_pw_state(c));
-    if (c->pw_pending_out.size() >= kStatusRing - 1) HG_TRY(hg_sync(c));
+    if (c->pw_pending_out.size() >= kStatusRing - 1 || !c->fwd_pending.empty()) HG_TRY(hg_sync(c));
     // The reference recomputes the per-triangle matrices on every setDestinyPoints and the map + inverses on every
     // warp(): both are part of the per-frame step, so both run here every time.
     HG_TRY(run_setup(c));
@@ -1280,30 +1316,34 @@ extern "C" int hg_sync(hg_ctx *c)
             }
         }
     }
-    if (c->fwd_pending.n > 0) {
-        // tile-binned forward piecewise frames the device flagged (a triangle it could not bound, an overfull tile list):
-        // redone through scatter + gather into the same output, from the state the call left in the context
-        const hg_ctx::FwdPending fp = c->fwd_pending;
-        c->fwd_pending.n = 0;
-        std::vector<int32_t> st((size_t)fp.n);
-        HIP_TRY(c, hipMemcpy(st.data(), fp.status, sizeof(int32_t) * fp.n, hipMemcpyDeviceToHost));
+    if (!c->fwd_pending.empty()) {
+        // tile-binned forward piecewise frames the device flagged (a triangle it could not bound, an overfull tile list): redone
+        // through scatter + gather into the output of the call that flagged them, from that call's staged frame set (newer sets
+        // may have been uploaded since).  The forward map is the context's: a new mesh settles queued runs first.
+        std::vector<hg_ctx::FwdPending> pending;
+        pending.swap(c->fwd_pending);
+        std::vector<int32_t> st(c->fwd_status_cap);
+        HIP_TRY(c, hipMemcpy(st.data(), c->d_fwd_status, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost));
         bool overflow = false, unbounded = false, any = false;
-        const int map_w = fp.max_src_x - c->min_src_x, map_h = fp.max_src_y - c->min_src_y;
-        size_t max_px = 0;
-        for (int f = 0; f < fp.n && f < (int)c->pw_frames.size(); f++)
-            if (st[f] != 0 && c->pw_frames[f].obj_w > 0 && c->pw_frames[f].obj_h > 0) max_px = std::max(max_px, (size_t)c->pw_frames[f].obj_w * c->pw_frames[f].obj_h);
-        if (max_px) HG_TRY(ensure(c, c->d_win32, c->win32_cap, max_px));
-        for (int f = 0; f < fp.n && f < (int)c->pw_frames.size(); f++) {
-            if (st[f] == 0) continue;
-            any = true; c->pw_redone++;
-            if (st[f] & FWD_OVERFLOW) overflow = true;
-            if (st[f] & FWD_FALLBACK) unbounded = true;
-            const FrameDesc &fd = c->pw_frames[f];
-            if (fd.obj_w <= 0 || fd.obj_h <= 0) continue;
-            launch_fwd_pw(c->d_fmap, c->d_fwd + (size_t)f * c->n_tris * 6, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, map_w, map_h,
-                          fd, c->d_win32, fp.out, c->stream);
+        for (size_t i = 0; i < pending.size(); i++) {
+            const hg_ctx::FwdPending &fp = pending[i];
+            bool superseded = false;                             // a later queued batch wrote the same output: its frames are the newer ones
+            for (size_t j = i + 1; j < pending.size(); j++) if (pending[j].out == fp.out) superseded = true;
+            const int32_t *sf = st.data() + (size_t)fp.slot * c->fwd_status_stride;
+            for (int f = 0; f < fp.n; f++) {
+                if (sf[f] == 0) continue;
+                any = true;
+                if (sf[f] & FWD_OVERFLOW) overflow = true;
+                if (sf[f] & FWD_FALLBACK) unbounded = true;
+                if (superseded) continue;
+                c->pw_redone++;
+                HG_TRY(redo_forward_frame_staged(c, fp.stage, f, fp.max_src_x, fp.max_src_y, fp.out));
+            }
         }
-        if (any) { HIP_TRY(c, hipGetLastError()); HIP_TRY(c, hipStreamSynchronize(c->stream)); }
+        if (any) {
+            HIP_TRY(c, hipMemsetAsync(c->d_fwd_status, 0, sizeof(int32_t) * c->fwd_status_cap, c->stream));   // (zero between calls)
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
         if (overflow) {
             if (c->fwd_pw_cap < kFwdPwCapMax) c->fwd_pw_cap = std::min(kFwdPwCapMax, c->fwd_pw_cap * 2);
             else c->fwd_pw_tiles_disabled = true;
@@ -1618,7 +1658,9 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
     //     so it is kept until the mesh (or the bbox) changes -- like the reference's cached _trianglesCorrespondencesMatrix.
     hg_geom gmap = { 0, c->min_src_y, (int32_t)map_w, (int32_t)map_h };
     const size_t zero = 0;
+    if (!c->pw_pending_out.empty()) HG_TRY(hg_sync(c));       // (queued inverse runs: one order of deferred redos per output buffer)
     if (n_map && !(c->fmap_valid && c->fmap_w == map_w && c->fmap_h == map_h)) {
+        if (!c->fwd_pending.empty()) HG_TRY(hg_sync(c));     // (queued batches are redone over the map they ran on)
         HG_TRY(hg_piecewise_set_frames(c, c->h_src.data(), &gmap, &zero, 1));
         c->status_ptr = c->d_status;
         HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t), c->stream));
@@ -1636,8 +1678,7 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
     const int rc_frames = hg_piecewise_set_frames(c, dst_points, geoms, offs, n);
     c->pw_quick_layout = false;
     HG_TRY(rc_frames);
-    c->status_ptr = c->d_status;
-    HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * n, c->stream));
+    c->status_ptr = c->d_status;                             // (k_tri_setup only ORs flags into these words and nothing on the forward path reads them: not cleared)
     launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
     c->pw_setup_done = false;
     size_t max_px = 0;
@@ -1652,24 +1693,38 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
             tiles += (int64_t)((fd.obj_w + kFwdTileW - 1) / kFwdTileW) * ((fd.obj_h + kFwdTileH - 1) / kFwdTileH);
         }
         const int tsx = (mw + kFwdTileW - 1) / kFwdTileW, tsy = (mh + kFwdTileH - 1) / kFwdTileH;
-        bool use_tiles = n_map > 0 && c->n_tris > 0 && !c->fwd_pw_tiles_disabled && tsy <= 65535 &&
+        bool use_tiles = n_map > 0 && c->n_tris > 0 && !c->fwd_pw_tiles_disabled && tsy <= 65535 && map_w <= 65535 &&   // (winner keys: 16 bits per map coordinate)
                          (c->opt_fwd_tiles > 0 || (c->opt_fwd_tiles < 0 && tiles >= 160 && (int64_t)n_map <= tiles * 32768 &&
                                                    (int64_t)c->n_tris * n <= 4 * tiles));   // (dense meshes, > 4 triangles per tile: no gain measured)
         if (use_tiles) { HG_TRY(ensure_fwd_rowext(c, (int)map_w, (int)map_h)); use_tiles = c->fwd_rowext_ok; }
         if (use_tiles) {
+            // The tile counters and the per-frame status words are ZERO between calls: k_fwd_pw_tiles clears the counter of every
+            // tile it consumes, hg_sync the status words it found set -- no memset in front of every batch (two stream operations
+            // less per call: they were a fifth of a single 4K frame's time).  Status words: a ring of sets, one per queued batch.
             const size_t per = (size_t)n * tsx * tsy;
-            HG_TRY(ensure(c, c->d_ftile_cnt, c->ftile_cnt_cap, per + (size_t)n));
+            { const size_t cap0 = c->ftile_cnt_cap;
+              HG_TRY(ensure(c, c->d_ftile_cnt, c->ftile_cnt_cap, per));
+              if (c->ftile_cnt_cap != cap0) HIP_TRY(c, hipMemsetAsync(c->d_ftile_cnt, 0, sizeof(int32_t) * c->ftile_cnt_cap, c->stream)); }
+            if (c->fwd_pending.size() >= kFwdStatusRing - 1 || (size_t)n > c->fwd_status_stride) {
+                HG_TRY(hg_sync(c));                              // ring full, or a larger batch than the ring's sets were laid out for
+                if ((size_t)n > c->fwd_status_stride) {
+                    HG_TRY(ensure(c, c->d_fwd_status, c->fwd_status_cap, (size_t)n * kFwdStatusRing));
+                    c->fwd_status_stride = c->fwd_status_cap / kFwdStatusRing;
+                    HIP_TRY(c, hipMemsetAsync(c->d_fwd_status, 0, sizeof(int32_t) * c->fwd_status_cap, c->stream));
+                }
+            }
+            c->fwd_slot = (c->fwd_slot + 1) % (int)kFwdStatusRing;
             HG_TRY(ensure(c, c->d_ftile_ent, c->ftile_ent_cap, per * (size_t)c->fwd_pw_cap));
-            HIP_TRY(c, hipMemsetAsync(c->d_ftile_cnt, 0, sizeof(int32_t) * (per + (size_t)n), c->stream));
             FwdPwTiles p;
             p.fmap = c->d_fmap; p.fwd = c->d_fwd; p.bbox = c->d_fbbox; p.frames = c->d_pw_frames; p.rowext = c->d_frowext; p.rowoff = c->d_frowoff;
-            p.tile_cnt = c->d_ftile_cnt; p.tile_ent = c->d_ftile_ent; p.status = c->d_ftile_cnt + per;
+            p.tile_cnt = c->d_ftile_cnt; p.tile_ent = c->d_ftile_ent; p.status = c->d_fwd_status + (size_t)c->fwd_slot * c->fwd_status_stride;
             p.T = c->n_tris; p.min_src_x = c->min_src_x; p.min_src_y = c->min_src_y; p.map_w = (int)map_w; p.map_h = (int)map_h;
             p.tsx = tsx; p.tsy = tsy; p.cap = c->fwd_pw_cap;
             launch_fwd_pw_tiles(p, n, mw, mh, c->d_img, c->W, c->H, static_cast<uint8_t *>(d_out), c->stream);
             HIP_TRY(c, hipGetLastError());
-            c->fwd_pending.out = static_cast<uint8_t *>(d_out); c->fwd_pending.n = n; c->fwd_pending.status = p.status;
-            c->fwd_pending.max_src_x = max_src_x; c->fwd_pending.max_src_y = max_src_y;
+            { hg_ctx::FwdPending fp;
+              fp.out = static_cast<uint8_t *>(d_out); fp.n = n; fp.slot = c->fwd_slot; fp.stage = c->stage_cur; fp.max_src_x = max_src_x; fp.max_src_y = max_src_y;
+              c->fwd_pending.push_back(fp); }
             c->fwd_last_kernel = 2;
             return HG_OK;
         }

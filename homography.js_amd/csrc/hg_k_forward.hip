@@ -227,17 +227,24 @@ __global__ __launch_bounds__(256) void k_fwd_tiles(FwdBatch batch, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------ forward piecewise, tile-binned
-// inclusive prefix sum over the 256 threads of a workgroup (two barriers; s_wsum: 4 ints of LDS)
-__device__ __forceinline__ int block_scan_incl(int v, int *s_wsum, int lane, int wave)
+// inclusive prefix sum over the NW * 64 threads of a workgroup (two barriers; s_wsum: NW ints of LDS); total = the sum over all
+template <int NW>
+__device__ __forceinline__ int block_scan_incl(int v, int *s_wsum, int lane, int wave, int &total)
 {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
     __syncthreads();
     if (lane == 63) s_wsum[wave] = v;
     __syncthreads();
+    total = 0;
 #pragma unroll
-    for (int w = 0; w < 3; w++) if (w < wave) v += s_wsum[w];
+    for (int w = 0; w < NW; w++) { const int ws = s_wsum[w]; if (w < wave) v += ws; total += ws; }
     return v;
+}
+__device__ __forceinline__ int block_scan_incl(int v, int *s_wsum, int lane, int wave)
+{
+    int total;
+    return block_scan_incl<4>(v, s_wsum, lane, wave, total);
 }
 
 __global__ void k_bbox_init(int32_t *bbox, int T)
@@ -350,22 +357,34 @@ __global__ __launch_bounds__(256) void k_fwd_pw_bins(FwdPwTiles p)
 // triangle's matrix, cut to the triangle's cell bbox; (1) one lane per (entry, row): the x interval; (2) one lane per source
 // pixel, kept only if the forward map assigns it to this triangle.  Both levels are laid out back to back with prefix sums, so
 // twenty small triangles cost what one large one costs.
-__global__ __launch_bounds__(256) void k_fwd_pw_tiles(FwdPwTiles p, const uint8_t *__restrict__ img, int W, int H, uint8_t *__restrict__ out)
+//
+// Shape of the workgroup (round 3; the loop was latency-bound, not ALU-bound: 46 of 65 us per 4K frame sat in step (2) with four
+// waves per SIMD, each walking a prefix array to find its row): 512 threads share the tile's 16 KB of winner words (8 waves per
+// SIMD at 4 workgroups per CU), and step (2) finds its row in ONE LDS read -- the rows of a pass are cut into 16-candidate
+// segments listed in s_seg, candidate c belongs to segment c >> 4 -- then reads one 16-byte row record and the matrix.
+constexpr int kPwT = 512;                  // threads per tile workgroup == (entry, row) records per pass
+constexpr int kPwSegW = 16, kPwSegLog2 = 4;
+constexpr int kPwSegCap = 1024;            // segments per round (16 384 candidates); a pass with more takes several rounds
+constexpr int kPwUnroll = 2;               // candidates in flight per lane (4: 70 VGPRs, 7 waves per SIMD; 2 with the cap below: 8)
+static_assert(kFwdPwCapMax <= kPwT && kPwT == 512, "row records carry the row's slot in 9 bits");
+
+__global__ __launch_bounds__(kPwT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fwd_pw_tiles(FwdPwTiles p, const uint8_t *__restrict__ img, int W, int H, uint8_t *__restrict__ out)
 {
-    __shared__ int s_win[kFwdTileW * kFwdTileH];
-    __shared__ double s_m[kFwdPwCapMax][6];
-    __shared__ int s_et[kFwdPwCapMax], s_ek[kFwdPwCapMax], s_eylo[kFwdPwCapMax], s_epre[kFwdPwCapMax];
-    __shared__ long long s_ebase[kFwdPwCapMax];                        // index of the entry's row-extent record for source row 0
-    __shared__ int s_pe[256], s_py[256], s_pxa[256], s_ppre[256];
-    __shared__ int s_wsum[4];
+    __shared__ uint32_t s_win[kFwdTileW * kFwdTileH];                  // 0 = no writer, else ((map row << 16) | map column) + 1
+    __shared__ float s_m[kFwdPwCapMax][6];                             // (the matrices ARE floats: _trianglesTransforms is a Float32Array)
+    __shared__ int s_etk[kFwdPwCapMax], s_eylo[kFwdPwCapMax], s_epre[kFwdPwCapMax];
+    __shared__ int s_ebase[kFwdPwCapMax];                              // index of the entry's row-extent record for source row 0 (< 2^27 rows in total)
+    __shared__ int4 s_row[kPwT];                                       // {first x, length, y, entry | t << 8 | (k + 2) << 24}
+    __shared__ uint32_t s_seg[kPwSegCap];                              // row slot | (segment of that row) << 9
+    __shared__ int s_wsum[kPwT / 64];
     const int f = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameDesc fd = p.frames[f];
     const int tx0 = blockIdx.x * kFwdTileW, ty0 = blockIdx.y * kFwdTileH;
     if (tx0 >= fd.obj_w || ty0 >= fd.obj_h) return;
-    if (p.status[f] != 0) return;                                      // flagged by k_fwd_pw_bins: the host redoes this frame
-    const int tx1 = min(tx0 + kFwdTileW, fd.obj_w), ty1 = min(ty0 + kFwdTileH, fd.obj_h);
-    for (int i = tid; i < kFwdTileW * kFwdTileH; i += 256) s_win[i] = -1;
     const size_t tidx = ((size_t)f * p.tsy + blockIdx.y) * p.tsx + blockIdx.x;
+    if (p.status[f] != 0) { if (tid == 0) p.tile_cnt[tidx] = 0; return; }   // flagged by k_fwd_pw_bins: the host redoes this frame (counters are left zero for the next batch)
+    const int tx1 = min(tx0 + kFwdTileW, fd.obj_w), ty1 = min(ty0 + kFwdTileH, fd.obj_h);
+    for (int i = tid; i < kFwdTileW * kFwdTileH; i += kPwT) s_win[i] = 0u;
     const int E = min(p.tile_cnt[tidx], p.cap);
     const int32_t *__restrict__ ents = p.tile_ent + tidx * p.cap;
     const float *__restrict__ fwd = p.fwd + (size_t)f * p.T * 6;
@@ -377,8 +396,8 @@ __global__ __launch_bounds__(256) void k_fwd_pw_tiles(FwdPwTiles p, const uint8_
         const int e = ents[tid], t = e & 0xffff, k = (e >> 16) - 2;
         double m[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) { m[j] = fwd[(size_t)t * 6 + j]; s_m[tid][j] = m[j]; }
-        const int cx0 = p.bbox[4 * t], cy0 = p.bbox[4 * t + 1], cx1 = p.bbox[4 * t + 2], cy1 = p.bbox[4 * t + 3];
+        for (int j = 0; j < 6; j++) { const float v = fwd[(size_t)t * 6 + j]; m[j] = v; s_m[tid][j] = v; }
+        const int cy0 = p.bbox[4 * t + 1], cy1 = p.bbox[4 * t + 3];
         int ylo = cy0 + p.min_src_y, yhi = cy1 + p.min_src_y;
         const double fx_lo = (double)(tx0 + k * fd.obj_w) + fd.x_off - 0.5 - eps, fx_hi = (double)(tx1 - 1 + k * fd.obj_w) + fd.x_off + 0.5 + eps;
         const double fy_lo = (double)(ty0 - k) + fd.y_off - 0.5 - eps, fy_hi = (double)(ty1 - 1 - k) + fd.y_off + 0.5 + eps;
@@ -401,34 +420,36 @@ __global__ __launch_bounds__(256) void k_fwd_pw_tiles(FwdPwTiles p, const uint8_
             }
         }
         nrows = yhi >= ylo ? yhi - ylo + 1 : 0;
-        s_et[tid] = t; s_ek[tid] = k; s_eylo[tid] = ylo;
-        s_ebase[tid] = (long long)p.rowoff[t] - (long long)(cy0 + p.min_src_y);
-        (void)cx0; (void)cx1;
+        s_etk[tid] = t | ((k + 2) << 16); s_eylo[tid] = ylo;
+        s_ebase[tid] = (int)((long long)p.rowoff[t] - (long long)(cy0 + p.min_src_y));
     }
     {
-        const int incl = block_scan_incl(nrows, s_wsum, lane, wave);
-        s_epre[tid] = incl;
+        int total;
+        const int incl = block_scan_incl<kPwT / 64>(nrows, s_wsum, lane, wave, total);
+        if (tid < kFwdPwCapMax) s_epre[tid] = incl;
+        if (tid == 0) p.tile_cnt[tidx] = 0;                            // (every thread read it before the scan's barriers) zero for the next batch
     }
     __syncthreads();
     const int R = s_epre[kFwdPwCapMax - 1];
 
 #pragma unroll 1
-    for (int q0 = 0; q0 < R; q0 += 256) {
+    for (int q0 = 0; q0 < R; q0 += kPwT) {
         // (1) one lane per (entry, source row)
-        int len = 0, xa = 0, pe = 0, py = 0;
+        int len = 0, xa = 0, pe = 0, py = 0, etk = 0;
         const int q = q0 + tid;
         if (q < R) {
             int lo = 0, hi = E - 1;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_epre[mid] > q) hi = mid; else lo = mid + 1; }
             pe = lo;
             py = s_eylo[pe] + (q - (pe ? s_epre[pe - 1] : 0));
-            const int k = s_ek[pe];
+            etk = s_etk[pe];
+            const int k = (etk >> 16) - 2;
             const double m0 = s_m[pe][0], m1 = s_m[pe][1], m2 = s_m[pe][2], m3 = s_m[pe][3], m4 = s_m[pe][4], m5 = s_m[pe][5];
             const double fx_lo = (double)(tx0 + k * fd.obj_w) + fd.x_off - 0.5 - eps, fx_hi = (double)(tx1 - 1 + k * fd.obj_w) + fd.x_off + 0.5 + eps;
             const double fy_lo = (double)(ty0 - k) + fd.y_off - 0.5 - eps, fy_hi = (double)(ty1 - 1 - k) + fd.y_off + 0.5 + eps;
             const double yd = (double)py, cx = m2 * yd + m4, cy = m3 * yd + m5;
             const double a[4] = { m0, -m0, m1, -m1 }, b[4] = { cx - fx_lo, fx_hi - cx, cy - fy_lo, fy_hi - cy };
-            const int2 ext = *reinterpret_cast<const int2 *>(p.rowext + 2 * (s_ebase[pe] + py));     // this triangle's cells in map row py
+            const int2 ext = *reinterpret_cast<const int2 *>(p.rowext + 2 * ((long long)s_ebase[pe] + py));     // this triangle's cells in map row py
             double xlo = (double)(ext.x + p.min_src_x), xhi = (double)(ext.y + p.min_src_x);
             bool empty = ext.y < ext.x;
 #pragma unroll
@@ -441,44 +462,80 @@ __global__ __launch_bounds__(256) void k_fwd_pw_tiles(FwdPwTiles p, const uint8_
             }
             if (!empty && xlo <= xhi) { xa = (int)xlo; len = (int)xhi - xa + 1; }
         }
-        const int incl = block_scan_incl(len, s_wsum, lane, wave);      // (its first barrier also fences the previous pass's readers)
-        s_pe[tid] = pe; s_py[tid] = py; s_pxa[tid] = xa; s_ppre[tid] = incl;
-        __syncthreads();
-        const int C = s_ppre[255];
-        // (2) one lane per candidate source pixel
-        int r = 0;
+        const int nseg = (len + kPwSegW - 1) >> kPwSegLog2;
+        int S;
+        const int sp = block_scan_incl<kPwT / 64>(nseg, s_wsum, lane, wave, S) - nseg;    // (its first barrier also fences the previous pass's readers)
+        s_row[tid] = make_int4(xa, len, py, pe | ((etk & 0xffff) << 8) | ((etk >> 16) << 24));
 #pragma unroll 1
-        for (int c = tid; c < C; c += 256) {
-            while (s_ppre[r] <= c) r++;
-            const int x = s_pxa[r] + (c - (r ? s_ppre[r - 1] : 0)), y = s_py[r], e = s_pe[r];
-            const int t = s_et[e], k = s_ek[e];
-            const int64_t cell = (int64_t)(y - p.min_src_y) * p.map_w + (x - p.min_src_x);
-            if ((int)(int16_t)p.fmap[cell] != t) continue;                                  // :957: this pixel uses another triangle's matrix
-            const double m[6] = { s_m[e][0], s_m[e][1], s_m[e][2], s_m[e][3], s_m[e][4], s_m[e][5] };
-            double nx, ny;
-            apply_affine(m, (double)x, (double)y, nx, ny);                                  // :961
-            double uh = nx - (double)fd.x_off, vh = ny - (double)fd.y_off;                               // :962
-            int ui, vi;
-            round_x2(uh, vh, ui, vi);
-            if (!(fabs(uh) < 1.0e9 && fabs(vh) < 1.0e9)) continue;
-            const int col = ui - k * fd.obj_w, row = vi + k;
-            if (row >= ty0 && row < ty1 && col >= tx0 && col < tx1) atomicMax(&s_win[(row - ty0) * kFwdTileW + (col - tx0)], (int)cell);
+        for (int B = 0; B < S; B += kPwSegCap) {
+            for (int j = max(0, B - sp); j < nseg && sp + j - B < kPwSegCap; j++) s_seg[sp + j - B] = (uint32_t)tid | ((uint32_t)j << 9);
+            __syncthreads();
+            // (2) one lane per candidate source pixel, kPwUnroll of them in flight
+            const int C = min(S - B, kPwSegCap) << kPwSegLog2;
+#pragma unroll 1
+            for (int c0 = tid; c0 < C; c0 += kPwT * kPwUnroll) {
+                int xs[kPwUnroll], ys[kPwUnroll], ws[kPwUnroll], owner[kPwUnroll];
+#pragma unroll
+                for (int j = 0; j < kPwUnroll; j++) {
+                    const int c = c0 + kPwT * j;
+                    ws[j] = -1; xs[j] = 0; ys[j] = 0;
+                    if (c < C) {
+                        const uint32_t sg = s_seg[c >> kPwSegLog2];
+                        const int4 rr = s_row[sg & (kPwT - 1)];
+                        const int off = (int)(sg >> 9) * kPwSegW + (c & (kPwSegW - 1));
+                        if (off < rr.y) { xs[j] = rr.x + off; ys[j] = rr.z; ws[j] = rr.w; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kPwUnroll; j++)
+                    owner[j] = ws[j] >= 0 ? (int)(int16_t)p.fmap[(ys[j] - p.min_src_y) * p.map_w + (xs[j] - p.min_src_x)] : -1;     // (cell < 2^31: forward_limits)
+#pragma unroll
+                for (int j = 0; j < kPwUnroll; j++) {
+                    if (ws[j] < 0) continue;
+                    const int e = ws[j] & 0xff, t = (ws[j] >> 8) & 0xffff, k = (ws[j] >> 24) - 2;
+                    const double m0 = s_m[e][0], m1 = s_m[e][1], m2 = s_m[e][2], m3 = s_m[e][3], m4 = s_m[e][4], m5 = s_m[e][5];
+                    if (owner[j] != t) continue;                                                    // :957: this pixel uses another triangle's matrix
+                    const double m[6] = { m0, m1, m2, m3, m4, m5 };
+                    double nx, ny;
+                    apply_affine(m, (double)xs[j], (double)ys[j], nx, ny);                          // :961
+                    double uh = nx - (double)fd.x_off, vh = ny - (double)fd.y_off;                  // :962
+                    int ui, vi;
+                    round_x2(uh, vh, ui, vi);
+                    if (!(fabs(uh) < 1.0e9 && fabs(vh) < 1.0e9)) continue;
+                    const int col = ui - k * fd.obj_w, row = vi + k;
+                    // winner = the LAST source pixel in raster order == the largest (row, column) key; map_w <= 65535 (launcher)
+                    const uint32_t key = ((uint32_t)(ys[j] - p.min_src_y) << 16 | (uint32_t)(xs[j] - p.min_src_x)) + 1u;
+                    if (row >= ty0 && row < ty1 && col >= tx0 && col < tx1) atomicMax(&s_win[(row - ty0) * kFwdTileW + (col - tx0)], key);
+                }
+            }
+            __syncthreads();                                                                        // (s_seg / s_row are rewritten next)
         }
     }
     __syncthreads();
     const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(img);
     uint32_t *__restrict__ o32 = reinterpret_cast<uint32_t *>(out + fd.out_off);
     const int cxl = tid & (kFwdTileW - 1);
-    for (int cyl = tid >> 6; cyl < ty1 - ty0; cyl += 4) {
-        if (tx0 + cxl >= tx1) continue;
-        const int w = s_win[cyl * kFwdTileW + cxl];
-        uint32_t px = 0u;
-        if (w >= 0) {
-            const int my = w / p.map_w, mx = w - my * p.map_w;
+    if (tx0 + cxl >= tx1) return;
+    constexpr int kRowsPerStep = 4, kRowStride = kPwT / kFwdTileW;     // source reads of 4 tile rows in flight per lane
+#pragma unroll 1
+    for (int cy0 = tid / kFwdTileW; cy0 < ty1 - ty0; cy0 += kRowStride * kRowsPerStep) {
+        uint32_t px[kRowsPerStep];
+#pragma unroll
+        for (int j = 0; j < kRowsPerStep; j++) {
+            const int cyl = cy0 + kRowStride * j;
+            px[j] = 0u;
+            if (cyl >= ty1 - ty0) continue;
+            const uint32_t w = s_win[cyl * kFwdTileW + cxl];
+            if (w == 0u) continue;
+            const int my = (int)((w - 1u) >> 16), mx = (int)((w - 1u) & 0xffffu);
             const int64_t sidx = (int64_t)(my + p.min_src_y) * W + (mx + p.min_src_x);                    // :960
-            if (sidx >= 0 && sidx < (int64_t)W * H) px = img32[sidx];
+            if (sidx >= 0 && sidx < (int64_t)W * H) px[j] = img32[sidx];
         }
-        o32[(size_t)(ty0 + cyl) * fd.obj_w + tx0 + cxl] = px;
+#pragma unroll
+        for (int j = 0; j < kRowsPerStep; j++) {
+            const int cyl = cy0 + kRowStride * j;
+            if (cyl < ty1 - ty0) o32[(size_t)(ty0 + cyl) * fd.obj_w + tx0 + cxl] = px[j];
+        }
     }
 }
 
@@ -527,7 +584,7 @@ void launch_fwd_pw_tiles(const FwdPwTiles &p, int n_frames, int max_w, int max_h
 {
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     if (p.T > 0) hipLaunchKernelGGL(k_fwd_pw_bins, dim3((p.T + 3) / 4, n_frames), dim3(64, 4), 0, stream, p);
-    hipLaunchKernelGGL(k_fwd_pw_tiles, dim3(p.tsx, p.tsy, n_frames), dim3(256), 0, stream, p, img, W, H, out);
+    hipLaunchKernelGGL(k_fwd_pw_tiles, dim3(p.tsx, p.tsy, n_frames), dim3(kPwT), 0, stream, p, img, W, H, out);
 }
 
 void launch_fwd_pw(const int32_t *fmap, const float *fwd, const uint8_t *img, int W, int H, int min_src_x, int min_src_y, int map_w, int map_h,

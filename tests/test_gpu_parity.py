@@ -382,46 +382,55 @@ def test_forward_piecewise_tiles_match_scatter_and_oracle():
         c.close()
 
 
-def test_forward_piecewise_flagged_batch_settles_before_the_next_frame_set():
-    """A queued tile-binned forward batch whose frame the device flagged (tile lists over capacity) is redone from the context's
-    frame arrays, so the NEXT frame set (another forward batch, or an inverse one) must settle it first: both outputs == oracle
-    with no hg_sync between the two calls."""
+def test_forward_piecewise_flagged_batches_are_redone_from_their_own_frame_sets():
+    """Queued tile-binned forward batches whose frames the device flagged (tile lists over capacity) are redone by hg_sync from the
+    frame set each of them was given (staged copy), not from the context's current arrays: three batches with different points
+    queued with no hg_sync in between, then an inverse batch; a batch whose output buffer a later batch reused is not redone."""
     rng = np.random.default_rng(99)
     W = H = 512                                                  # 12 800 triangles: ~200 entries per tile against a first capacity of 64 -> FWD_OVERFLOW
     img = G.lcg_image(W, H, 4242)
     sp, tris = WL.grid_points(W, H, 80, 80), WL.grid_triangles(80, 80)
     ms = O.minmax_xy(sp)
     sets = []
-    for k in range(2):
+    for k in range(3):
         dp = (sp.reshape(-1, 2) * rng.uniform(0.8, 1.0, 2) + rng.uniform(-1.5, 1.5, (sp.size // 2, 2)) + 7 + 11 * k).astype(np.float32).ravel()
         md = O.minmax_xy(dp)
         sets.append((dp, (int(md[0]), int(md[1]), int(md[2] - md[0]), int(md[3] - md[1]))))
-    for second in ("forward", "inverse"):
+    want = [_fwd_pw_oracle(sp, dp, tris, img, g) for dp, g in sets]
+    for tail in ("forward", "inverse", "reuse"):
         c = HG.Context(0)
         try:
             c.set_image(img)
             c.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
             c.set_option("fwd_tiles", 1)
-            (dpa, ga), (dpb, gb) = sets
-            na, nb = ga[2] * ga[3] * 4, gb[2] * gb[3] * 4
-            d_a, d_b = c.alloc(na), c.alloc(nb)
+            nbytes = [g[2] * g[3] * 4 for _, g in sets]
+            bufs = [c.alloc(max(nbytes)) for _ in sets]
             try:
                 r0 = c.redone_frames()
-                c.warp_forward_piecewise_batch_device(dpa, int(ms[2]), int(ms[3]), [ga], [0], d_a)
-                assert c.last_forward_kernel() == 2
-                if second == "forward":
-                    c.warp_forward_piecewise_batch_device(dpb, int(ms[2]), int(ms[3]), [gb], [0], d_b)
-                else:
-                    c.piecewise_set_frames(dpb, [gb], [0])
-                    c.warp_inverse_piecewise_frames_device(d_b)
+                for k, (dp, g) in enumerate(sets):
+                    d = bufs[0] if tail == "reuse" else bufs[k]
+                    c.warp_forward_piecewise_batch_device(dp, int(ms[2]), int(ms[3]), [g], [0], d)
+                    assert c.last_forward_kernel() == 2
+                if tail == "inverse":
+                    c.piecewise_set_frames(sets[0][0], [sets[0][1]], [0])
+                    d_inv = c.alloc(nbytes[0])
+                    c.warp_inverse_piecewise_frames_device(d_inv)
+                    c.free(d_inv)
                 c.sync()
-                assert c.redone_frames() > r0
-                assert np.array_equal(c.to_host(d_a, na).reshape(ga[3], ga[2], 4), _fwd_pw_oracle(sp, dpa, tris, img, ga)), second
-                if second == "forward":
-                    assert np.array_equal(c.to_host(d_b, nb).reshape(gb[3], gb[2], 4), _fwd_pw_oracle(sp, dpb, tris, img, gb))
+                assert c.redone_frames() - r0 == (1 if tail == "reuse" else 3), (tail, c.redone_frames() - r0)
+                for k, (dp, g) in enumerate(sets):
+                    if tail == "reuse" and k != 2:
+                        continue
+                    d = bufs[0] if tail == "reuse" else bufs[k]
+                    assert np.array_equal(c.to_host(d, nbytes[k]).reshape(g[3], g[2], 4), want[k]), (tail, k)
+                # capacity grew at the sync: the next batch fits or flags again, and is right either way
+                dp, g = sets[1]
+                c.warp_forward_piecewise_batch_device(dp, int(ms[2]), int(ms[3]), [g], [0], bufs[1])
+                c.sync()
+                assert np.array_equal(c.to_host(bufs[1], nbytes[1]).reshape(g[3], g[2], 4), want[1]), tail
             finally:
-                c.free(d_a)
-                c.free(d_b)
+                for d in bufs:
+                    c.free(d)
         finally:
             c.close()
 

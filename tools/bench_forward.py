@@ -13,11 +13,13 @@ hg, wl = load("hgwarp", "hgwarp.py"), load("hg_workloads", "workloads.py")
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3840, 2160)
+ONLY = os.environ.get("FWD_ONLY", "")             # substring filter on the case name
 ctx = hg.Context(0)
 ctx.set_image(wl.lcg_image(W, H, 1))
 cases = {"affine rot 0.1 scale 1.0": (0, 0.1, 1.0, 0.0), "affine rot 0.6 scale 0.7": (0, 0.6, 0.7, 0.0), "affine rot -0.3 scale 1.5": (0, -0.3, 1.5, 0.0),
          "projective rot 0.1 persp 5e-5": (1, 0.1, 1.0, 5e-5)}
 for name, (kind, ang, s, g) in cases.items():
+    if ONLY not in name: continue
     mats, geoms = [], []
     for f in range(F):
         a = ang + 0.01 * f
@@ -53,6 +55,7 @@ for name, (kind, ang, s, g) in cases.items():
 # piecewise forward: the BASELINE C3 mesh (10 x 10 cells) and a dense one, shrunk to fit the source size
 for name, (gx, gy, A) in {"piecewise 10x10 grid": (10, 10, 40.0), "piecewise 32x18 grid": (32, 18, 16.0), "piecewise 48x27 grid": (48, 27, 10.0),
                           "piecewise 96x54 grid": (96, 54, 6.0)}.items():
+    if ONLY not in name: continue
     sp, tris = wl.grid_points(W, H, gx, gy), wl.grid_triangles(gx, gy)
     msx, msy = wl.src_min(sp)
     mm = hg.minmax_xy(sp)
