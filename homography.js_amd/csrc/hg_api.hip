@@ -109,6 +109,7 @@ struct hg_ctx {
     int opt_table = -1;                                        // 1: the table path whenever eligible; -1 / 0: row lists (the default, see run_setup)
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
     int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate
+    int opt_tri_group = -1;                                    // k_tri_spans_grouped: 16 / 64 triangles per workgroup, 0 never, -1 by mesh size
     int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
     int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
     // layout estimates of the last frame set, reused for the next set of the same shape (the kernels check the real counts)
@@ -383,6 +384,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
     else if (!std::strcmp(key, "table")) { c->opt_table = value; c->pw_table_disabled = false; }
     else if (!std::strcmp(key, "tri_threads")) c->opt_tri_threads = (value == 64 || value == 128 || value == 256) ? value : -1;
+    else if (!std::strcmp(key, "tri_group")) c->opt_tri_group = value < 0 ? -1 : (value >= 64 ? 64 : (value ? 16 : 0));
     else if (!std::strcmp(key, "rows1_threads")) c->opt_rows1_threads = (value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "col_split")) c->opt_col_split = (value == 1 || value == 2 || value == 4) ? value : -1;
     else if (!std::strcmp(key, "lds_pad")) c->opt_lds_pad = std::min(std::max(value, -1), 40);
@@ -1028,6 +1030,12 @@ static PwFrames frames_of(const hg_ctx *c)
     f.max_obj_h = mh;
     f.row_group = c->pw_row_group;
     f.tri_threads = c->pw_table ? (c->pw_tri_rows_max <= 64 ? 64 : 128) : c->pw_tri_threads;
+    // k_tri_spans_grouped where the per-workgroup solves of k_tri_spans dominate the producer (measured round 3, producer us, 64 frames of
+    // 4K unless noted, k_tri_spans -> grouped 16 -> 64): 512 triangles 89 -> 68 -> 68, 3200: 222 -> 151 -> 114, 4608: 342 -> 238 -> 169,
+    // C5 (8 frames of 5000) 80 -> 57 -> 57; but C3 (200 triangles of 216 rows) 47.7 -> 51.2 and C4 37.1 -> 38.7: their cost is the
+    // slot atomics, not the solves.  64 triangles per workgroup need >= ~1000 workgroups to fill the chip.
+    { const int64_t ft = (int64_t)c->pw_frames.size() * c->n_tris;
+      f.tri_group = c->opt_tri_group >= 0 ? c->opt_tri_group : ((c->n_tris >= 384 && ft >= 2048) ? (ft >= 65536 ? 64 : 16) : 0); }
     // Windows per phase, measured (C3 / C4, 64 frames): shared (cache-resident) source: 2, or 4 when a window holds
     // several spans (C4's face mesh ~4.5, C3 1.5: the longer span walk then overlaps four windows' gathers); one source per
     // frame (HBM-bound): 4 windows per phase AND fewer, deeper waves -- 12-16 KB of idle LDS per workgroup leave 5 of them on a

@@ -262,6 +262,110 @@ __global__ __launch_bounds__(256) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
 }
 
 
+// ------------------------------------------------------------------------------------------------ k_tri_spans_grouped (round 3)
+// The same spans into the same row lists, for frame sets with thousands of (frame, triangle) pairs.  In k_tri_spans every wave of
+// a triangle's workgroup repeats that triangle's solves -- 15 fp64 divisions, ~500 dependent instructions, 2000 clocks of a SIMD
+// whichever lanes are useful: at 128 threads per triangle that was 21 of the kernel's 42 us on C3 and all but a few of its
+// 66 us on C5 (40 000 triangles of ~150 rows).  Here a workgroup takes kTriGroup consecutive triangles of a frame: lanes
+// 0..15 of its first wave solve one triangle EACH (same 2000 clocks, 16 triangles), the results go through LDS, and then every
+// wave takes whole triangles (wave w: w, w + 8) with one lane per row as before, its triangle's records read from LDS as
+// wave-uniform values.  The 8 waves per workgroup keep ~6 waves per SIMD in flight on C3 for the returning slot atomics.
+constexpr int kTriGroupThreads = 512;
+
+template <class X, bool COMPACT, int kTriGroup>       // kTriGroup: 16, or 64 (a full wave of solves) for dense meshes
+__global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh mesh, PwFrames fr, RowLists rl)
+{
+    __shared__ Seg s_seg[kTriGroup][3];
+    __shared__ float s_inv[kTriGroup][8];
+    __shared__ long long s_rows[kTriGroup][2];                  // clamped row range [y_first, y_stop)
+    const int t0 = blockIdx.x * kTriGroup, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FrameDesc fd = fr.frames[f];
+    const int W = fd.obj_w;
+    const int64_t len = (int64_t)W * fd.obj_h;
+    if (tid < kTriGroup && t0 + tid < mesh.n_tris) {
+        const int t = t0 + tid;
+        const float *dp = fr.dst_pts + (size_t)f * mesh.n_pts * 2;
+        float s[6], d[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t v = mesh.tris[3 * (size_t)t + k];
+            if (v < (uint32_t)mesh.n_pts) {
+                s[2 * k] = mesh.src_pts[2 * (size_t)v]; s[2 * k + 1] = mesh.src_pts[2 * (size_t)v + 1];
+                d[2 * k] = dp[2 * (size_t)v];           d[2 * k + 1] = dp[2 * (size_t)v + 1];
+            } else {
+                s[2 * k] = s[2 * k + 1] = d[2 * k] = d[2 * k + 1] = NAN;
+            }
+        }
+        float fwd[6], inv[6];
+        if (X::tri_solve) { solve_affine(s, d, fwd); invert_affine(fwd, inv); }
+        else { for (int k = 0; k < 6; k++) { fwd[k] = d[k]; inv[k] = s[k]; } }
+        Seg seg[3];
+        define_seg(d[0], d[1], d[2], d[3], seg[0]);     // p0->p1
+        define_seg(d[0], d[1], d[4], d[5], seg[1]);     // p0->p2
+        define_seg(d[2], d[3], d[4], d[5], seg[2]);     // p1->p2
+        int32_t y_min, y_end;
+        tri_rows(d[1], d[3], d[5], y_min, y_end);
+        const size_t ft = (size_t)f * mesh.n_tris + t;
+#pragma unroll
+        for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];                                 // taps + inputs of the map path
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
+        fr.segs[ft * 3] = seg[0]; fr.segs[ft * 3 + 1] = seg[1]; fr.segs[ft * 3 + 2] = seg[2];
+        TriRange tr; tr.y_min = y_min; tr.y_end = y_end; tr.a = 0; tr.b = 0;
+        fr.trir[ft] = tr;
+        int64_t y_first = y_min, y_stop = y_end;
+        if (W > 0 && fd.obj_h > 0) clamp_rows(y_first, y_stop, fd.y_off, W, len);               // rows that cannot write a cell are skipped (hg_math.h)
+        else y_stop = y_first;
+        s_seg[tid][0] = seg[0]; s_seg[tid][1] = seg[1]; s_seg[tid][2] = seg[2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) s_inv[tid][k] = inv[k];
+        s_rows[tid][0] = y_first; s_rows[tid][1] = y_stop;
+    }
+    __syncthreads();
+    if (W <= 0 || fd.obj_h <= 0) return;
+    int32_t *__restrict__ rowcnt = rl.cnt + (size_t)f * rl.row_stride;
+    const size_t ent0 = (size_t)f * rl.row_stride * rl.cap;
+    const int nw = blockDim.x >> 6;
+#pragma unroll 1
+    for (int j = wave; j < kTriGroup && t0 + j < mesh.n_tris; j += nw) {
+        const int t = t0 + j;
+        Seg seg[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            seg[e].m = sgpr_f64(s_seg[j][e].m); seg[e].b = sgpr_f64(s_seg[j][e].b);
+            seg[e].minY = sgpr_f64(s_seg[j][e].minY); seg[e].maxY = sgpr_f64(s_seg[j][e].maxY);
+        }
+        float inv[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) inv[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_inv[j][k])));
+        const int64_t y_first = s_rows[j][0], y_stop = s_rows[j][1];
+        for (int64_t y = y_first + lane; y < y_stop; y += 64) {
+            int64_t k, fin;
+            span_cells(seg, (double)y, (double)fd.y_off, (double)W, len, k, fin);
+            if (k >= fin) continue;
+            // usual case: the span sits in output row (y - yOff) (+objH when it wrapped); otherwise divide
+            int64_t r = y - fd.y_off;
+            if (r < 0) r += fd.obj_h;
+            if (r < 0 || r >= fd.obj_h || k < r * W || k >= (r + 1) * W) r = k / W;
+            for (; r * W < fin; r++) {
+                const int64_t lo = (k > r * W ? k : r * W) - r * W, hi = (fin < (r + 1) * W ? fin : (r + 1) * W) - r * W;
+                const int slot = X::slot(&rowcnt[r], t, y);
+                if (slot < rl.cap && X::store_entries) {
+                    const size_t idx = ent0 + (size_t)r * rl.cap + slot;
+                    const uint32_t lh = (uint32_t)lo | ((uint32_t)hi << 16);
+                    if (COMPACT) static_cast<uint2 *>(rl.ent)[idx] = make_uint2(lh, (uint32_t)t);
+                    else {
+                        uint4 *dst = static_cast<uint4 *>(rl.ent) + 2 * idx;
+                        dst[0] = make_uint4(lh, (uint32_t)t, __float_as_uint(inv[0]), __float_as_uint(inv[1]));
+                        dst[1] = make_uint4(__float_as_uint(inv[2]), __float_as_uint(inv[3]), __float_as_uint(inv[4]), __float_as_uint(inv[5]));
+                    }
+                }
+            }
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------ k_tri_table (round 3)
 // The same work as k_tri_spans -- per (frame, triangle): solves, edge equations, one thread per source row y evaluating
 // predictXLimits + the two flat fill() indices exactly -- but the result is NOT filed under output rows.  Row y's cells
@@ -727,6 +831,18 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
 #ifdef HG_EXPERIMENTS
     if (launch_tri_spans_ablated(mesh, fr, rl, grid, block, stream)) return;      // experiments/hg_ablate.h
 #endif
+    if (fr.tri_group) {                                      // thousands of (frame, triangle) pairs: the solves of 16 triangles on 16 lanes
+        const int G = fr.tri_group >= 64 ? 64 : 16;
+        const dim3 ggrid((mesh.n_tris + G - 1) / G, fr.n_frames), gblock(kTriGroupThreads);
+        if (G == 64) {
+            if (rl.compact) hipLaunchKernelGGL((k_tri_spans_grouped<NoExperiment, true, 64>), ggrid, gblock, 0, stream, mesh, fr, rl);
+            else            hipLaunchKernelGGL((k_tri_spans_grouped<NoExperiment, false, 64>), ggrid, gblock, 0, stream, mesh, fr, rl);
+        } else {
+            if (rl.compact) hipLaunchKernelGGL((k_tri_spans_grouped<NoExperiment, true, 16>), ggrid, gblock, 0, stream, mesh, fr, rl);
+            else            hipLaunchKernelGGL((k_tri_spans_grouped<NoExperiment, false, 16>), ggrid, gblock, 0, stream, mesh, fr, rl);
+        }
+        return;
+    }
     if (rl.compact) hipLaunchKernelGGL((k_tri_spans<NoExperiment, true>), grid, block, 0, stream, mesh, fr, rl);
     else            hipLaunchKernelGGL((k_tri_spans<NoExperiment, false>), grid, block, 0, stream, mesh, fr, rl);
 }

@@ -61,6 +61,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t max_obj_h;              // max over frames (grid size)
     int32_t row_group;              // output rows per k_pw_rows workgroup: kRowGroup (sparse rows) or 1 (dense meshes)
     int32_t tri_threads;            // k_tri_spans workgroup size: 128, or 64 when the triangles are short (one row per thread)
+    int32_t tri_group;              // 16 / 64: k_tri_spans_grouped (that many triangles per workgroup, their solves one per lane) instead of k_tri_spans; 0: k_tri_spans
     int32_t phase;                  // k_pw_rows: windows whose gathers are issued before their stores (1, 2 or 4)
     int32_t xcc_rotate;             // 1: XCD x takes band (x + frame) mod XCCs instead of band x (uneven rows, or no source shared between frames)
     int32_t xcc_log2;               // log2 of the device's XCC count (8 on an unpartitioned MI355X): block id -> XCD row band

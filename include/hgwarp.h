@@ -290,6 +290,10 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
  *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
  *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;
+ *   "tri_group" (default -1 = by mesh size: meshes of >= 384 triangles in sets of >= 2048 (frame, triangle) pairs): 16 or 64 (any
+ *           other non-zero value = 16): the span producer takes that many triangles per workgroup and solves them one per lane
+ *           (k_tri_spans_grouped) instead of one triangle per workgroup whose waves all repeat its solves (k_tri_spans, the
+ *           lower-latency choice for a single frame and for sparse meshes); 0: never;
  *   "xcc_rotate" (default -1 = by estimate): 1: XCD x walks row band (x + frame) mod XCCs instead of band x -- even load where
  *           rows differ in cost or the frames share no source; 0: fixed bands (a shared source's band stays in that XCD's L2);
  *   "xcc" (default: hipDeviceAttributeNumberOfXccs of the device, 8 on an unpartitioned MI355X): number of XCCs the
