@@ -362,8 +362,8 @@ def test_forward_piecewise_tiles_match_scatter_and_oracle():
                 redone0 = c.redone_frames()
                 c.warp_forward_piecewise_batch_device(np.concatenate(frames), int(ms[2]), int(ms[3]), geoms, offs, d_b)
                 c.sync()
-                # (the policy keeps meshes with more than ~4 triangles per output tile on the scatter path)
-                assert c.last_forward_kernel() == (2 if gx == 10 else 1) and c.redone_frames() == redone0, (gx, c.last_forward_kernel(), c.redone_frames() - redone0)
+                # (the policy takes the tile kernels up to ~8 triangles per output tile: both meshes)
+                assert c.last_forward_kernel() == 2 and c.redone_frames() == redone0, (gx, c.last_forward_kernel(), c.redone_frames() - redone0)
                 if gx != 10:
                     c.set_option("fwd_tiles", 1)
                     c.warp_forward_piecewise_batch_device(np.concatenate(frames), int(ms[2]), int(ms[3]), geoms, offs, d_b)

@@ -21,3 +21,6 @@ python tools/profile_summary.py $o/default_trace > $o/default_trace/summary.txt 
 bash tools/r3_lat.sh > $o/latency.log 2>&1
 for s in 0.0 0.026 0.5; do timeout 120 tools/bin/calib_shape --slope $s --pad 12 >> $o/calib_shape.log 2>&1; done
 ls $o gpurun_out | head -40
+# forward warps: scatter + gather vs the tile kernels (4K batch of 8, single frames, 1080p batch of 8)
+{ python tools/bench_forward.py 8 30; python tools/bench_forward.py 1 40; python tools/bench_forward.py 8 30 1920 1080; } 2>/dev/null | grep "^{" > $o/forward.jsonl
+python tools/fmt_forward.py $o/forward.jsonl > $o/forward_tiles.txt
