@@ -1,0 +1,729 @@
+// hg_api_piecewise.hip -- the C ABI, part 3: _inversePiecewiseAffineWarp: mesh, frame sets (staging, layout estimate), the fused
+// path and its deferred redo, hg_sync, the taps.
+#include "hg_ctx.h"
+
+// ------------------------------------------------------------------------------------------------ piecewise affine
+// NaN is a legal (if useless) coordinate -- the reference then simply draws nothing for that triangle -- but magnitudes beyond
+// kMaxCoord (Infinity included) are refused: the row loops of the rasterisers are bounded under that assumption (hg_math.h).
+static bool coords_ok(const float *p, size_t n)
+{
+    for (size_t i = 0; i < n; i++) if (std::fabs((double)p[i]) > kMaxCoord) return false;      // (NaN compares false)
+    return true;
+}
+
+extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, const uint32_t *tris, int n_tris, int msx, int msy)
+{
+    HG_TRY(bind(c));
+    if (!src || n_pts <= 0 || n_tris < 0 || (!tris && n_tris > 0)) return fail(c, HG_ERR_INVALID, "hg_piecewise_set_mesh: bad arguments");
+    if (!coords_ok(src, (size_t)n_pts * 2))
+        return fail(c, HG_ERR_INVALID, "hg_piecewise_set_mesh: a source coordinate is infinite or beyond 2^24 in magnitude");
+    // bindings re-send the mesh on every warp (the reference keeps it cached, :742, :758): an identical mesh keeps the
+    // device copies and what was derived from them (the forward triangle map)
+    if (c->have_mesh && n_pts == c->n_pts && n_tris == c->n_tris && msx == c->min_src_x && msy == c->min_src_y &&
+        std::memcmp(src, c->h_src.data(), sizeof(float) * 2 * (size_t)n_pts) == 0 &&
+        (n_tris == 0 || std::memcmp(tris, c->h_tris.data(), sizeof(uint32_t) * 3 * (size_t)n_tris) == 0))
+        return HG_OK;
+    HG_TRY(hg_sync(c));
+    HG_TRY(ensure(c, c->d_src, c->src_cap, (size_t)n_pts * 2));
+    HG_TRY(ensure(c, c->d_tris, c->tris_cap, (size_t)std::max(n_tris, 1) * 3));
+    HIP_TRY(c, hipMemcpyAsync(c->d_src, src, sizeof(float) * 2 * n_pts, hipMemcpyHostToDevice, c->stream));
+    if (n_tris > 0) HIP_TRY(c, hipMemcpyAsync(c->d_tris, tris, sizeof(uint32_t) * 3 * n_tris, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_pts = n_pts; c->n_tris = n_tris; c->min_src_x = msx; c->min_src_y = msy;
+    c->h_tris.assign(tris, tris + (size_t)3 * n_tris);
+    c->h_src.assign(src, src + (size_t)2 * n_pts);
+    c->fmap_valid = false;
+    c->have_mesh = true;
+    c->mesh_gen++;
+    c->fwd_pw_tiles_disabled = false; c->fwd_pw_cap = 64;     // (learned on the previous mesh)
+    c->pw_frames.clear(); c->pw_setup_done = false;
+    return HG_OK;
+}
+
+// Largest number of triangles whose fillTriangle row range (:1113-1120) covers one output row, over the uploaded frames:
+// an estimate of the longest per-row span list, used ONLY to pick k_pw_rows' layout (4 rows per workgroup with 64 LDS
+// slots each, or 1 row with all 256); the kernel checks the real counts and is exact either way.
+static int max_row_cover(const hg_ctx *c, const float *dst, double *mean_tri_rows, int *max_group_tris, double *mean_shear, int *max_tri_rows, double *fill)
+{
+    double tallest = 0.0, band_worst = 1.0;
+    const int nb = 1 << c->xcc_log2;
+    std::vector<double> band((size_t)nb, 0.0);
+    int worst = 0, worst_group = 0;
+    double rows_total = 0.0, tris_total = 0.0, shear_total = 0.0, shear_n = 0.0;
+    std::vector<int> diff, tdiff, starts;
+    const int shear_stride = std::max(1, c->n_tris / 1024);
+    for (size_t f = 0; f < c->pw_frames.size(); f++) {
+        const FrameDesc &fd = c->pw_frames[f];
+        if (fd.obj_w <= 0 || fd.obj_h <= 0) continue;
+        const float *dp = dst + f * (size_t)c->n_pts * 2;
+        diff.assign((size_t)fd.obj_h + 2, 0);
+        starts.assign((size_t)fd.obj_h + 2, 0);
+        tdiff.assign((size_t)fd.obj_h + 2, 0);
+        for (int t = 0; t < c->n_tris; t++) {
+            double lo = INFINITY, hi = -INFINITY;
+            bool ok = true;
+            double sx[3], sy[3], dx[3], dy[3];
+            for (int k = 0; k < 3; k++) {
+                const uint32_t v = c->h_tris[3 * (size_t)t + k];
+                if (v >= (uint32_t)c->n_pts) { ok = false; break; }
+                const double y = dp[2 * (size_t)v + 1];
+                if (!(y == y)) { ok = false; break; }
+                lo = std::min(lo, y); hi = std::max(hi, y);
+                sx[k] = c->h_src[2 * (size_t)v]; sy[k] = c->h_src[2 * (size_t)v + 1]; dx[k] = dp[2 * (size_t)v]; dy[k] = y;
+            }
+            if (!ok) continue;
+            if (t % shear_stride == 0) {   // |d(source row) / d(output x)| of the triangle's inverse map (a sample is enough): how many source lines 64 consecutive output
+                // pixels spread over (plain doubles: an estimate, never used for pixels)
+                const double e1x = sx[1] - sx[0], e1y = sy[1] - sy[0], e2x = sx[2] - sx[0], e2y = sy[2] - sy[0];
+                const double f1x = dx[1] - dx[0], f1y = dy[1] - dy[0], f2x = dx[2] - dx[0], f2y = dy[2] - dy[0];
+                const double D = e1x * e2y - e2x * e1y;
+                const double a = (f1x * e2y - f2x * e1y) / D, cc = (e1x * f2x - e2x * f1x) / D;
+                const double b = (f1y * e2y - f2y * e1y) / D, d = (e1x * f2y - e2x * f1y) / D;
+                const double sh = std::fabs(b / (a * d - b * cc));
+                if (sh == sh && sh < 1e6) { shear_total += sh; shear_n += 1.0; }
+            }
+            // rows [trunc(minY), ceil(maxY)) - yOff, one more below for spans that spill over the row end (x-offset quirk)
+            const double a = std::max(std::trunc(lo) - fd.y_off, 0.0), b = std::min(std::ceil(hi) - fd.y_off + 1.0, (double)fd.obj_h);
+            if (!(a < b)) continue;
+            diff[(size_t)a] += 1; diff[(size_t)b] -= 1;
+            rows_total += b - a; tris_total += 1.0;
+            tallest = std::max(tallest, std::min(std::ceil(hi) - std::trunc(lo), 1.0e6));       // rows of fillTriangle's loop :1113-1120
+
+            // tighter, for the triangles-per-group estimate: a triangle has spans on the integer rows inside [minY, maxY]
+            // (:1179; triangles that only touch a row at a vertex between two integers do not count), plus the spill row when
+            // the window is offset in x
+            const double ta = std::max(std::ceil(lo) - fd.y_off, 0.0), tb = std::min(std::floor(hi) - fd.y_off + (fd.x_off != 0 ? 2.0 : 1.0), (double)fd.obj_h);
+            if (ta < tb) { tdiff[(size_t)ta] += 1; tdiff[(size_t)tb] -= 1; starts[(size_t)ta] += 1; }
+        }
+        int run = 0, trun = 0;
+        int group = 0;                                       // triangles with spans in the 4-row group the row belongs to
+        std::fill(band.begin(), band.end(), 0.0);
+        for (int r = 0; r < fd.obj_h; r++) {
+            run += diff[r];
+            trun += tdiff[r];
+            worst = std::max(worst, run);
+            band[(size_t)((int64_t)r * nb / fd.obj_h)] += 2.0 + run;          // a row's cost ~ a constant + its spans (layout heuristic only)
+            group = (r % kRowGroup == 0) ? trun : group + starts[r];
+            worst_group = std::max(worst_group, group);
+        }
+        double bsum = 0.0, bmax = 0.0;
+        for (double v : band) { bsum += v; bmax = std::max(bmax, v); }
+        if (bsum > 0) band_worst = std::max(band_worst, bmax * nb / bsum);
+    }
+    *mean_tri_rows = tris_total > 0 ? rows_total / tris_total : 0.0;
+    *max_group_tris = worst_group;
+    *mean_shear = shear_n > 0 ? shear_total / shear_n : 0.0;
+    *max_tri_rows = (int)tallest;
+    *fill = band_worst;                                      // heaviest XCD band / mean band, over the frames (1 = even rows)
+    return worst;
+}
+
+static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n);
+
+// Transactional wrapper: if validation, an allocation or an upload fails part-way, the context is left WITHOUT a frame set
+// (the next warp returns HG_ERR_STATE) rather than with n new host-side frames over device buffers sized for the old set.
+extern "C" int hg_piecewise_set_frames(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n)
+{
+    const int rc = pw_set_frames_impl(c, dst, geoms, offs, n);
+    if (rc != HG_OK && c) {
+        const std::string why = c->err;
+        (void)hg_sync(c);                                   // queued runs of the old set are settled against the old set
+        c->pw_frames.clear(); c->pw_setup_done = false; c->rows_clean = false;
+        c->err = why; g_err = why;
+    }
+    return rc;
+}
+
+static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n)
+{
+    HG_TRY(bind(c));
+    if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
+    if (!dst || !geoms || n <= 0) return fail(c, HG_ERR_INVALID, "hg_piecewise_set_frames: bad arguments");
+    if (!coords_ok(dst, (size_t)n * c->n_pts * 2))
+        return fail(c, HG_ERR_INVALID, "hg_piecewise_set_frames: a destiny coordinate is infinite or beyond 2^24 in magnitude "
+                                       "(the reference's fillTriangle row loop would run for that many rows, forever for Infinity)");
+    // Queued runs are NOT waited for: the uploads below are ordered behind them on the stream, and each of them keeps its own
+    // staged copy of the set it warped (deferred redo, hg_sync).  Only a staging slot that a queued run still refers to forces a
+    // settlement first (a caller that uploads 64 sets per run).
+    const size_t T = (size_t)std::max(c->n_tris, 1), F = (size_t)n;
+    const int slot = (c->stage_cur + 1) % (int)kStatusRing;
+    for (const hg_ctx::Pending &pd : c->pw_pending_out) if (pd.stage == slot) { HG_TRY(hg_sync(c)); break; }
+    for (const hg_ctx::FwdPending &pd : c->fwd_pending) if (pd.stage == slot) { HG_TRY(hg_sync(c)); break; }   // (their redo reads the staged set too)
+    std::vector<FrameDesc> fresh;
+    HG_TRY(fill_frames(c, fresh, geoms, offs, n));
+    HG_TRY(ensure(c, c->d_set, c->set_cap, sizeof(FrameDesc) * F + sizeof(float) * 2 * c->n_pts * F));
+    HG_TRY(ensure(c, c->d_trir, c->trir_cap, F * T));
+    HG_TRY(ensure(c, c->d_segs, c->segs_cap, F * T * 3));
+    HG_TRY(ensure(c, c->d_fwd, c->fwd_cap, F * T * 6));
+    HG_TRY(ensure(c, c->d_inv, c->inv_cap, F * T * kInvStride));
+    HG_TRY(ensure(c, c->d_status, c->status_cap, F));
+    if (F * kStatusRing > c->h_status_cap) {
+        HG_TRY(hg_sync(c));
+        if (c->h_status) HIP_TRY(c, hipHostFree(c->h_status));
+        c->h_status = nullptr; c->h_status_cap = 0;
+        void *q = nullptr;
+        HIP_TRY(c, hipHostMalloc(&q, sizeof(int32_t) * F * kStatusRing, hipHostMallocDefault));
+        c->h_status = static_cast<int32_t *>(q); c->h_status_cap = F * kStatusRing;
+    }
+    hg_ctx::Stage &st = c->stage[slot];
+    const size_t fd_bytes = sizeof(FrameDesc) * F, pt_bytes = sizeof(float) * 2 * c->n_pts * F;
+    if (fd_bytes + pt_bytes > st.cap) {
+        // (an older upload out of this slot may still be queued; no queued run refers to it -- checked above -- but the DMA does)
+        if (st.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(st.h)); st.h = nullptr; st.cap = 0; }
+        void *q = nullptr;
+        const size_t want = fd_bytes + pt_bytes + (fd_bytes + pt_bytes) / 4;
+        hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipHostMalloc (frame-set staging): ") + hipGetErrorString(e));
+        st.h = static_cast<uint8_t *>(q); st.cap = want;
+    }
+    std::memcpy(st.h, fresh.data(), fd_bytes);
+    std::memcpy(st.h + fd_bytes, dst, pt_bytes);
+    st.n = n; st.n_pts = c->n_pts;
+    static_assert(sizeof(FrameDesc) % 8 == 0, "the destiny points follow the frame records in the same block");
+    c->d_pw_frames = reinterpret_cast<FrameDesc *>(c->d_set); c->d_dst = reinterpret_cast<float *>(c->d_set + fd_bytes);
+    HIP_TRY(c, hipMemcpyAsync(c->d_set, st.h, fd_bytes + pt_bytes, hipMemcpyHostToDevice, c->stream));    // (one DMA: the staged block has the device layout)
+    c->pw_frames.swap(fresh);
+    c->stage_cur = slot;
+    double tri_rows = 0.0, shear = 0.0;
+    int group_tris = 0, max_w = 0, cover = 0, tall = 0;
+    double fill = 1.0;
+    int64_t total_px = 0;
+    for (const FrameDesc &d : c->pw_frames) { max_w = std::max(max_w, d.obj_w); if (d.obj_w > 0 && d.obj_h > 0) total_px += (int64_t)d.obj_w * d.obj_h; }
+    int max_h = 0;
+    for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) max_h = std::max(max_h, d.obj_h);
+    const bool quick = c->pw_quick_layout || (total_px < ((int64_t)4 << 20) && (int64_t)F * c->n_tris > 4096);
+    // The host walk over every triangle of every frame only picks kernel LAYOUTS (rows per workgroup, entry format, k_pw_patch);
+    // the kernels check the real counts and flag what does not fit.  A caller that uploads fresh points for the same mesh and
+    // the same window shape every step (the reference's loop, test/benchmark.js:107-110) therefore keeps the previous estimate:
+    // same frame count, same mesh, window extents within 1/16; re-walked every 256 sets and whenever a run had to be redone.
+    hg_ctx::LayoutKey key;
+    key.n = n; key.n_tris = c->n_tris; key.max_w = max_w; key.max_h = max_h; key.mesh_gen = c->mesh_gen; key.quick = quick;
+    const hg_ctx::LayoutKey &ok = c->layout_key;
+    const bool same_shape = ok.n == key.n && ok.n_tris == key.n_tris && ok.mesh_gen == key.mesh_gen && ok.quick == key.quick &&
+                            std::abs(ok.max_w - key.max_w) * 16 <= ok.max_w && std::abs(ok.max_h - key.max_h) * 16 <= ok.max_h &&
+                            c->layout_age < 256;
+    if (same_shape) {
+        cover = c->pw_cover; tri_rows = c->pw_tri_rows; group_tris = c->pw_group_tris; shear = c->pw_shear; tall = c->pw_tri_rows_max; fill = c->pw_fill;
+        c->layout_age++;
+    } else if (quick) {
+        // small frames of a dense mesh (the README's 400x400 / 23 000-triangle benchmark): walking every triangle on the host
+        // would cost more than the frame (and the forward paths, which only need the per-triangle solves, skip the walk); guess the row density from the triangle count (the span lists grow if it was low)
+        cover = (int)(2.5 * std::sqrt((double)c->n_tris));
+        group_tris = 1 << 30;                               // (no k_pw_patch without the real estimate)
+        tri_rows = 64.0;
+        tall = 0;                                           // (unknown: no table path without the walk)
+    } else {
+        cover = max_row_cover(c, dst, &tri_rows, &group_tris, &shear, &tall, &fill);
+        c->pw_layout_walks++;
+    }
+    if (!same_shape) { c->layout_key = key; c->layout_age = 0; }
+    c->pw_tri_rows = tri_rows; c->pw_group_tris = group_tris; c->pw_tri_rows_max = tall; c->pw_fill = fill;
+    c->pw_cover = cover;
+    c->pw_spans_per_window = max_w > 0 ? (double)cover * 256.0 / (double)max_w : 0.0;
+    c->pw_row_group = cover <= 56 ? kRowGroup : 1;
+    {   // few rows in total (a single 4K frame has 560 four-row groups for 256 CUs): one row per workgroup fills the chip better
+        int64_t groups = 0;
+        for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + kRowGroup - 1) / kRowGroup;
+        if (groups < c->opt_min_row_groups) c->pw_row_group = 1;
+    }
+    // dense rows that still fit the patch kernel's LDS budget, sheared enough for 2-D gather patches to pay.  Measured
+    // (k_pw_rows one row per workgroup -> k_pw_patch): C5, shear 0.39, cover 190: 0.63 -> 0.50 ms; 4K 60x60 grid, 0.15, 148:
+    // 0.58 -> 0.50; 40x40, 0.16, 98: 0.47 -> 0.45; 32x32, 0.18, 92: 0.43 -> 0.42; but 24x24, 0.08, 60: 0.37 -> 0.38 and C5
+    // without its shear, 0.04, 150 (5 spans per 256-pixel window): 0.35 -> 0.37.  Regardless of shear it also wins when many
+    // narrow spans share a window (k_pw_rows tests every span of a window on all four pixels of every lane, k_pw_patch only
+    // the spans of the lane's 64-pixel bin): lens-distortion style 64x36 grid on 4K, shear 0.02, 8.5 spans per window:
+    // 0.73 -> 0.49 ms.  Layout choice only: the kernels check the real counts.
+    c->pw_patch = cover > 56 && cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW &&
+                  (int64_t)cover * 64 <= (int64_t)8 * max_w &&          // spans per 64-pixel bin ~ cover * 64 / width: overfull bins are slow
+                  (shear >= 0.1 || (int64_t)cover * 256 >= (int64_t)6 * max_w) && !c->pw_patch_disabled;
+    // one source per frame (decided at run time, hg_set_images_device may follow): k_pw_patch whenever the frame set fits it, see patch_preferred()
+    {
+        int64_t groups = 0;
+        for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + kRowGroup - 1) / kRowGroup;
+        c->pw_patch_fits = cover <= kPatchMaxRowSpans && group_tris <= kPatchMaxGroupTris && max_w <= kPatchMaxW && max_w >= 256 &&
+                           (int64_t)cover * 64 <= (int64_t)8 * max_w && groups >= c->opt_min_row_groups && !c->pw_patch_disabled;
+    }
+    c->pw_shear = shear;
+    // beyond that budget, up to ~480 spans per row: the same kernel without matrix records in LDS (pixels read them from global)
+    c->pw_patch_dense = !c->pw_patch && cover > kPatchMaxRowSpans && cover <= kPatchMaxRowSpansDense && max_w <= kPatchMaxW &&
+                        (int64_t)cover * 64 <= (int64_t)8 * max_w && !c->pw_patch_disabled;
+    if (c->pw_patch_dense) c->pw_patch = true;
+    // k_tri_spans: one thread per triangle row and round.  Measured round 3 (step ms, 64 / 128 / 256 threads): C5 (~150 rows per
+    // triangle, 8 frames) 0.475 / 0.463 / 0.489, C3 (~300 rows, 64 frames) 0.612 / 0.589 / 0.603; a single 4K frame 25.4 / 23.4 / 22.6 us
+    c->pw_tri_threads = tri_rows <= 96.0 ? 64 : ((int64_t)F * c->n_tris <= 2048 && tri_rows > 128.0 ? 256 : 128);
+    if (c->opt_tri_threads > 0) c->pw_tri_threads = c->opt_tri_threads;
+    if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
+    if (cover > 200 && c->row_cap < kRowSpanCapDense) c->row_cap = kRowSpanCapDense;
+    // (the row counters and the status ring are reused as they are when their layout -- frame count, rows per frame, list
+    //  capacity, entry format -- is that of the previous set: run_setup())
+    c->pw_setup_done = false;
+    return HG_OK;
+}
+
+extern "C" int hg_piecewise_prepare(hg_ctx *c, const float *dst, hg_geom geom)
+{
+    const size_t zero = 0;
+    return hg_piecewise_set_frames(c, dst, &geom, &zero, 1);
+}
+
+PwMesh mesh_of(const hg_ctx *c)
+{
+    PwMesh m;
+    m.src_pts = c->d_src; m.tris = c->d_tris; m.n_pts = c->n_pts; m.n_tris = c->n_tris;
+    m.min_src_x = c->min_src_x; m.min_src_y = c->min_src_y; m.img = c->d_img; m.W = c->W; m.H = c->H;
+    m.n_imgs = c->n_imgs; m.img_stride = c->img_stride;
+    return m;
+}
+
+PwFrames frames_of(const hg_ctx *c)
+{
+    PwFrames f;
+    f.frames = c->d_pw_frames; f.dst_pts = c->d_dst; f.trir = c->d_trir; f.segs = c->d_segs; f.fwd = c->d_fwd; f.inv = c->d_inv;
+    f.status = c->status_ptr ? c->status_ptr : c->d_status; f.n_frames = (int)c->pw_frames.size();
+    int mh = 0;
+    for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
+    f.max_obj_h = mh;
+    f.row_group = c->pw_row_group;
+    f.tri_threads = c->pw_table ? (c->pw_tri_rows_max <= 64 ? 64 : 128) : c->pw_tri_threads;
+    // k_tri_spans_grouped where the per-workgroup solves of k_tri_spans dominate the producer (measured round 3, producer us, 64 frames of
+    // 4K unless noted, k_tri_spans -> grouped 16 -> 64): 512 triangles 89 -> 68 -> 68, 3200: 222 -> 151 -> 114, 4608: 342 -> 238 -> 169,
+    // C5 (8 frames of 5000) 80 -> 57 -> 57; but C3 (200 triangles of 216 rows) 47.7 -> 51.2 and C4 37.1 -> 38.7: their cost is the
+    // slot atomics, not the solves.  64 triangles per workgroup need >= ~1000 workgroups to fill the chip.
+    { const int64_t ft = (int64_t)c->pw_frames.size() * c->n_tris;
+      f.tri_group = c->opt_tri_group >= 0 ? c->opt_tri_group : ((c->n_tris >= 384 && ft >= 2048) ? (ft >= 65536 ? 64 : 16) : 0); }
+    // Windows per phase, measured (C3 / C4, 64 frames): shared (cache-resident) source: 2, or 4 when a window holds
+    // several spans (C4's face mesh ~4.5, C3 1.5: the longer span walk then overlaps four windows' gathers); one source per
+    // frame (HBM-bound): 4 windows per phase AND fewer, deeper waves -- 12-16 KB of idle LDS per workgroup leave 5 of them on a
+    // CU instead of 7 (round 3, same box: C3 0.934 -> 0.910 ms, C4 0.406 -> 0.371), where k_pw_patch does not take the frame set anyway.
+    // XCD bands: fixed per XCD when every frame reads the same source and the mesh fills its window (the band's source rows then
+    // stay in that XCD's L2 from frame to frame), rotating with the frame otherwise (even load; measured in hg_k_piecewise.hip)
+    f.xcc_rotate = c->opt_xcc_rotate >= 0 ? (c->opt_xcc_rotate != 0) : (c->n_imgs > 1 || c->pw_fill > 1.08);
+    f.xcc_log2 = c->xcc_log2; f.no_hi_bounds = c->opt_hi_bounds ? 0 : 1;
+    f.sgpr_cap = c->opt_sgpr_cap >= 0 ? (c->opt_sgpr_cap != 0) : (c->n_imgs <= 1);
+    f.lds_pad_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : (c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0);
+    f.lds_pad_patch_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : 0;
+    {   // small frame sets: split every row group's windows over 2 or 4 workgroups until the launch has ~4000 of them
+        int64_t groups = 0;
+        const int rg = c->pw_row_group == kRowGroup ? kRowGroup : 1;
+        for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + rg - 1) / rg;
+        f.col_split = c->opt_col_split > 0 ? c->opt_col_split : 1;
+        f.rows1_threads = c->opt_rows1_threads > 0 ? c->opt_rows1_threads : 256;
+        (void)groups;
+    }
+    f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
+    f.patch_blocks = c->opt_phase > 0 ? c->opt_phase : 8;    // (k_pw_patch: measured best in both source layouts, hg_k_patch.hip)
+    return f;
+}
+
+static RowLists rows_of(const hg_ctx *c)
+{
+    RowLists r;
+    r.ent = c->d_rowent; r.cap = c->row_cap; r.compact = c->pw_compact ? 1 : 0;
+    int mh = 0;
+    for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
+    r.row_stride = std::max(mh, 1);
+    const size_t set = c->pw_frames.size() * (size_t)r.row_stride;           // two counter sets, then the status ring
+    r.cnt = c->d_rowcnt ? c->d_rowcnt + (size_t)c->rows_parity * set : nullptr;
+    r.cnt_clear = c->d_rowcnt ? c->d_rowcnt + (size_t)(1 - c->rows_parity) * set : nullptr;
+    return r;
+}
+
+// Would the next fused warp of this frame set go through k_pw_patch (the parity tap, which passes a map, never does)?
+static bool patch_preferred(const hg_ctx *c, bool *global_records)
+{
+#ifdef HG_EXPERIMENTS
+    static const int env_force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;    // experiments build only: 0 = never, 1 = whenever allowed by size
+#else
+    constexpr int env_force = -1;                            // the shipped library reads no environment variable
+#endif
+    const int force = c->opt_patch >= 0 ? c->opt_patch : env_force;
+    int mw = 0;
+    for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
+    if (global_records) *global_records = force == 2 ? true : (force == 1 ? false : c->pw_patch_dense);
+    // by estimate (dense, sheared rows), and -- measured round 3 -- whenever every frame streams its own source from HBM and the
+    // set fits the kernel: its 16 x 4 gather patches and 8-byte lists beat k_pw_rows there even on sparse meshes (same box, one
+    // source per frame: C4 0.371 -> 0.330 ms, C3 step 0.973 -> 0.947)
+    return c->pw_fast && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force >= 1 : (c->pw_patch || (c->n_imgs > 1 && c->pw_patch_fits)));
+}
+
+// per-frame solves; status words are reset first.  Fast path: k_tri_spans (solves + per-row span lists);
+// general path (more than 32767 triangles, huge sources, negative source minimum): k_tri_setup.
+static int run_setup(hg_ctx *c)
+{
+    const size_t F = c->pw_frames.size();
+    int mw = 0;
+    for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
+    c->pw_fast = pw_fast_ok(mesh_of(c), mw);
+    if (c->pw_fast) {
+        // entry format of the span lists (hg_kernels.h): 8 bytes for dense rows and whenever k_pw_patch will read them
+        const bool compact = patch_preferred(c, nullptr) || c->pw_cover > 56;
+        if (compact != c->pw_compact) { c->pw_compact = compact; c->rows_clean = false; }
+        // Table path (k_tri_table -> k_pw_rows<TBL>), option "table" = 1 only: sparse meshes -- where the row lists would carry
+        // 32-byte entries -- whose triangles a workgroup can afford to scan (every 4-row group tests all of them); the tallest
+        // triangle sizes the table.  Layout choice only: what does not fit (a taller triangle, more spans per row than a packed
+        // block holds) flags its frame.  NOT the default: measured round 3 (same box, 64 frames): the producer gets faster (C3
+        // k_tri_spans 42 -> k_tri_table 35 us; without its table stores 22) but the consumer's prologue -- scan, candidate list,
+        // two more barriers -- costs more than that (C3 warp kernel 583 -> 604 us, C4 244 -> 249, F = 1 step 23.4 -> 24.9 us).
+        const size_t T = (size_t)std::max(c->n_tris, 1);
+        c->pw_table = !compact && !c->pw_table_disabled && c->opt_table == 1 && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 &&
+                      c->pw_tri_rows_max > 0 && c->pw_tri_rows_max <= 8192 && (c->pw_row_group == 1 || c->pw_cover <= 56);
+        if (c->pw_table) {
+            const int want = ((c->pw_tri_rows_max + 8 + 15) / 16) * 16 << c->pw_table_grown;
+            if (want > c->tbl_stride) c->tbl_stride = want;
+            if (F * T * (size_t)c->tbl_stride > ((size_t)1 << 28)) c->pw_table = false;          // (2 GiB of table: not this path)
+        }
+        if (c->pw_table) HG_TRY(ensure(c, c->d_tbl, c->tbl_cap, F * T * (size_t)c->tbl_stride));
+        RowLists rl = rows_of(c);
+        // Two sets of row counters (ping-pong) + kStatusRing sets of per-frame status words share one allocation.  It is zeroed by a
+        // memset only when the layout changes (or after a setup whose warp never ran): the warp kernel of a step zeroes the OTHER
+        // counter set -- the one the previous step consumed, the one the next step counts into -- and the next status set.
+        const int32_t *before = c->d_rowcnt;
+        const size_t ent_bytes = c->pw_table ? 0 : F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt));
+        if (2 * F * rl.row_stride + kStatusRing * F > c->rowcnt_cap || ent_bytes > c->rowent_cap) HG_TRY(hg_sync(c));   // (queued runs flag into the old ring)
+        HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, 2 * F * rl.row_stride + kStatusRing * F));
+        HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, ent_bytes));
+        rl = rows_of(c);
+        if (before != c->d_rowcnt || c->rows_F != F || c->rows_stride != rl.row_stride || c->rows_cap != rl.cap) c->rows_clean = false;
+        c->rows_F = F; c->rows_stride = rl.row_stride; c->rows_cap = rl.cap;
+        if (c->rows_clean) { c->status_slot = (c->status_slot + 1) % (int)kStatusRing; c->rows_parity ^= 1; }
+        else {
+            HG_TRY(hg_sync(c));                              // (queued runs still own status sets)
+            c->status_slot = 0; c->rows_parity = 0;
+            HIP_TRY(c, hipMemsetAsync(c->d_rowcnt, 0, sizeof(int32_t) * (2 * F * rl.row_stride + kStatusRing * F), c->stream));
+        }
+        rl = rows_of(c);                                     // (parity settled)
+        c->status_base = c->d_rowcnt + 2 * F * rl.row_stride;
+        c->status_ptr = c->status_base + (size_t)c->status_slot * F;
+        c->status_next = c->status_base + (size_t)((c->status_slot + 1) % (int)kStatusRing) * F;
+        if (c->pw_table) {                                   // (the counters stay untouched: clean for whichever path runs next)
+            c->rows_clean = true;
+            TriTable tb; tb.ent = c->d_tbl; tb.stride = c->tbl_stride;
+            launch_tri_table(mesh_of(c), frames_of(c), tb, c->stream);
+        } else {
+            c->rows_clean = false;                           // dirty until the warp kernel has consumed them
+            launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
+        }
+    } else {
+        HG_TRY(hg_sync(c));                                  // (queued fast-path runs are settled against their own status ring first)
+        c->status_ptr = c->d_status;
+        HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * F, c->stream));
+        launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->pw_setup_done = true;
+    return HG_OK;
+}
+
+static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
+{
+    bool global_records = false;
+    const bool patch = patch_preferred(c, &global_records) && !map_out && c->pw_compact;
+    c->pw_used_patch = patch;
+    c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
+    if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
+    else if (c->pw_fast) {
+        TriTable tb; tb.ent = c->pw_table ? c->d_tbl : nullptr; tb.stride = c->tbl_stride;
+        launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), tb, d_out, map_out, c->status_next, c->stream); c->rows_clean = true;
+    }
+    else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
+}
+
+static int check_pw_state(hg_ctx *c)
+{
+    if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
+    if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
+    if (c->pw_frames.empty()) return fail(c, HG_ERR_STATE, "no frame prepared: call hg_piecewise_prepare / hg_piecewise_set_frames first");
+    return HG_OK;
+}
+
+// one frame through the materialised map (exact for any input)
+static int run_frame_via_map(hg_ctx *c, int f, uint8_t *d_out)
+{
+    const FrameDesc &fd = c->pw_frames[f];
+    const size_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h : 0;
+    if (n == 0) return HG_OK;
+    HG_TRY(ensure(c, c->d_map32, c->map32_cap, n));
+    PwMesh mesh = mesh_of(c);
+    mesh.img = frame_img(mesh, f); mesh.n_imgs = 1;          // this frame's own source
+    launch_map_build(mesh, frames_of(c), f, fd, c->d_map32, c->stream);
+    launch_pw_from_map(mesh, frames_of(c), f, fd, c->d_map32, d_out, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
+// Deferred redo: frame f of the staged set `stage` (the set a queued run warped; newer sets may have been uploaded since)
+// through the materialised map, into `d_out` at the frame's own offset.  Self-contained: the frame's window and points go from
+// the staging buffer to a one-frame scratch, k_tri_setup solves it there, then rasteriser + pixel loop.  Mesh and source
+// image are those of the context (changing either settles queued runs first).
+static int redo_frame_staged(hg_ctx *c, int stage, int f, uint8_t *d_out)
+{
+    const hg_ctx::Stage &st = c->stage[stage];
+    if (stage < 0 || !st.h || f >= st.n || st.n_pts != c->n_pts) return fail(c, HG_ERR_STATE, "deferred redo: the staged frame set is gone");
+    const FrameDesc fd = reinterpret_cast<const FrameDesc *>(st.h)[f];
+    const size_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h : 0;
+    if (n == 0) return HG_OK;
+    const size_t T = (size_t)std::max(c->n_tris, 1);
+    HG_TRY(ensure(c, c->d_redo_frame, c->redo_frame_cap, (size_t)1));
+    HG_TRY(ensure(c, c->d_redo_dst, c->redo_dst_cap, (size_t)c->n_pts * 2));
+    HG_TRY(ensure(c, c->d_redo_trir, c->redo_trir_cap, T));
+    HG_TRY(ensure(c, c->d_redo_segs, c->redo_segs_cap, T * 3));
+    HG_TRY(ensure(c, c->d_redo_fwd, c->redo_fwd_cap, T * 6));
+    HG_TRY(ensure(c, c->d_redo_inv, c->redo_inv_cap, T * kInvStride));
+    HG_TRY(ensure(c, c->d_redo_status, c->redo_status_cap, (size_t)1));
+    HG_TRY(ensure(c, c->d_map32, c->map32_cap, n));
+    const float *pts = reinterpret_cast<const float *>(st.h + sizeof(FrameDesc) * (size_t)st.n) + (size_t)f * c->n_pts * 2;
+    HIP_TRY(c, hipMemcpyAsync(c->d_redo_frame, st.h + sizeof(FrameDesc) * (size_t)f, sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_redo_dst, pts, sizeof(float) * 2 * c->n_pts, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_redo_status, 0, sizeof(int32_t), c->stream));
+    PwMesh mesh = mesh_of(c);
+    mesh.img = frame_img(mesh, f); mesh.n_imgs = 1;          // this frame's own source
+    PwFrames fr = frames_of(c);
+    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
+    fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
+    launch_tri_setup(mesh, fr, c->stream);
+    launch_map_build(mesh, fr, 0, fd, c->d_map32, c->stream);
+    launch_pw_from_map(mesh, fr, 0, fd, c->d_map32, d_out, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
+// The forward counterpart: frame f of the staged set through k_fwd_scatter_pw + k_fwd_gather with its own matrices (solved in the
+// one-frame scratch), over the context's forward map.
+int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int max_src_y, uint8_t *d_out)
+{
+    if (stage < 0 || !c->fmap_valid) return fail(c, HG_ERR_STATE, "deferred forward redo: the staged frame set is gone");
+    const hg_ctx::Stage &st = c->stage[stage];
+    if (!st.h || f >= st.n || st.n_pts != c->n_pts) return fail(c, HG_ERR_STATE, "deferred forward redo: the staged frame set is gone");
+    const FrameDesc fd = reinterpret_cast<const FrameDesc *>(st.h)[f];
+    const size_t n = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h : 0;
+    if (n == 0) return HG_OK;
+    const size_t T = (size_t)std::max(c->n_tris, 1);
+    HG_TRY(ensure(c, c->d_redo_frame, c->redo_frame_cap, (size_t)1));
+    HG_TRY(ensure(c, c->d_redo_dst, c->redo_dst_cap, (size_t)c->n_pts * 2));
+    HG_TRY(ensure(c, c->d_redo_trir, c->redo_trir_cap, T));
+    HG_TRY(ensure(c, c->d_redo_segs, c->redo_segs_cap, T * 3));
+    HG_TRY(ensure(c, c->d_redo_fwd, c->redo_fwd_cap, T * 6));
+    HG_TRY(ensure(c, c->d_redo_inv, c->redo_inv_cap, T * kInvStride));
+    HG_TRY(ensure(c, c->d_redo_status, c->redo_status_cap, (size_t)1));
+    HG_TRY(ensure(c, c->d_win32, c->win32_cap, n));
+    const float *pts = reinterpret_cast<const float *>(st.h + sizeof(FrameDesc) * (size_t)st.n) + (size_t)f * c->n_pts * 2;
+    HIP_TRY(c, hipMemcpyAsync(c->d_redo_frame, st.h + sizeof(FrameDesc) * (size_t)f, sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_redo_dst, pts, sizeof(float) * 2 * c->n_pts, hipMemcpyHostToDevice, c->stream));
+    PwFrames fr = frames_of(c);
+    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
+    fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
+    launch_tri_setup(mesh_of(c), fr, c->stream);
+    launch_fwd_pw(c->d_fmap, c->d_redo_fwd, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, max_src_x - c->min_src_x, max_src_y - c->min_src_y,
+                  fd, c->d_win32, d_out, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return HG_OK;
+}
+
+extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
+{
+    HG_TRY(bind(c));
+    if (!d_out) return fail(c, HG_ERR_INVALID, "d_out is NULL");
+    HG_TRY(check_pw_state(c));
+    if (c->pw_pending_out.size() >= kStatusRing - 1 || !c->fwd_pending.empty()) HG_TRY(hg_sync(c));
+    // The reference recomputes the per-triangle matrices on every setDestinyPoints and the map + inverses on every
+    // warp(): both are part of the per-frame step, so both run here every time.
+    HG_TRY(run_setup(c));
+    HG_TRY(time_begin(c));
+    run_warp(c, static_cast<uint8_t *>(d_out), nullptr);
+    HG_TRY(time_end(c));
+    HIP_TRY(c, hipGetLastError());
+    if (c->pw_fast) c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), c->status_slot, c->stage_cur});
+    else {                                                   // general path: one status set, checked right away
+        HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
+        c->status_base = nullptr;
+        c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), 0, c->stage_cur});
+        HG_TRY(hg_sync(c));
+    }
+    return HG_OK;
+}
+
+extern "C" int hg_sync(hg_ctx *c)
+{
+    HG_TRY(bind(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->pw_pending_out.empty()) {
+        // frames a fused run flagged (irregular, or a row list overflowed) are redone through the materialised map, into the
+        // output of the call that flagged them, in call order
+        std::vector<hg_ctx::Pending> pending;
+        pending.swap(c->pw_pending_out);
+        bool redo = false;
+        // (all queued runs share one layout of the status ring: a set with another frame count settles them before it runs)
+        const int st0 = pending.front().stage;
+        const size_t F = (st0 >= 0 && c->stage[st0].h) ? (size_t)c->stage[st0].n : c->pw_frames.size();
+        if (c->status_base) HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < pending.size(); i++) {
+            const hg_ctx::Pending &p = pending[i];
+            // a later queued run into the SAME output allocation has overwritten this run's frames already (a caller that reuses one
+            // buffer step after step): redoing them now would put stale frames over newer ones
+            bool superseded = false;
+            for (size_t j = i + 1; j < pending.size() && !superseded; j++) superseded = pending[j].out == p.out;
+            for (size_t f = 0; f < F; f++)
+                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) {
+                    redo = true; c->pw_redone++;
+                    if (!superseded) HG_TRY(redo_frame_staged(c, p.stage, (int)f, p.out));
+                }
+        }
+        if (redo) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->pw_used_patch) c->pw_patch_disabled = true;   // (its limits are tighter than k_pw_rows': do not pay the map path again)
+            if (c->pw_fast && c->row_cap < kRowSpanCapDense)      // denser mesh than assumed: larger lists next time
+                c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
+            c->layout_age = 1 << 30;                             // ... and a fresh layout estimate for the next frame set
+            if (c->pw_table) {                                   // the table path flagged: taller triangles than estimated (or denser rows): once more with twice the stride, then row lists
+                if (c->pw_table_grown >= 1) c->pw_table_disabled = true; else c->pw_table_grown++;
+            }
+        }
+    }
+    if (!c->fwd_pending.empty()) {
+        // tile-binned forward piecewise frames the device flagged (a triangle it could not bound, an overfull tile list): redone
+        // through scatter + gather into the output of the call that flagged them, from that call's staged frame set (newer sets
+        // may have been uploaded since).  The forward map is the context's: a new mesh settles queued runs first.
+        std::vector<hg_ctx::FwdPending> pending;
+        pending.swap(c->fwd_pending);
+        std::vector<int32_t> st(c->fwd_status_cap);
+        HIP_TRY(c, hipMemcpy(st.data(), c->d_fwd_status, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost));
+        bool overflow = false, unbounded = false, any = false;
+        for (size_t i = 0; i < pending.size(); i++) {
+            const hg_ctx::FwdPending &fp = pending[i];
+            bool superseded = false;                             // a later queued batch wrote the same output: its frames are the newer ones
+            for (size_t j = i + 1; j < pending.size(); j++) if (pending[j].out == fp.out) superseded = true;
+            const int32_t *sf = st.data() + (size_t)fp.slot * c->fwd_status_stride;
+            for (int f = 0; f < fp.n; f++) {
+                if (sf[f] == 0) continue;
+                any = true;
+                if (sf[f] & FWD_OVERFLOW) overflow = true;
+                if (sf[f] & FWD_FALLBACK) unbounded = true;
+                if (superseded) continue;
+                c->pw_redone++;
+                HG_TRY(redo_forward_frame_staged(c, fp.stage, f, fp.max_src_x, fp.max_src_y, fp.out));
+            }
+        }
+        if (any) {
+            HIP_TRY(c, hipMemsetAsync(c->d_fwd_status, 0, sizeof(int32_t) * c->fwd_status_cap, c->stream));   // (zero between calls)
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        if (overflow) {
+            if (c->fwd_pw_cap < kFwdPwCapMax) c->fwd_pw_cap = std::min(kFwdPwCapMax, c->fwd_pw_cap * 2);
+            else c->fwd_pw_tiles_disabled = true;
+        }
+        if (unbounded) c->fwd_pw_tiles_disabled = true;      // (a degenerate triangle in this mesh: do not pay for both paths again)
+    }
+    const int d = c->deferred;
+    c->deferred = HG_OK;
+    return d;
+}
+
+extern "C" int hg_warp_inverse_piecewise_batch_device(hg_ctx *c, const float *dst, const hg_geom *geoms, const size_t *offs, int n, void *d_out)
+{
+    HG_TRY(hg_piecewise_set_frames(c, dst, geoms, offs, n));
+    return hg_warp_inverse_piecewise_frames_device(c, d_out);
+}
+
+extern "C" int hg_warp_inverse_piecewise_device(hg_ctx *c, void *d_out) { return hg_warp_inverse_piecewise_frames_device(c, d_out); }
+
+static int single_frame_bytes(hg_ctx *c, size_t *bytes)
+{
+    HG_TRY(check_pw_state(c));
+    if (c->pw_frames.size() != 1) return fail(c, HG_ERR_STATE, "this call needs exactly one prepared frame (hg_piecewise_prepare)");
+    const FrameDesc &fd = c->pw_frames[0];
+    *bytes = (fd.obj_w > 0 && fd.obj_h > 0) ? (size_t)fd.obj_w * fd.obj_h * 4 : 0;
+    return HG_OK;
+}
+
+extern "C" int hg_warp_inverse_piecewise(hg_ctx *c, uint8_t *out_host)
+{
+    HG_TRY(bind(c));
+    if (!out_host) return fail(c, HG_ERR_INVALID, "out is NULL");
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    if (bytes == 0) return HG_OK;
+    const uint64_t keep = c->pw_frames[0].out_off;
+    if (keep != 0) return fail(c, HG_ERR_STATE, "prepared frame has a non-zero output offset");
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
+    HG_TRY(hg_warp_inverse_piecewise_frames_device(c, c->d_out_tmp));
+    HG_TRY(hg_sync(c));
+    HIP_TRY(c, hipMemcpy(out_host, c->d_out_tmp, bytes, hipMemcpyDeviceToHost));
+    return HG_OK;
+}
+
+extern "C" int hg_warp_inverse_piecewise_via_map(hg_ctx *c, uint8_t *out_host)
+{
+    HG_TRY(bind(c));
+    if (!out_host) return fail(c, HG_ERR_INVALID, "out is NULL");
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    if (bytes == 0) return HG_OK;
+    HG_TRY(hg_sync(c));
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
+    HG_TRY(run_setup(c));
+    HG_TRY(run_frame_via_map(c, 0, c->d_out_tmp));
+    HIP_TRY(c, hipMemcpyAsync(out_host, c->d_out_tmp, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HG_OK;
+}
+
+extern "C" int hg_get_tri_map(hg_ctx *c, int16_t *out, size_t len)
+{
+    HG_TRY(bind(c));
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    const size_t n = bytes / 4;
+    if (!out || len != n) return fail(c, HG_ERR_INVALID, "hg_get_tri_map: len must be obj_w*obj_h");
+    if (n == 0) return HG_OK;
+    HG_TRY(hg_sync(c));
+    HG_TRY(run_setup(c));
+    HG_TRY(ensure(c, c->d_map32, c->map32_cap, n));
+    HG_TRY(ensure(c, c->d_map16, c->map16_cap, n));
+    launch_map_build(mesh_of(c), frames_of(c), 0, c->pw_frames[0], c->d_map32, c->stream);
+    launch_map_to_i16(c->d_map32, c->d_map16, n, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_map16, n * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HG_OK;
+}
+
+extern "C" int hg_get_tri_map_fused(hg_ctx *c, int16_t *out, size_t len)
+{
+    HG_TRY(bind(c));
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    const size_t n = bytes / 4;
+    if (!out || len != n) return fail(c, HG_ERR_INVALID, "hg_get_tri_map_fused: len must be obj_w*obj_h");
+    if (n == 0) return HG_OK;
+    HG_TRY(hg_sync(c));
+    HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
+    HG_TRY(ensure(c, c->d_map16, c->map16_cap, n));
+    HG_TRY(run_setup(c));
+    run_warp(c, c->d_out_tmp, c->d_map16);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_status[0] != FRAME_OK)
+        return fail(c, HG_ERR_STATE, c->h_status[0] & FRAME_IRREGULAR ? "frame is irregular: the fused path defers it to the map path"
+                                                                     : "a row overflowed the fused kernel's LDS span list");
+    HIP_TRY(c, hipMemcpy(out, c->d_map16, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return HG_OK;
+}
+
+extern "C" int hg_get_matrices(hg_ctx *c, float *fwd, float *inv)
+{
+    HG_TRY(bind(c));
+    size_t bytes = 0;
+    HG_TRY(single_frame_bytes(c, &bytes));
+    HG_TRY(hg_sync(c));
+    if (!c->pw_setup_done) HG_TRY(run_setup(c));
+    const size_t T = (size_t)c->n_tris;
+    if (T == 0) return HG_OK;
+    if (fwd) HIP_TRY(c, hipMemcpyAsync(fwd, c->d_fwd, sizeof(float) * 6 * T, hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> tmp;
+    if (inv) { tmp.resize(T * kInvStride); HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_inv, sizeof(float) * kInvStride * T, hipMemcpyDeviceToHost, c->stream)); }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (inv) for (size_t t = 0; t < T; t++) std::memcpy(inv + 6 * t, tmp.data() + kInvStride * t, sizeof(float) * 6);
+    return HG_OK;
+}
+

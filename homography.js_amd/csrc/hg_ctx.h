@@ -1,0 +1,213 @@
+// hg_ctx.h -- the context behind the C ABI of include/hgwarp.h and the helpers its translation units share
+// (hg_api.hip: library / context / buffers / host-side solves / source image; hg_api_geometric.hip; hg_api_piecewise.hip;
+// hg_api_forward.hip).  Internal: nothing here is exported.
+#pragma once
+#include "../../include/hgwarp.h"
+#include "hg_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hg;
+
+constexpr size_t kFwdStatusRing = 16;   // tile-binned forward piecewise batches that may be queued before their status words are checked
+constexpr size_t kStatusRing = 64;      // fused piecewise runs that may be queued before their status words are checked
+
+// ------------------------------------------------------------------------------------------------ errors
+extern thread_local std::string g_err;   // (hg_api.hip) message of the last failure on this thread, for calls without a context
+
+struct hg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int deferred = HG_OK;
+
+    // source image
+    uint8_t *d_img = nullptr; size_t img_cap = 0; bool img_aliased = false;
+    int W = 0, H = 0;
+    int n_imgs = 1; size_t img_stride = 0;                     // hg_set_images_device: frame f reads image f % n_imgs
+
+    // mesh (source side)
+    float *d_src = nullptr; size_t src_cap = 0;
+    uint32_t *d_tris = nullptr; size_t tris_cap = 0;
+    std::vector<uint32_t> h_tris;                              // host copies (row-density / shear estimates in hg_piecewise_set_frames)
+    std::vector<float> h_src;
+    int n_pts = 0, n_tris = 0, min_src_x = 0, min_src_y = 0;
+    bool have_mesh = false;
+
+    // piecewise frames
+    std::vector<FrameDesc> pw_frames;          // host copy
+    uint8_t *d_set = nullptr; size_t set_cap = 0;             // the frame set in ONE block: F frame records, then F x n_pts x 2 destiny floats (one upload)
+    FrameDesc *d_pw_frames = nullptr;                         // = d_set
+    float *d_dst = nullptr;                                   // = d_set + F * sizeof(FrameDesc)
+    TriRange *d_trir = nullptr; size_t trir_cap = 0;
+    Seg *d_segs = nullptr; size_t segs_cap = 0;
+    float *d_fwd = nullptr; size_t fwd_cap = 0;
+    float *d_inv = nullptr; size_t inv_cap = 0;
+    int32_t *d_status = nullptr; size_t status_cap = 0;
+    int32_t *status_ptr = nullptr;                             // where this frame set's status words live (d_status, or the tail of d_rowcnt)
+    int32_t *h_status = nullptr; size_t h_status_cap = 0;      // pinned
+    bool pw_setup_done = false;                                // the per-triangle solves ran for the uploaded frames
+    // fast path: per-output-row span lists
+    int32_t *d_rowcnt = nullptr; size_t rowcnt_cap = 0;
+    uint8_t *d_rowent = nullptr; size_t rowent_cap = 0;        // bytes
+    int pw_cover = 0;                                          // estimated longest per-row span list of the uploaded frames
+    bool pw_compact = false;                                   // span lists use 8-byte entries (dense rows / k_pw_patch), else 32-byte
+    int row_cap = 64;                                          // entries per row; grows (sticky) after an overflow
+    bool pw_fast = false;                                      // uploaded frames are eligible for k_tri_spans/k_pw_rows
+    bool rows_clean = false;                                   // span counters + the next status set were zeroed by the last k_pw_rows
+    int status_slot = 0;                                       // which of the kStatusRing status-word sets the current step uses
+    int32_t *status_base = nullptr, *status_next = nullptr;
+    int pw_row_group = kRowGroup;                              // output rows per k_pw_rows workgroup (4, or 1 for dense meshes)
+    int pw_tri_threads = 128;                                  // k_tri_spans workgroup size
+    bool pw_patch = false;                                     // dense mesh that fits k_pw_patch (4-row groups, 2-D gather patches)
+    bool pw_patch_fits = false;                                // ... the frame set is within k_pw_patch's limits (it may be preferred later: one source per frame)
+    double pw_fill = 1.0;                                      // heaviest XCD row band / mean band (span counts per row), 1 = even rows
+    int opt_xcc_rotate = -1;                                   // -1 by estimate, 0 / 1
+    double pw_shear = 0.0;                                     // mean |d(source row) / d(output x)| of the uploaded frames (layout heuristic)
+    bool pw_patch_dense = false;                               // ... only in its global-record variant (up to 511 spans per row)
+    bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
+    bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
+    int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
+    long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
+    int opt_min_row_groups = 1536, opt_patch = -1, opt_phase = -1, opt_geo_nw = 8;   // hg_set_option()
+    int xcc_log2 = 3;                                          // log2(XCCs of the device): hipDeviceAttributeNumberOfXccs at hg_create, option "xcc"
+    int opt_lds_pad = -1;                                       // KB of dynamic LDS padding per k_pw_rows workgroup (occupancy experiments)
+    int opt_sgpr_cap = -1;                                     // -1 auto (shared source), 0 never, 1 always: k_pw_rows_s80
+    int opt_hi_bounds = 1;                                     // 0: fp64 bounds compares instead of the high-dword form (hg_dev.h)
+    // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
+    // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
+    struct Pending { uint8_t *out; int slot; int stage; };     // stage: which staged frame set (points + windows) the run warped
+    std::vector<Pending> pw_pending_out;
+    // Frame sets arrive through a ring of page-locked staging buffers (FrameDesc[F], then the F x n_pts x 2 destination
+    // points): hg_piecewise_set_frames copies the caller's arrays there and queues stream-ordered uploads -- it neither waits
+    // for the GPU nor keeps caller memory.  A staged set stays intact until every run that used it has been settled, so frames a
+    // fused run flagged can still be redone (through the materialised map) after newer sets were uploaded.
+    struct Stage { uint8_t *h = nullptr; size_t cap = 0; int n = 0, n_pts = 0; };
+    Stage stage[kStatusRing];
+    int stage_cur = -1;
+    // scratch of the deferred redo (one frame): its FrameDesc, points, solves
+    FrameDesc *d_redo_frame = nullptr; size_t redo_frame_cap = 0;
+    float *d_redo_dst = nullptr; size_t redo_dst_cap = 0;
+    TriRange *d_redo_trir = nullptr; size_t redo_trir_cap = 0;
+    Seg *d_redo_segs = nullptr; size_t redo_segs_cap = 0;
+    float *d_redo_fwd = nullptr; size_t redo_fwd_cap = 0;
+    float *d_redo_inv = nullptr; size_t redo_inv_cap = 0;
+    int32_t *d_redo_status = nullptr; size_t redo_status_cap = 0;
+    // layout of the row counters / status ring as of their last memset (a frame set with the same layout reuses them as they are)
+    size_t rows_F = 0; int rows_stride = 0, rows_cap = 0;
+    // table path (k_tri_table -> k_pw_rows<TBL>, hg_kernels.h): spans per (frame, triangle, source row), no row lists
+    int2 *d_tbl = nullptr; size_t tbl_cap = 0;
+    int tbl_stride = 0;                                        // entries per triangle (>= the tallest triangle of the frame set; doubles after an overflow)
+    int pw_tri_rows_max = 0;                                   // tallest triangle of the uploaded frames, in rows (host estimate)
+    bool pw_table = false;                                     // the current step uses the table path
+    bool pw_table_disabled = false;                            // it overflowed twice: row lists from now on
+    int pw_table_grown = 0;
+    int opt_table = -1;                                        // 1: the table path whenever eligible; -1 / 0: row lists (the default, see run_setup)
+    int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
+    int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate
+    int opt_tri_group = -1;                                    // k_tri_spans_grouped: 16 / 64 triangles per workgroup, 0 never, -1 by mesh size
+    int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
+    int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
+    // layout estimates of the last frame set, reused for the next set of the same shape (the kernels check the real counts)
+    struct LayoutKey { int n = -1, n_tris = -1, max_w = -1, max_h = -1; uint64_t mesh_gen = 0; bool quick = false; } layout_key;
+    uint64_t mesh_gen = 0; int layout_age = 0;
+    double pw_tri_rows = 0.0; int pw_group_tris = 0;
+    long pw_layout_walks = 0;                                  // host walks over the triangles (hg_layout_walks(): tests / bench)
+
+    // geometric frame sets arrive like the piecewise ones: copied into page-locked staging, uploaded stream-ordered, no GPU wait
+    // (nothing refers back to a staged geometric set, so a slot is simply reused once its own upload has completed)
+    struct GeoStage { uint8_t *h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+    GeoStage geo_stage[8];
+    int geo_stage_cur = -1;
+    // geometric frames
+    int geo_kind = 0;
+    bool geo_f32_exact = false;                                // affine matrices hold float values, |x| < 2^28
+    std::vector<FrameDesc> geo_frames;
+    FrameDesc *d_geo_frames = nullptr; size_t geo_frames_cap = 0;
+    double *d_mats = nullptr; size_t mats_cap = 0;
+    bool geo_from_points = false;                              // matrices are (re)solved on the device at every warp (hg_geometric_set_frames_points)
+    float *d_geo_pts = nullptr; size_t geo_pts_cap = 0;        // F x (from | to) point sets
+    int32_t *d_geo_plain = nullptr; size_t geo_plain_cap = 0;  // per-frame "plain division range" flags written by k_solve_frames
+
+    // scratch
+    int32_t *d_map32 = nullptr; size_t map32_cap = 0;
+    int32_t *d_fmap = nullptr; size_t fmap_cap = 0;            // forward (source-side) triangle map of the current mesh, kept across warps
+    bool fmap_valid = false; int fmap_w = 0, fmap_h = 0;
+    int32_t *d_win32 = nullptr; size_t win32_cap = 0;
+    uint8_t *d_fwd_par = nullptr; size_t fwd_par_cap = 0;      // k_fwd_tiles: FwdParam[n] then FrameDesc[n]
+    int32_t *d_fbbox = nullptr; size_t fbbox_cap = 0;          // forward piecewise tiles: per-matrix cell bbox of the forward map (valid with it)
+    uint32_t *d_frowoff = nullptr; size_t frowoff_cap = 0;     // ... offset of its per-row extents
+    int32_t *d_frowext = nullptr; size_t frowext_cap = 0;      // ... {min mx, max mx} per (matrix index, map row of its bbox)
+    bool fwd_rowext_ok = false;
+    int32_t *d_ftile_cnt = nullptr; size_t ftile_cnt_cap = 0;  // F x tiles counters (zero between calls)
+    int32_t *d_fwd_status = nullptr; size_t fwd_status_cap = 0, fwd_status_stride = 0;   // kFwdStatusRing sets of `stride` status words of tile-binned forward piecewise batches (zero between calls)
+    int32_t *d_ftile_ent = nullptr; size_t ftile_ent_cap = 0;  // F x tiles x fwd_pw_cap entries
+    double pw_spans_per_window = 0.0;                          // longest row's span count per 256-pixel window (layout heuristic)
+    bool pw_quick_layout = false;                              // set around the forward paths' hg_piecewise_set_frames calls
+    int fwd_pw_cap = 64;                                       // entries per tile (doubles after an overflow, up to kFwdPwCapMax)
+    bool fwd_pw_tiles_disabled = false;                        // overflowed at the largest capacity once: stay with the scatter path for this mesh
+    // queued tile-binned forward piecewise batches: status set `slot` of the forward status ring, frame set in staging slot `stage`
+    struct FwdPending { uint8_t *out = nullptr; int n = 0; int slot = 0; int stage = -1; int max_src_x = 0, max_src_y = 0; };
+    std::vector<FwdPending> fwd_pending;
+    int fwd_slot = 0;
+    int opt_fwd_tiles = -1;                                    // forward paths: -1 auto, 0 scatter + gather, 1 tiles whenever admissible
+    int fwd_last_kernel = 0;                                   // 1 scatter + gather, 2 k_fwd_tiles (hg_last_kernel-style tap for the tests)
+    int16_t *d_map16 = nullptr; size_t map16_cap = 0;
+    uint8_t *d_out_tmp = nullptr; size_t out_tmp_cap = 0;
+
+    // timing of the dominant kernel: a ring of event pairs recorded around each launch of it
+    static constexpr int kEvRing = 256;
+    bool timing = false;
+    hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
+    long ev_count = 0;                                         // launches recorded since timing was (re)enabled
+};
+
+inline int fail(hg_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail((c), HG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+#define HG_TRY(expr) do { int s_ = (expr); if (s_ != HG_OK) return s_; } while (0)
+
+template <typename T>
+inline int ensure(hg_ctx *c, T *&p, size_t &cap, size_t need)
+{
+    if (need <= cap) return HG_OK;
+    const size_t n = std::max(need, cap + cap / 2);          // geometric growth from the OLD capacity
+    if (p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(p)); p = nullptr; cap = 0; }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    p = static_cast<T *>(q); cap = n;
+    return HG_OK;
+}
+
+inline int bind(hg_ctx *c)
+{
+    if (!c) return fail(nullptr, HG_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return HG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ shared between the translation units
+int time_begin(hg_ctx *c);                                   // hg_api.hip: event pair around the dominant kernel (hg_set_timing)
+int time_end(hg_ctx *c);
+int fill_frames(hg_ctx *c, std::vector<FrameDesc> &v, const hg_geom *geoms, const size_t *offs, int n);      // hg_api.hip
+PwMesh mesh_of(const hg_ctx *c);                             // hg_api_piecewise.hip: kernel argument blocks of the current mesh / frame set
+PwFrames frames_of(const hg_ctx *c);
+int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int max_src_y, uint8_t *d_out);    // hg_api_piecewise.hip, beside its inverse twin

@@ -475,7 +475,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // (fr.xcc_rotate: the band an XCD takes rotates with the frame.  Where rows differ in cost -- C4's face mesh fills the middle
     //  bands and leaves the top and bottom ones nearly empty -- a fixed band per XCD hands the same XCD the expensive band of EVERY
     //  frame: C4 0.234 -> 0.220 ms.  Where they do not and the frames share one source, the fixed band is what keeps that band's
-    //  source rows in the XCD's L2 from frame to frame: C3 0.551 fixed, 0.607 rotating.  The host decides, hg_api.hip.)
+    //  source rows in the XCD's L2 from frame to frame: C3 0.551 fixed, 0.607 rotating.  The host decides, hg_api_piecewise.hip.)
     const int band = (xcd + (fr.xcc_rotate ? f : 0)) & ((1 << fr.xcc_log2) - 1);
     const int r0 = (band * groups_per_xcd + (bi - f * groups_per_xcd)) * rows_per_group;
     const FrameDesc fd = fr.frames[f];

@@ -138,7 +138,7 @@ void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double 
 // per set; kind 0 = affine closed form, 3 points per set.  mats = F x 8 doubles; plain[f] = 1 where the projective frame's
 // window stays in the plain division range (launch_geo then takes the per-frame flag instead of a host proof).
 void launch_solve_frames(int kind, const float *from, const float *to, const FrameDesc *frames, double *mats, int32_t *plain, int n, hipStream_t stream);
-// (f32_exact doubles as "plain division range proved" for kind 1: see geo_plain_division() in hg_api.hip)
+// (f32_exact doubles as "plain division range proved" for kind 1: see geo_plain_division() in hg_api_geometric.hip)
 // div2_plain vs IEEE division on `samples` pseudo-random operand triples; returns the number of mismatching quotients
 unsigned long long run_selftest_division(uint64_t seed, uint64_t samples, unsigned long long *d_counter, hipStream_t stream);
 
