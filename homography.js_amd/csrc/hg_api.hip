@@ -358,6 +358,30 @@ extern "C" int hg_set_images_device(hg_ctx *c, const void *d_rgba, int w, int h,
 }
 
 // ------------------------------------------------------------------------------------------------ frames helpers
+void output_layout(const std::vector<FrameDesc> &frames, size_t *extent, uint64_t *layout)
+{
+    size_t ext = 0;
+    uint64_t h = 1469598103934665603ull;                     // FNV-1a over (offset, bytes) of every frame with pixels
+    for (const FrameDesc &d : frames) {
+        if (d.obj_w <= 0 || d.obj_h <= 0) continue;
+        const uint64_t bytes = (uint64_t)d.obj_w * d.obj_h * 4, v[2] = { d.out_off, bytes };
+        ext = std::max(ext, (size_t)(d.out_off + bytes));
+        for (uint64_t x : v) for (int k = 0; k < 8; k++) { h ^= (x >> (8 * k)) & 0xff; h *= 1099511628211ull; }
+    }
+    *extent = ext; *layout = h ? h : 1;
+}
+
+int settle_output_conflicts(hg_ctx *c, const void *out, size_t extent, uint64_t layout)
+{
+    const uint8_t *lo = static_cast<const uint8_t *>(out), *hi = lo + extent;
+    bool conflict = false;
+    for (const hg_ctx::Pending &p : c->pw_pending_out)
+        if (p.out < hi && lo < p.out + p.extent && !(layout != 0 && p.out == lo && p.extent == extent && p.layout == layout)) conflict = true;
+    for (const hg_ctx::FwdPending &p : c->fwd_pending)
+        if (p.out < hi && lo < p.out + p.extent && !(layout != 0 && p.out == lo && p.extent == extent && p.layout == layout)) conflict = true;
+    return conflict ? hg_sync(c) : HG_OK;
+}
+
 int fill_frames(hg_ctx *c, std::vector<FrameDesc> &v, const hg_geom *geoms, const size_t *offs, int n)
 {
     if (n > 65535) return fail(c, HG_ERR_INVALID, "more than 65535 frames in one set (the frame index is a grid dimension)");

@@ -218,6 +218,9 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
     c->status_ptr = c->d_status;                             // (k_tri_setup only ORs flags into these words and nothing on the forward path reads them: not cleared)
     launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
     c->pw_setup_done = false;
+    size_t out_extent = 0;
+    uint64_t out_layout = 0;
+    output_layout(c->pw_frames, &out_extent, &out_layout);
     size_t max_px = 0;
     for (const FrameDesc &fd : c->pw_frames) if (fd.obj_w > 0 && fd.obj_h > 0) max_px = std::max(max_px, (size_t)fd.obj_w * fd.obj_h);
     if (max_px) {
@@ -261,11 +264,13 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
             HIP_TRY(c, hipGetLastError());
             { hg_ctx::FwdPending fp;
               fp.out = static_cast<uint8_t *>(d_out); fp.n = n; fp.slot = c->fwd_slot; fp.stage = c->stage_cur; fp.max_src_x = max_src_x; fp.max_src_y = max_src_y;
+              fp.extent = out_extent; fp.layout = out_layout;
               c->fwd_pending.push_back(fp); }
             c->fwd_last_kernel = 2;
             return HG_OK;
         }
         c->fwd_last_kernel = 1;
+        HG_TRY(settle_output_conflicts(c, d_out, out_extent, 0));      // (this path keeps no pending record: nothing queued may be redone over it later)
         HG_TRY(ensure(c, c->d_win32, c->win32_cap, max_px));
         for (int f = 0; f < n; f++)
             launch_fwd_pw(c->d_fmap, c->d_fwd + (size_t)f * c->n_tris * 6, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, (int)map_w, (int)map_h,

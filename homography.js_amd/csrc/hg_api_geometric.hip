@@ -124,6 +124,12 @@ extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
     if (c->geo_frames.empty()) return fail(c, HG_ERR_STATE, "no frames: call hg_geometric_set_frames first");
     int mw = 0, mh = 0;
     for (const FrameDesc &d : c->geo_frames) { mw = std::max(mw, d.obj_w); mh = std::max(mh, d.obj_h); }
+    if (!c->pw_pending_out.empty() || !c->fwd_pending.empty()) {     // a queued piecewise run's deferred redo must not land on these frames later
+        size_t extent = 0;
+        uint64_t layout = 0;
+        output_layout(c->geo_frames, &extent, &layout);
+        HG_TRY(settle_output_conflicts(c, d_out, extent, 0));
+    }
     // the reference re-solves the inverse matrix from the swapped point sets at the head of every warp (:994): so does the step
     if (c->geo_from_points)
         launch_solve_frames(c->geo_kind, c->d_geo_pts, c->d_geo_pts + c->geo_frames.size() * 8, c->d_geo_frames, c->d_mats, c->d_geo_plain,

@@ -525,6 +525,9 @@ extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
     if (!d_out) return fail(c, HG_ERR_INVALID, "d_out is NULL");
     HG_TRY(check_pw_state(c));
     if (c->pw_pending_out.size() >= kStatusRing - 1 || !c->fwd_pending.empty()) HG_TRY(hg_sync(c));
+    size_t extent = 0;
+    uint64_t layout = 0;
+    output_layout(c->pw_frames, &extent, &layout);           // (hg_sync orders the deferred redos of overlapping runs: replay_queued)
     // The reference recomputes the per-triangle matrices on every setDestinyPoints and the map + inverses on every
     // warp(): both are part of the per-frame step, so both run here every time.
     HG_TRY(run_setup(c));
@@ -532,12 +535,57 @@ extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
     run_warp(c, static_cast<uint8_t *>(d_out), nullptr);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
-    if (c->pw_fast) c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), c->status_slot, c->stage_cur});
+    if (c->pw_fast) c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), c->status_slot, c->stage_cur, extent, layout});
     else {                                                   // general path: one status set, checked right away
         HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
         c->status_base = nullptr;
-        c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), 0, c->stage_cur});
+        c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), 0, c->stage_cur, extent, layout});
         HG_TRY(hg_sync(c));
+    }
+    return HG_OK;
+}
+
+// ---- settling queued runs in call order (hg_sync)
+// The bytes frame f of a queued run wrote: from the run's staged frame set (the context's current one if the run had none).
+struct FrameRange { const uint8_t *lo, *hi; };
+static bool queued_frame_range(const hg_ctx *c, int stage, int f, const uint8_t *out, FrameRange *r)
+{
+    const FrameDesc *fd = nullptr;
+    if (stage >= 0 && c->stage[stage].h) { if (f < c->stage[stage].n) fd = reinterpret_cast<const FrameDesc *>(c->stage[stage].h) + f; }
+    else if (f < (int)c->pw_frames.size()) fd = &c->pw_frames[f];
+    if (!fd || fd->obj_w <= 0 || fd->obj_h <= 0) return false;
+    r->lo = out + fd->out_off; r->hi = r->lo + (size_t)fd->obj_w * fd->obj_h * 4;
+    return true;
+}
+
+// Sequential semantics for deferred redos: runs are visited in call order; a frame is redone if the device flagged it, or if it
+// overlaps bytes an EARLIER run's redo has just rewritten (that redo came after this frame's fast-path write, so the frame is put
+// back on top of it) -- unless a LATER queued run wrote exactly the same byte range (a caller reusing one buffer with one layout:
+// the later frame is the newer one, the older redo is skipped).  n_frames(i), flagged(i, f), redo(i, f) describe the list.
+template <class P, class NF, class Flagged, class Redo>
+static int replay_queued(hg_ctx *c, const std::vector<P> &pending, NF n_frames, Flagged flagged, Redo redo)
+{
+    std::vector<FrameRange> dirty;
+    for (size_t i = 0; i < pending.size(); i++) {
+        const P &p = pending[i];
+        for (int f = 0; f < n_frames(i); f++) {
+            FrameRange r;
+            if (!queued_frame_range(c, p.stage, f, p.out, &r)) continue;
+            bool again = flagged(i, f);
+            for (size_t d = 0; d < dirty.size() && !again; d++) again = dirty[d].lo < r.hi && r.lo < dirty[d].hi;
+            if (!again) continue;
+            bool superseded = false;
+            for (size_t j = i + 1; j < pending.size() && !superseded; j++) {
+                const P &q = pending[j];
+                if (q.out == p.out && q.extent == p.extent && q.layout == p.layout) { superseded = true; break; }     // same buffer, same layout
+                FrameRange w;
+                for (int g = 0; g < n_frames(j) && !superseded; g++)
+                    superseded = queued_frame_range(c, q.stage, g, q.out, &w) && w.lo == r.lo && w.hi == r.hi;
+            }
+            if (superseded) continue;
+            HG_TRY(redo(i, f));
+            dirty.push_back(r);
+        }
     }
     return HG_OK;
 }
@@ -556,18 +604,13 @@ extern "C" int hg_sync(hg_ctx *c)
         const int st0 = pending.front().stage;
         const size_t F = (st0 >= 0 && c->stage[st0].h) ? (size_t)c->stage[st0].n : c->pw_frames.size();
         if (c->status_base) HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < pending.size(); i++) {
-            const hg_ctx::Pending &p = pending[i];
-            // a later queued run into the SAME output allocation has overwritten this run's frames already (a caller that reuses one
-            // buffer step after step): redoing them now would put stale frames over newer ones
-            bool superseded = false;
-            for (size_t j = i + 1; j < pending.size() && !superseded; j++) superseded = pending[j].out == p.out;
+        for (size_t i = 0; i < pending.size(); i++)
             for (size_t f = 0; f < F; f++)
-                if (c->h_status[(size_t)p.slot * F + f] != FRAME_OK) {
-                    redo = true; c->pw_redone++;
-                    if (!superseded) HG_TRY(redo_frame_staged(c, p.stage, (int)f, p.out));
-                }
-        }
+                if (c->h_status[(size_t)pending[i].slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; }
+        if (redo)
+            HG_TRY(replay_queued(c, pending, [&](size_t) { return (int)F; },
+                                 [&](size_t i, int f) { return c->h_status[(size_t)pending[i].slot * F + f] != FRAME_OK; },
+                                 [&](size_t i, int f) { return redo_frame_staged(c, pending[i].stage, f, pending[i].out); }));
         if (redo) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->pw_used_patch) c->pw_patch_disabled = true;   // (its limits are tighter than k_pw_rows': do not pay the map path again)
@@ -588,21 +631,20 @@ extern "C" int hg_sync(hg_ctx *c)
         std::vector<int32_t> st(c->fwd_status_cap);
         HIP_TRY(c, hipMemcpy(st.data(), c->d_fwd_status, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost));
         bool overflow = false, unbounded = false, any = false;
-        for (size_t i = 0; i < pending.size(); i++) {
-            const hg_ctx::FwdPending &fp = pending[i];
-            bool superseded = false;                             // a later queued batch wrote the same output: its frames are the newer ones
-            for (size_t j = i + 1; j < pending.size(); j++) if (pending[j].out == fp.out) superseded = true;
+        for (const hg_ctx::FwdPending &fp : pending) {
             const int32_t *sf = st.data() + (size_t)fp.slot * c->fwd_status_stride;
             for (int f = 0; f < fp.n; f++) {
                 if (sf[f] == 0) continue;
                 any = true;
                 if (sf[f] & FWD_OVERFLOW) overflow = true;
                 if (sf[f] & FWD_FALLBACK) unbounded = true;
-                if (superseded) continue;
-                c->pw_redone++;
-                HG_TRY(redo_forward_frame_staged(c, fp.stage, f, fp.max_src_x, fp.max_src_y, fp.out));
             }
         }
+        if (any)
+            HG_TRY(replay_queued(c, pending, [&](size_t i) { return pending[i].n; },
+                                 [&](size_t i, int f) { return st[(size_t)pending[i].slot * c->fwd_status_stride + f] != 0; },
+                                 [&](size_t i, int f) { c->pw_redone++;
+                                                        return redo_forward_frame_staged(c, pending[i].stage, f, pending[i].max_src_x, pending[i].max_src_y, pending[i].out); }));
         if (any) {
             HIP_TRY(c, hipMemsetAsync(c->d_fwd_status, 0, sizeof(int32_t) * c->fwd_status_cap, c->stream));   // (zero between calls)
             HIP_TRY(c, hipStreamSynchronize(c->stream));

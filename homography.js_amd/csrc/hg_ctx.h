@@ -82,7 +82,10 @@ struct hg_ctx {
     int opt_hi_bounds = 1;                                     // 0: fp64 bounds compares instead of the high-dword form (hg_dev.h)
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
-    struct Pending { uint8_t *out; int slot; int stage; };     // stage: which staged frame set (points + windows) the run warped
+    // stage: which staged frame set (points + windows) the run warped; extent / layout: the bytes it writes from `out` on and a hash of
+    // its frames' (offset, size) list -- a later call into the SAME layout supersedes its deferred redos frame by frame, any other
+    // overlapping writer settles it first (settle_output_conflicts)
+    struct Pending { uint8_t *out; int slot; int stage; size_t extent; uint64_t layout; };
     std::vector<Pending> pw_pending_out;
     // Frame sets arrive through a ring of page-locked staging buffers (FrameDesc[F], then the F x n_pts x 2 destination
     // points): hg_piecewise_set_frames copies the caller's arrays there and queues stream-ordered uploads -- it neither waits
@@ -153,7 +156,7 @@ struct hg_ctx {
     int fwd_pw_cap = 64;                                       // entries per tile (doubles after an overflow, up to kFwdPwCapMax)
     bool fwd_pw_tiles_disabled = false;                        // overflowed at the largest capacity once: stay with the scatter path for this mesh
     // queued tile-binned forward piecewise batches: status set `slot` of the forward status ring, frame set in staging slot `stage`
-    struct FwdPending { uint8_t *out = nullptr; int n = 0; int slot = 0; int stage = -1; int max_src_x = 0, max_src_y = 0; };
+    struct FwdPending { uint8_t *out = nullptr; int n = 0; int slot = 0; int stage = -1; int max_src_x = 0, max_src_y = 0; size_t extent = 0; uint64_t layout = 0; };
     std::vector<FwdPending> fwd_pending;
     int fwd_slot = 0;
     int opt_fwd_tiles = -1;                                    // forward paths: -1 auto, 0 scatter + gather, 1 tiles whenever admissible
@@ -208,6 +211,12 @@ inline int bind(hg_ctx *c)
 int time_begin(hg_ctx *c);                                   // hg_api.hip: event pair around the dominant kernel (hg_set_timing)
 int time_end(hg_ctx *c);
 int fill_frames(hg_ctx *c, std::vector<FrameDesc> &v, const hg_geom *geoms, const size_t *offs, int n);      // hg_api.hip
+// The bytes a frame list writes from its output pointer on, and a hash of its (offset, size) pairs (0 is never returned).
+void output_layout(const std::vector<FrameDesc> &frames, size_t *extent, uint64_t *layout);                  // hg_api.hip
+// Before a call writes [out, out + extent): queued runs whose deferred redo could land on those bytes later are settled now, unless
+// the new call has the same base and layout (then hg_sync skips the older run's redo frame by frame: `superseded`).  layout = 0:
+// a writer that keeps no pending record (geometric warps, the scatter paths) -- any overlap settles.
+int settle_output_conflicts(hg_ctx *c, const void *out, size_t extent, uint64_t layout);                     // hg_api.hip
 PwMesh mesh_of(const hg_ctx *c);                             // hg_api_piecewise.hip: kernel argument blocks of the current mesh / frame set
 PwFrames frames_of(const hg_ctx *c);
 int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int max_src_y, uint8_t *d_out);    // hg_api_piecewise.hip, beside its inverse twin

@@ -1,6 +1,9 @@
 """GPU parity: the HIP path (through the C ABI) against (a) the golden vectors generated from the reference and
 (b) the CPU oracle on the same inputs.  Bar: bit-exact RGBA, bit-exact triangle-index map, bit-exact f32 matrices.
 Run with `pytest -m gpu` on an MI355X."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -385,7 +388,8 @@ def test_forward_piecewise_tiles_match_scatter_and_oracle():
 def test_forward_piecewise_flagged_batches_are_redone_from_their_own_frame_sets():
     """Queued tile-binned forward batches whose frames the device flagged (tile lists over capacity) are redone by hg_sync from the
     frame set each of them was given (staged copy), not from the context's current arrays: three batches with different points
-    queued with no hg_sync in between, then an inverse batch; a batch whose output buffer a later batch reused is not redone."""
+    queued with no hg_sync in between, then an inverse batch; batches into ONE buffer are redone in call order (different windows) or only
+    the last of them (the same window: the later frame supersedes the earlier one)."""
     rng = np.random.default_rng(99)
     W = H = 512                                                  # 12 800 triangles: ~200 entries per tile against a first capacity of 64 -> FWD_OVERFLOW
     img = G.lcg_image(W, H, 4242)
@@ -397,7 +401,7 @@ def test_forward_piecewise_flagged_batches_are_redone_from_their_own_frame_sets(
         md = O.minmax_xy(dp)
         sets.append((dp, (int(md[0]), int(md[1]), int(md[2] - md[0]), int(md[3] - md[1]))))
     want = [_fwd_pw_oracle(sp, dp, tris, img, g) for dp, g in sets]
-    for tail in ("forward", "inverse", "reuse"):
+    for tail in ("forward", "inverse", "reuse", "reuse_same"):
         c = HG.Context(0)
         try:
             c.set_image(img)
@@ -408,7 +412,9 @@ def test_forward_piecewise_flagged_batches_are_redone_from_their_own_frame_sets(
             try:
                 r0 = c.redone_frames()
                 for k, (dp, g) in enumerate(sets):
-                    d = bufs[0] if tail == "reuse" else bufs[k]
+                    d = bufs[0] if tail.startswith("reuse") else bufs[k]
+                    if tail == "reuse_same":
+                        dp, g = sets[2]                          # the same window three times: only the LAST call's frame is redone
                     c.warp_forward_piecewise_batch_device(dp, int(ms[2]), int(ms[3]), [g], [0], d)
                     assert c.last_forward_kernel() == 2
                 if tail == "inverse":
@@ -417,11 +423,12 @@ def test_forward_piecewise_flagged_batches_are_redone_from_their_own_frame_sets(
                     c.warp_inverse_piecewise_frames_device(d_inv)
                     c.free(d_inv)
                 c.sync()
-                assert c.redone_frames() - r0 == (1 if tail == "reuse" else 3), (tail, c.redone_frames() - r0)
+                # (different windows into one buffer: every flagged frame is redone, in call order -- the last one on top)
+                assert c.redone_frames() - r0 == (1 if tail == "reuse_same" else 3), (tail, c.redone_frames() - r0)
                 for k, (dp, g) in enumerate(sets):
-                    if tail == "reuse" and k != 2:
+                    if tail.startswith("reuse") and k != 2:
                         continue
-                    d = bufs[0] if tail == "reuse" else bufs[k]
+                    d = bufs[0] if tail.startswith("reuse") else bufs[k]
                     assert np.array_equal(c.to_host(d, nbytes[k]).reshape(g[3], g[2], 4), want[k]), (tail, k)
                 # capacity grew at the sync: the next batch fits or flags again, and is right either way
                 dp, g = sets[1]
@@ -433,6 +440,18 @@ def test_forward_piecewise_flagged_batches_are_redone_from_their_own_frame_sets(
                     c.free(d)
         finally:
             c.close()
+
+
+def test_sequence_fuzz_of_the_queueing_logic():
+    """tools/fuzz_seq.py: random sequences of inverse / forward piecewise batches, affine frames, option changes and syncs into a small
+    pool of reused output buffers, on meshes that make the device flag frames; after every sync each buffer == what the CPU oracle
+    gives for the last call that wrote each byte (deferred redos in call order, staged sets, status rings).  The first version of
+    this tool found a skipped redo when a later, SMALLER batch reused the buffer of a flagged one."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_seq.py"), "32", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatching buffers" in r.stdout and " 0 frames redone" not in r.stdout, r.stdout[-500:]
 
 
 def test_forward_scatter_batches_stay_on_the_device(ctx):
