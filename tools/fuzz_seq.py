@@ -85,6 +85,20 @@ for seq in range(n_seq):
                         print(f"MISMATCH seq {seq} kind {kind} op {op} buffer {k}: {d.size} bytes, first {d[:3]}", flush=True)
                         want[k] = got.copy()                 # (report once)
                 continue
+            if r < 0.24 and kind in (0, 2):                  # a new source image / a new mesh in the middle of the queue (both settle queued runs)
+                if rng.random() < 0.5:
+                    img = G.lcg_image(W, H, 7000 + seq * 16 + op)
+                    c.set_image(img)
+                else:
+                    nx, ny = int(rng.integers(1, 10)), int(rng.integers(1, 8))
+                    sp = WL.grid_points(W, H, nx, ny).reshape(-1, 2).astype(np.float64)
+                    tris = WL.grid_triangles(nx, ny)
+                    sp32 = sp.astype(np.float32).ravel()
+                    ms = O.minmax_xy(sp32)
+                    fmap_w, fmap_h = int(ms[2] - ms[0]), int(ms[3] - ms[1])
+                    fmap = O.build_tri_map(sp32, tris, fmap_w, int(ms[1]), fmap_w * fmap_h) if fmap_w > 0 and fmap_h > 0 else None
+                    c.piecewise_set_mesh(sp32, tris, int(ms[0]), int(ms[1]))
+                continue
             if r < 0.3:
                 c.set_option(str(rng.choice(["phase", "patch", "tri_group", "xcc_rotate", "table"])), int(rng.choice([-1, 0, 1, 2])))
                 continue
