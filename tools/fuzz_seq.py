@@ -63,6 +63,7 @@ for seq in range(n_seq):
     c = HG.Context(0)
     try:
         c.set_image(img)
+        imgs, d_srcs = [img], 0
         c.piecewise_set_mesh(sp32, tris, int(ms[0]), int(ms[1]))
         if kind == 3:
             c.set_option("fwd_tiles", 1)
@@ -86,9 +87,21 @@ for seq in range(n_seq):
                         want[k] = got.copy()                 # (report once)
                 continue
             if r < 0.24 and kind in (0, 2):                  # a new source image / a new mesh in the middle of the queue (both settle queued runs)
-                if rng.random() < 0.5:
-                    img = G.lcg_image(W, H, 7000 + seq * 16 + op)
+                u = rng.random()
+                if u < 0.3:
+                    imgs = [G.lcg_image(W, H, 7000 + seq * 16 + op)]
+                    img = imgs[0]
                     c.set_image(img)
+                elif u < 0.6:                                # one source per frame: frame f reads image f mod n_images
+                    imgs = [G.lcg_image(W, H, 9000 + seq * 16 + op + q) for q in range(int(rng.integers(2, 4)))]
+                    img = imgs[0]
+                    c.sync()
+                    if d_srcs:
+                        c.free(d_srcs)
+                    d_srcs = c.alloc(W * H * 4 * len(imgs))
+                    for q, im in enumerate(imgs):
+                        c.to_device(d_srcs, im, q * W * H * 4)
+                    c.set_images_device(d_srcs, W, H, len(imgs), W * H * 4)
                 else:
                     nx, ny = int(rng.integers(1, 10)), int(rng.integers(1, 8))
                     sp = WL.grid_points(W, H, nx, ny).reshape(-1, 2).astype(np.float64)
@@ -112,7 +125,7 @@ for seq in range(n_seq):
             if total > cap:
                 continue
             calls += 1
-            if r < 0.38:                                     # an affine frame (inverse geometric: no pending record of its own) into the same pool
+            if r < 0.38 and len(imgs) == 1:                  # an affine frame (inverse geometric: no pending record of its own) into the same pool
                 a = rng.uniform(-0.5, 0.5); sc = rng.uniform(0.6, 1.4)
                 m = np.array([np.cos(a) * sc, np.sin(a) * sc, -np.sin(a) * sc, np.cos(a) * sc, rng.uniform(-10, 30), rng.uniform(-10, 30), 0, 0], np.float64)
                 lim = O.transform_limits(0, m[:6], W, H)
@@ -123,11 +136,11 @@ for seq in range(n_seq):
                 c.warp_inverse_geometric_device(0, np.concatenate([inv, [0, 0]]), g, bufs[k])
                 want[k][:g[2] * g[3] * 4] = O.warp_inverse_geometric(0, np.concatenate([inv, [0, 0]]), img, *g).ravel()
                 continue
-            if r < 0.65 or fmap is None:                     # inverse batch
+            if r < 0.65 or fmap is None or len(imgs) > 1:    # inverse batch (the forward warps take one source image)
                 c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
                 c.warp_inverse_piecewise_frames_device(bufs[k])
                 for f, g in enumerate(geoms):
-                    w = O.warp_inverse_piecewise(sp32, frames[f], tris, img, int(ms[0]), int(ms[1]), *g)
+                    w = O.warp_inverse_piecewise(sp32, frames[f], tris, imgs[f % len(imgs)], int(ms[0]), int(ms[1]), *g)
                     want[k][offs[f]:offs[f] + g[2] * g[3] * 4] = w.ravel()
             else:                                            # forward batch
                 c.warp_forward_piecewise_batch_device(np.concatenate(frames), int(ms[2]), int(ms[3]), geoms, offs, bufs[k])
@@ -138,6 +151,8 @@ for seq in range(n_seq):
         redone += c.redone_frames()
         for b in bufs:
             c.free(b)
+        if d_srcs:
+            c.free(d_srcs)
     finally:
         c.close()
 print(f"sequence fuzz done: {n_seq} sequences, {calls} batches, {redone} frames redone, {bad} mismatching buffers", flush=True)
