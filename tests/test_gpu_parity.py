@@ -1158,6 +1158,37 @@ def test_far_away_and_absurd_vertices(ctx):
     assert np.array_equal(ctx.warp_inverse_piecewise(), O.warp_inverse_piecewise(sp, d3, tris, img, ms[0], ms[1], *geom))
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_multi_device_batch_with_flagged_frames(devices):
+    """hg_multi_* queues every device's D2H copies before it waits for any device; frames the fused path only flagged are redone by
+    that device's settlement afterwards and copied AGAIN.  A mesh whose rows always overflow the span lists (1100 thin triangles):
+    every frame takes that road, to host arrays and as resident frames, twice in a row (capacity policies change after a redo)."""
+    n, W2, H2, F = 1100, 2400, 8, 5
+    img = G.lcg_image(W2, H2, 10)
+    xs = np.linspace(0, W2, n + 1)
+    sp = np.stack([np.repeat(xs, 2), np.tile([0.0, H2], n + 1)], 1).astype(np.float32).ravel()
+    tris = np.array([[2 * i, 2 * i + 2, 2 * i + 1] for i in range(n)], np.uint32).ravel()
+    frames = []
+    for f in range(F):
+        d = sp.copy(); d[1::2] *= 1.2 + 0.2 * f; d[0::2] += 3.0 * f
+        frames.append(d)
+    geoms = [WL.piecewise_geom(d) for d in frames]
+    mm = O.minmax_xy(sp)
+    want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, int(mm[0]), int(mm[1]), *geoms[f]) for f in range(F)]
+    assert all(w.any() for w in want)
+    with HG.Multi(devices) as m:
+        m.set_image(img)
+        m.piecewise_set_mesh(sp, tris, int(mm[0]), int(mm[1]))
+        for rep in range(2):
+            outs = [np.zeros_like(w) for w in want]
+            m.warp_piecewise_batch(np.concatenate(frames), geoms, [o.ctypes.data for o in outs])
+            for f in range(F):
+                assert np.array_equal(outs[f], want[f]), ("host", rep, f)
+            m.warp_piecewise_batch(np.concatenate(frames), geoms)
+            for f in range(F):
+                assert np.array_equal(m.frame_to_host(f), want[f]), ("resident", rep, f)
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
 def test_multi_device_batch(devices):
     """hg_multi_*: the batch caller loop over a device list from one host thread.  [0] is the degenerate single-GPU case;
