@@ -182,6 +182,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "hi_bounds")) c->opt_hi_bounds = value != 0;
     else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
     else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
+    else if (!std::strcmp(key, "compact")) c->opt_compact = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "table")) { c->opt_table = value; c->pw_table_disabled = false; }
     else if (!std::strcmp(key, "tri_threads")) c->opt_tri_threads = (value == 64 || value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "tri_group")) c->opt_tri_group = value < 0 ? -1 : (value >= 64 ? 64 : (value ? 16 : 0));

@@ -356,7 +356,7 @@ static int run_setup(hg_ctx *c)
     c->pw_fast = pw_fast_ok(mesh_of(c), mw);
     if (c->pw_fast) {
         // entry format of the span lists (hg_kernels.h): 8 bytes for dense rows and whenever k_pw_patch will read them
-        const bool compact = patch_preferred(c, nullptr) || c->pw_cover > 56;
+        const bool compact = c->opt_compact >= 0 ? c->opt_compact != 0 : (patch_preferred(c, nullptr) || c->pw_cover > 56);
         if (compact != c->pw_compact) { c->pw_compact = compact; c->rows_clean = false; }
         // Table path (k_tri_table -> k_pw_rows<TBL>), option "table" = 1 only: sparse meshes -- where the row lists would carry
         // 32-byte entries -- whose triangles a workgroup can afford to scan (every 4-row group tests all of them); the tallest

@@ -69,6 +69,7 @@ struct hg_ctx {
     bool pw_patch_fits = false;                                // ... the frame set is within k_pw_patch's limits (it may be preferred later: one source per frame)
     double pw_fill = 1.0;                                      // heaviest XCD row band / mean band (span counts per row), 1 = even rows
     int opt_xcc_rotate = -1;                                   // -1 by estimate, 0 / 1
+    int opt_compact = -1;                                      // span-list entry format: 1 = 8-byte entries, 0 = 32-byte entries with the matrix, -1 by estimate
     double pw_shear = 0.0;                                     // mean |d(source row) / d(output x)| of the uploaded frames (layout heuristic)
     bool pw_patch_dense = false;                               // ... only in its global-record variant (up to 511 spans per row)
     bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows

@@ -290,6 +290,8 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
  *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
  *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;
+ *   "compact" (default -1 = by estimate: dense rows, or whenever k_pw_patch reads the lists): 1 / 0: 8-byte span-list entries (the
+ *           consumer fetches the matrix by triangle id) / 32-byte entries carrying the matrix;
  *   "tri_group" (default -1 = by mesh size: meshes of >= 384 triangles in sets of >= 2048 (frame, triangle) pairs): 16 or 64 (any
  *           other non-zero value = 16): the span producer takes that many triangles per workgroup and solves them one per lane
  *           (k_tri_spans_grouped) instead of one triangle per workgroup whose waves all repeat its solves (k_tri_spans, the

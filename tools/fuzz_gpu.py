@@ -30,6 +30,7 @@ for t in range(trials):
     ctx.set_option("table", int(rng.choice([-1, 1, 0])))
     ctx.set_option("xcc_rotate", int(rng.choice([-1, 0, 1])))
     ctx.set_option("tri_group", int(rng.choice([-1, 0, 16, 64])))
+    ctx.set_option("compact", int(rng.choice([-1, -1, 0, 1])))
     ctx.set_option("xcc", int(rng.choice([8, 8, 1, 2, 4, 16])))
     nx, ny = int(rng.integers(1, 24)), int(rng.integers(1, 16))
     if mode == 6:
