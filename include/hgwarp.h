@@ -67,7 +67,11 @@ const char *hg_last_error(const hg_ctx *ctx);
  * Also settles queued piecewise runs: hg_warp_inverse_piecewise_frames_device calls are queued back to back (up to 63
  * before the library syncs by itself); a frame whose mesh is denser than the fast path's row lists (or whose spans are
  * irregular) is only flagged by the kernel and is redone here, through the materialised map, into the output buffer of
- * the call that flagged it.  A frame is final once hg_sync (or any synchronous call) has returned. */
+ * the call that flagged it (from the frame set that call was given: a staged copy, newer sets may have gone up since).  Queued
+ * calls that wrote overlapping bytes are settled in call order: a later call's frame goes back on top of an earlier call's redo,
+ * and an earlier redo is skipped when a later call wrote exactly the same byte range (one buffer reused step after step).  The
+ * same holds for queued hg_warp_forward_piecewise_batch_device calls (tile lists over capacity, triangles the tiles cannot bound).
+ * A frame is final once hg_sync (or any synchronous call) has returned. */
 int hg_sync(hg_ctx *ctx);
 /* Device scratch/output helpers so that bindings without a device allocator (Node) can keep frames resident. */
 int hg_device_alloc(hg_ctx *ctx, size_t bytes, void **dptr);
