@@ -40,7 +40,9 @@ def main():
             geoms = [wl.piecewise_geom(d) for d in frames]
             msx, msy = wl.src_min(sp)
         offs, total = hg.pack_offsets(geoms)
-        out = torch.empty(total, dtype=torch.uint8, device=dev)
+        shift = int(os.environ.get("OUT_SHIFT", "0"))     # output base moved by this many bytes inside a larger allocation (placement experiments)
+        out_alloc = torch.empty(total + shift, dtype=torch.uint8, device=dev)
+        out = out_alloc[shift:]
         ref = None
         for src in sources:
             for combo in itertools.product(*knobs.values()):
@@ -48,8 +50,12 @@ def main():
                 ctx = hg.Context(0, stream=stream.cuda_stream)
                 for k, v in zip(knobs, combo): ctx.set_option(k, v)
                 if src == "distinct":
-                    if srcs is None: srcs = img.unsqueeze(0).repeat(F, 1, 1, 1)
-                    ctx.set_images_device(srcs.data_ptr(), W, H, F, W * H * 4)
+                    pad = int(os.environ.get("SRC_PAD", "0"))     # bytes between consecutive sources (HBM channel-mapping experiments)
+                    if srcs is None:
+                        flat = torch.empty(F * (W * H * 4 + pad), dtype=torch.uint8, device=dev)
+                        for f in range(F): flat[f * (W * H * 4 + pad): f * (W * H * 4 + pad) + W * H * 4] = img.reshape(-1)
+                        srcs = flat
+                    ctx.set_images_device(srcs.data_ptr(), W, H, F, W * H * 4 + pad)
                 else:
                     ctx.set_image_device(img.data_ptr(), W, H)
                 if proj:
