@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) output checks")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
+    ap.add_argument("--also", default="", help="further configs measured in the same invocation, e.g. C4:64,C5:8 (config:frames per GPU per step); "
+                                               "each is reported under \"also\" with the fields of the headline line")
     ap.add_argument("--launch-dry-run", action="store_true", help="print the torchrun command --gpus N would re-execute under, and exit")
     args = ap.parse_args()
 
@@ -164,8 +166,30 @@ def main():
 
     hg = _load("hgwarp", os.path.join(PKG, "hgwarp.py"))
     wl = _load("hg_workloads", os.path.join(PKG, "workloads.py"))
-    cfg = wl.CONFIGS[args.config]
-    W, H, F = cfg["W"], cfg["H"], args.frames
+    env = dict(torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank, dev=dev, n_devices=n_devices, hgdist=hgdist, hg=hg, wl=wl)
+    line, ok = measure(args, args.config, args.frames, env, primary=True)
+    # --also C4:64,C5:8: the other sharded configs of BASELINE.json in the SAME invocation (one multi-GPU lease yields every curve);
+    # each is a complete measurement (own context, own checks), attached under "also" with the same fields as the headline
+    for item in [a for a in (args.also or "").split(",") if a]:
+        name, _, fr = item.partition(":")
+        extra, ok_x = measure(args, name, int(fr) if fr else args.frames, env, primary=False)
+        ok = ok and ok_x
+        if rank == 0:
+            line.setdefault("also", []).append(extra)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if (ok or args.no_verify) else 3
+
+
+def measure(args, config, F, env, primary=True):
+    """One complete measurement of `config` with F frames per GPU per step: inputs -> HBM, timed regions, untimed checks, CPU baseline
+    (headline only).  Returns (the JSON line as a dict -- meaningful on rank 0 --, verified)."""
+    torch, dist, world, rank, local_rank, dev = env["torch"], env["dist"], env["world"], env["rank"], env["local_rank"], env["dev"]
+    n_devices, hgdist, hg, wl = env["n_devices"], env["hgdist"], env["hg"], env["wl"]
+    cfg = wl.CONFIGS[config]
+    W, H = cfg["W"], cfg["H"]
     do_shared, do_distinct = args.sources in ("both", "shared"), args.sources in ("both", "distinct")
 
     # ---------------------------------------------------------------- inputs -> HBM (untimed)
@@ -201,7 +225,7 @@ def main():
         offs, total = hg.pack_offsets(geoms)
         ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
         run_resident = ctx.warp_inverse_piecewise_frames_device
-        workload = (f"{args.config}: {W}x{H} RGBA piecewise-affine, {mesh_txt} "
+        workload = (f"{config}: {W}x{H} RGBA piecewise-affine, {mesh_txt} "
                     f"({tris.size // 3} triangles), {F} frames/GPU/step")
     else:
         s4 = wl.corners(W, H)
@@ -217,7 +241,7 @@ def main():
         ctx.geometric_set_frames_points(1, np.concatenate(d4s), np.tile(s4, F), geoms, offs)     # inverse: dst -> src (:994)
         solve_txt = ", 8x8 DLT solve per frame on the device inside the step"
         run_resident = ctx.warp_inverse_geometric_frames_device
-        workload = f"{args.config}: {W}x{H} RGBA projective, 4 corner points, {F} frames/GPU/step{solve_txt}"
+        workload = f"{config}: {W}x{H} RGBA projective, 4 corner points, {F} frames/GPU/step{solve_txt}"
 
     run = run_resident
     # --points fresh: a ring of R point sets (the config's own sequence shifted by k frames), one uploaded per timed step
@@ -336,13 +360,20 @@ def main():
     kernel_name = None
     region_stats = []
 
-    def roofline_block(k_ms, launches, sources):
+    def step_frac(elapsed_s):
+        """The whole step against the roofline, not only its dominant kernel: algorithmic bytes of one step / wall time per step
+        (producer kernel, kernel boundaries and host launch gaps included) / peak.  This is the fraction `value` corresponds to."""
+        return round(algo_bytes_per_launch / (elapsed_s / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if elapsed_s > 0 else 0.0
+
+    def roofline_block(k_ms, launches, sources, elapsed_s):
         achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_src = _pmc_traffic(args.config, F, sources)
+        traffic, traffic_src = _pmc_traffic(config, F, sources)
         return {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "step_frac": step_frac(elapsed_s),
+                "step_ms": round(elapsed_s * 1e3 / args.steps, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": round(k_ms, 5), "launches_timed": launches, "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
-                "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel"}
+                "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel; "
+                        "step_frac = the same bytes / wall time per step (all kernels of the step, boundaries, launch gaps) / peak"}
 
     verified, checks = True, []
 
@@ -362,7 +393,7 @@ def main():
     if do_shared:
         elapsed, k_ms, k_launches = timed_region()
         kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
-        rf = roofline_block(k_ms, k_launches, "shared")
+        rf = roofline_block(k_ms, k_launches, "shared", elapsed)
         comp = compulsory_bytes_shared / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         rf["hbm_compulsory_frac"] = round(comp / HBM_PEAK_GBS, 4)
         rf["note"] += ("; all frames share ONE source, whose reads are largely served by L2 / the 256 MiB Infinity Cache: "
@@ -370,10 +401,10 @@ def main():
                        "roofline_distinct is the layout where algorithmic bytes are HBM bytes")
         res["shared"] = (elapsed, rf)
         if not args.no_verify:                      # the bytes the timed kernels wrote (untimed checks)
-            want = {i: h for i, h in _golden_shas(args.config).items() if i in frame_ids}
+            want = {i: h for i, h in _golden_shas(config).items() if i in frame_ids}
             if want:
                 ok = all(hashlib.sha256(frame_view(out_t, frame_ids.index(i)).cpu().numpy().tobytes()).hexdigest() == h for i, h in want.items())
-                check(f"frames {sorted(want)} of the timed output == reference goldens {GOLDEN_CASE[args.config]} (sha256)", ok)
+                check(f"frames {sorted(want)} of the timed output == reference goldens {GOLDEN_CASE[config]} (sha256)", ok)
             for f in range(F):
                 if same_as[f] is not None and n_out[f] == n_out[same_as[f]]:
                     if not torch.equal(frame_view(out_t, f), frame_view(out_t, same_as[f])):
@@ -405,7 +436,7 @@ def main():
         elapsed_f, k_ms_f, k_launches_f = timed_region(run_fresh)
         k_last = (step_i[0] - 1) % len(fresh_sets)
         fs = fresh_sets[k_last]
-        fresh = {"ms_per_step": round(elapsed_f * 1e3 / args.steps, 4), "kernel_ms": round(k_ms_f, 5),
+        fresh = {"ms_per_step": round(elapsed_f * 1e3 / args.steps, 4), "kernel_ms": round(k_ms_f, 5), "step_frac": step_frac(elapsed_f),
                  "value_mpixels_per_s": round(px_all * args.steps / elapsed_f / 1e6, 1),
                  "vs_resident_ms_per_step": round(elapsed_f / res["shared"][0], 4),
                  "layout_walks_in_region": ctx.layout_walks() - walks0, "frames_redone_in_region": ctx.redone_frames() - redone0,
@@ -439,7 +470,7 @@ def main():
         elapsed_d, k_ms_d, k_launches_d = timed_region()
         kernel_shared = kernel_name                 # (the layout policy may pick another kernel when every frame streams its own source)
         kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
-        rd = roofline_block(k_ms_d, k_launches_d, "distinct")
+        rd = roofline_block(k_ms_d, k_launches_d, "distinct", elapsed_d)
         kernel_name = kernel_shared or kernel_name
         rd["sources"] = f"{F} distinct {W}x{H} RGBA sources per step ({F * W * H * 4 / 1e6:.0f} MB >> 256 MiB Infinity Cache): algorithmic bytes are HBM bytes"
         rd["ms_per_step"] = round(elapsed_d * 1e3 / args.steps, 4)
@@ -461,15 +492,22 @@ def main():
                     ok = False
                     break
             check("distinct-source frames == shared-source frames XOR per-frame constant on exactly the hit pixels (all frames)", ok)
-            want = {i: h for i, h in _golden_shas(args.config).items() if i in frame_ids}
-            if "shared" not in res and want:
-                ok = all(hashlib.sha256(frame_view(out_t, frame_ids.index(i)).cpu().numpy().tobytes()).hexdigest() == h for i, h in want.items())
-                check(f"frames {sorted(want)} == reference goldens {GOLDEN_CASE[args.config]} (sha256)", ok)
+            # ... and against the reference's own goldens: frame f of the TIMED output with its constant XOR-ed back on the hit
+            # pixels is what the un-XOR-ed source gives (the goldens were generated from that source)
+            want = {i: h for i, h in _golden_shas(config).items() if i in frame_ids}
+            if want:
+                ok = True
+                for i, h in want.items():
+                    f = frame_ids.index(i)
+                    undo = (hit_masks[f].to(torch.uint8) * consts[f]).unsqueeze(1).expand(-1, 4)
+                    rec = frame_view(out_t, f).view(-1, 4) ^ undo
+                    ok = ok and hashlib.sha256(rec.contiguous().cpu().numpy().tobytes()).hexdigest() == h
+                check(f"frames {sorted(want)} of the timed one-source-per-frame output, constants XOR-ed back on the hit pixels, == reference goldens {GOLDEN_CASE[config]} (sha256)", ok)
         del srcs, shared_copy
         ctx.set_image_device(img_t.data_ptr(), W, H)
 
-    primary = "shared" if "shared" in res else "distinct"
-    elapsed, roofline = res[primary]
+    primary_src = "shared" if "shared" in res else "distinct"
+    elapsed, roofline = res[primary_src]
     ms_per_step = elapsed * 1e3 / args.steps
     value = px_all * args.steps / elapsed / 1e6          # Mpixels/s, whole job
     if world > 1:
@@ -479,7 +517,7 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if primary and rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from hgtest import oracle as O             # checker / baseline only; never on the measured GPU path
         img = img_t.cpu().numpy()
@@ -521,13 +559,13 @@ def main():
                                 "sample": f"{sum(r[1] for r in r_mt)} frames on {cores} threads (one frame per thread at a time, "
                                           f"fresh output buffers per frame) in {dt_mt:.1f} s"}
         # the same algorithm as plain JavaScript under this box's Node (what the reference's own loops achieve here)
-        if piecewise and args.config in ("C3", "C5"):
+        if piecewise and config in ("C3", "C5"):
             import shutil
             import subprocess
             node = shutil.which("node")
             if node:
                 try:
-                    p = subprocess.run([node, os.path.join(ROOT, "oracle", "hg_oracle_js.mjs"), "bench", args.config, "8"],
+                    p = subprocess.run([node, os.path.join(ROOT, "oracle", "hg_oracle_js.mjs"), "bench", config, "8"],
                                        capture_output=True, text=True, timeout=120)
                     j = json.loads(p.stdout.strip().splitlines()[-1])
                     cpu["node"] = {"value": j["mpix_per_s"], "unit": "Mpixels/s", "cores": 1, "node": j["node"],
@@ -535,26 +573,24 @@ def main():
                 except Exception as e:                      # noqa: BLE001 - the baseline is informative only
                     cpu["node"] = {"error": str(e)[:200]}
 
-    if rank == 0:
-        line = {"metric": "Mpixels/s warped (piecewise-affine, 4K RGBA)" if args.config == "C3" else f"Mpixels/s warped ({args.config})",
-                "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "u8 pixels / f64 coordinates", "data": "synthetic",
-                "config": {"workload": workload + (" on a shared source" if primary == "shared" else ", one source per frame"),
-                           "frames_per_gpu_per_step": F, "point_sets": pts_txt,
-                           "output_pixels_per_step_per_gpu": int(px_per_step), "sources": primary,
-                           "parallelism": f"frames sharded over {world} GPU(s); shared source broadcast once (scatter+all_gather over RCCL)",
-                           "broadcast_ms": round(broadcast_ms, 3), "broadcast": broadcast, "gpus_on_node": n_devices,
-                           "kernel_ms_over_ranks": {"min": round(region_stats[0]["kernel_ms_min"], 5), "max": round(region_stats[0]["kernel_ms_max"], 5),
-                                                    "by_rank": [round(v, 5) for v in region_stats[0]["kernel_ms_by_rank"]]} if region_stats else None},
-                "verified": None if args.no_verify else verified, "checks": checks,
-                "roofline": roofline, "roofline_fresh": fresh, "roofline_distinct": res["distinct"][1] if "distinct" in res and primary != "distinct" else None,
-                "cpu_baseline": cpu}
-        print(json.dumps(line), flush=True)
+    step_ms_by_rank = [round(e * 1e3 / args.steps, 5) for e in region_stats[0]["elapsed_s_by_rank"]] if region_stats else None
+    line = {"metric": "Mpixels/s warped (piecewise-affine, 4K RGBA)" if config == "C3" else f"Mpixels/s warped ({config})",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 pixels / f64 coordinates", "data": "synthetic",
+            "config": {"workload": workload + (" on a shared source" if primary_src == "shared" else ", one source per frame"),
+                       "frames_per_gpu_per_step": F, "point_sets": pts_txt,
+                       "output_pixels_per_step_per_gpu": int(px_per_step), "sources": primary_src,
+                       "parallelism": f"frames sharded over {world} GPU(s); shared source broadcast once (scatter+all_gather over RCCL)",
+                       "broadcast_ms": round(broadcast_ms, 3), "broadcast": broadcast, "gpus_on_node": n_devices,
+                       "ms_per_step_by_rank": step_ms_by_rank,
+                       "kernel_ms_over_ranks": {"min": round(region_stats[0]["kernel_ms_min"], 5), "max": round(region_stats[0]["kernel_ms_max"], 5),
+                                                "by_rank": [round(v, 5) for v in region_stats[0]["kernel_ms_by_rank"]]} if region_stats else None},
+            "verified": None if args.no_verify else verified, "checks": checks,
+            "roofline": roofline, "roofline_fresh": fresh, "roofline_distinct": res["distinct"][1] if "distinct" in res and primary_src != "distinct" else None,
+            "cpu_baseline": cpu}
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
-    return 0 if (verified or args.no_verify) else 3
+    return line, bool(verified or args.no_verify)
 
 
 if __name__ == "__main__":

@@ -65,7 +65,7 @@ extern "C" void hg_destroy(hg_ctx *c)
                      c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_fwd_status, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
-    for (hg_ctx::Stage &st : c->stage) if (st.h) (void)hipHostFree(st.h);
+    for (hg_ctx::Stage &st : c->stage) { if (st.h) (void)hipHostFree(st.h); if (st.done) (void)hipEventDestroy(st.done); }
     for (hg_ctx::GeoStage &gs : c->geo_stage) { if (gs.h) (void)hipHostFree(gs.h); if (gs.done) (void)hipEventDestroy(gs.done); }
     { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status };
       for (void *q : rp) if (q) (void)hipFree(q); }
@@ -89,7 +89,9 @@ extern "C" int hg_device_alloc(hg_ctx *c, size_t bytes, void **dptr)
 extern "C" int hg_device_free(hg_ctx *c, void *dptr)
 {
     HG_TRY(bind(c));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // Queued runs are settled first: a frame one of them flagged is redone INTO its output buffer by hg_sync, which must not
+    // happen after that buffer has been freed.
+    HG_TRY(hg_sync(c));
     if (dptr) HIP_TRY(c, hipFree(dptr));
     return HG_OK;
 }

@@ -167,9 +167,12 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     }
     hg_ctx::Stage &st = c->stage[slot];
     const size_t fd_bytes = sizeof(FrameDesc) * F, pt_bytes = sizeof(float) * 2 * c->n_pts * F;
+    // An older upload out of this slot may still be queued (no queued run refers to the slot -- checked above -- but its DMA reads
+    // it): wait for THAT copy, not for the stream.  64 sets back it has long run in any loop that also launches kernels.
+    if (!st.done) HIP_TRY(c, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    if (st.used) HIP_TRY(c, hipEventSynchronize(st.done));
     if (fd_bytes + pt_bytes > st.cap) {
-        // (an older upload out of this slot may still be queued; no queued run refers to it -- checked above -- but the DMA does)
-        if (st.h) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipHostFree(st.h)); st.h = nullptr; st.cap = 0; }
+        if (st.h) { HIP_TRY(c, hipHostFree(st.h)); st.h = nullptr; st.cap = 0; }
         void *q = nullptr;
         const size_t want = fd_bytes + pt_bytes + (fd_bytes + pt_bytes) / 4;
         hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
@@ -182,6 +185,8 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     static_assert(sizeof(FrameDesc) % 8 == 0, "the destiny points follow the frame records in the same block");
     c->d_pw_frames = reinterpret_cast<FrameDesc *>(c->d_set); c->d_dst = reinterpret_cast<float *>(c->d_set + fd_bytes);
     HIP_TRY(c, hipMemcpyAsync(c->d_set, st.h, fd_bytes + pt_bytes, hipMemcpyHostToDevice, c->stream));    // (one DMA: the staged block has the device layout)
+    HIP_TRY(c, hipEventRecord(st.done, c->stream));
+    st.used = true;
     c->pw_frames.swap(fresh);
     c->stage_cur = slot;
     double tri_rows = 0.0, shear = 0.0;

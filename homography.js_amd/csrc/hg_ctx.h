@@ -92,7 +92,9 @@ struct hg_ctx {
     // points): hg_piecewise_set_frames copies the caller's arrays there and queues stream-ordered uploads -- it neither waits
     // for the GPU nor keeps caller memory.  A staged set stays intact until every run that used it has been settled, so frames a
     // fused run flagged can still be redone (through the materialised map) after newer sets were uploaded.
-    struct Stage { uint8_t *h = nullptr; size_t cap = 0; int n = 0, n_pts = 0; };
+    // `done` is recorded behind the slot's upload: the slot's bytes are not rewritten before the DMA that reads them has run
+    // (paths that keep no pending record -- the forward scatter path -- could otherwise lap the ring with uploads still queued)
+    struct Stage { uint8_t *h = nullptr; size_t cap = 0; int n = 0, n_pts = 0; hipEvent_t done = nullptr; bool used = false; };
     Stage stage[kStatusRing];
     int stage_cur = -1;
     // scratch of the deferred redo (one frame): its FrameDesc, points, solves

@@ -137,8 +137,15 @@ extern "C" int hg_multi_set_image(hg_multi *m, const uint8_t *rgba, int w, int h
     if (!rgba || w <= 0 || h <= 0) return mfail(m, HG_ERR_INVALID, "hg_multi_set_image: bad image");
     const size_t bytes = (size_t)w * h * 4;
     const int G = (int)m->devs.size();
+    // Queued warps still read the old image, and the previous fan-out may still be running on the peers' copy streams (set_image
+    // returns after the root's H2D): EVERY device is settled -- its warp stream waited for its own "whole image here" event, so
+    // a settled device has finished its pulls -- before ANY buffer is replaced: peers pull slices out of each other's buffers.
     for (auto &d : m->devs) {
-        MHG(m, d.ctx, hg_sync(d.ctx));                       // queued warps still read the old image
+        MHG(m, d.ctx, hg_sync(d.ctx));
+        MHIP(m, hipSetDevice(d.id));
+        MHIP(m, hipStreamSynchronize(d.copy));
+    }
+    for (auto &d : m->devs) {
         if (bytes > d.img_cap) {
             // grow: new buffer first, the context's alias moves to it, only then the old one goes (never a dangling alias,
             // whatever fails on the way)

@@ -90,19 +90,22 @@ def check_launch(world, rank, local_rank, n_devices):
 
 def aggregate_step_stats(dist, world, device, elapsed_s, pixels_per_step, kernel_ms, verified):
     """What rank 0 reports for a timed region: elapsed = MAX over ranks (the job is as slow as its slowest rank), pixels =
-    SUM over ranks (whole-job throughput), verified = AND over ranks, kernel_ms min / max over ranks (a straggler GPU shows)."""
+    SUM over ranks (whole-job throughput), verified = AND over ranks, kernel_ms min / max over ranks and every rank's own elapsed time
+    (a straggler GPU shows)."""
     import torch
     if world == 1:
         return {"elapsed_s": float(elapsed_s), "pixels_per_step": float(pixels_per_step), "verified": bool(verified),
-                "kernel_ms_min": float(kernel_ms), "kernel_ms_max": float(kernel_ms), "kernel_ms_by_rank": [float(kernel_ms)]}
+                "kernel_ms_min": float(kernel_ms), "kernel_ms_max": float(kernel_ms), "kernel_ms_by_rank": [float(kernel_ms)],
+                "elapsed_s_by_rank": [float(elapsed_s)]}
     mx = torch.tensor([elapsed_s, kernel_ms, 0.0 if verified else 1.0], dtype=torch.float64, device=device)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     mn = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
     dist.all_reduce(mn, op=dist.ReduceOp.MIN)
     sm = torch.tensor([pixels_per_step], dtype=torch.float64, device=device)
     dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-    mine = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+    mine = torch.tensor([kernel_ms, elapsed_s], dtype=torch.float64, device=device)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     return {"elapsed_s": float(mx[0].item()), "pixels_per_step": float(sm[0].item()), "verified": bool(mx[2].item() == 0.0),
-            "kernel_ms_min": float(mn[0].item()), "kernel_ms_max": float(mx[1].item()), "kernel_ms_by_rank": [float(t.item()) for t in parts]}
+            "kernel_ms_min": float(mn[0].item()), "kernel_ms_max": float(mx[1].item()), "kernel_ms_by_rank": [float(t[0].item()) for t in parts],
+            "elapsed_s_by_rank": [float(t[1].item()) for t in parts]}

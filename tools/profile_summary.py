@@ -1,11 +1,24 @@
 #!/usr/bin/env python3
-"""Summarises rocprofv3 sqlite outputs (kernel trace stats + PMC passes) as plain text."""
+"""Summarises rocprofv3 sqlite outputs (kernel trace stats + PMC passes) as plain text.
+
+Refuses (exit status 2, nothing on stdout) when a bench line found in the run's logs says "verified": false: a summary whose own
+bench line is unverified is not evidence and must not reach profiles/."""
+import builtins
 import glob
+import io
+import json
 import os
 import sqlite3
 import sys
 
 out = sys.argv[1]
+_buf, _unverified = io.StringIO(), []
+
+
+def print(*a, **k):                                         # collected; written at the end only if every bench line is verified
+    builtins.print(*a, file=_buf, **k)
+
+
 for db in sorted(glob.glob(os.path.join(out, "trace", "*.db"))):
     con = sqlite3.connect(db)
     print("== rocprofv3 --kernel-trace --stats  (top kernels; durations in us)")
@@ -34,6 +47,16 @@ for log in sorted(glob.glob(os.path.join(out, "*.log"))):
     lines = open(log, errors="replace").read().strip().splitlines()
     js = [ln for ln in lines if ln.startswith("{")]
     if js:
+        try:
+            if json.loads(js[-1]).get("verified") is False:
+                _unverified.append(os.path.basename(log))
+        except ValueError:
+            pass
         print(f"-- {os.path.basename(log)}: bench line printed by this run: {js[-1]}")
     else:
         print(f"-- {os.path.basename(log)}: {lines[-1][:300] if lines else ''}")
+
+if _unverified:
+    builtins.print(f"profile_summary: REFUSED -- bench line(s) with \"verified\": false in {', '.join(_unverified)}", file=sys.stderr)
+    sys.exit(2)
+sys.stdout.write(_buf.getvalue())
