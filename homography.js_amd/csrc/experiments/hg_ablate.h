@@ -37,7 +37,7 @@ struct Ablate : NoExperiment {
     __device__ static __forceinline__ bool skip_store(const uint32_t *px) { return (ABL & 4) && (px[0] ^ px[1] ^ px[2] ^ px[3]) != 0x9e3779b9u; }
     __device__ static __forceinline__ int slot(int32_t *cnt, int t, int64_t y) { return (ABL & 32) ? (int)((t * 7 + (int)y) & 31) : atomicAdd(cnt, 1); }
     static constexpr bool store_entries = !(ABL & 64);
-    static constexpr bool tri_solve = !(ABL & 128);
+    static constexpr bool tri_solve = !(ABL & 128);          // k_tri_spans_grouped: skip the per-triangle solves
 };
 
 static bool launch_tri_spans_ablated(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, dim3 grid, dim3 block, hipStream_t stream)
@@ -51,22 +51,11 @@ static bool launch_tri_spans_ablated(const PwMesh &mesh, const PwFrames &fr, con
     }
 }
 
-static bool launch_tri_table_ablated(const PwMesh &mesh, const PwFrames &fr, const TriTable &tb, dim3 grid, dim3 block, hipStream_t stream)
-{
-    static const int abl = getenv("HG_ABLATE_TRI") ? atoi(getenv("HG_ABLATE_TRI")) : 0;
-    switch (abl) {
-    case 64:  hipLaunchKernelGGL(k_tri_table<Ablate<64>>, grid, block, 0, stream, mesh, fr, tb); return true;
-    case 128: hipLaunchKernelGGL(k_tri_table<Ablate<128>>, grid, block, 0, stream, mesh, fr, tb); return true;
-    case 192: hipLaunchKernelGGL(k_tri_table<Ablate<192>>, grid, block, 0, stream, mesh, fr, tb); return true;
-    default: return false;
-    }
-}
-
-static bool launch_pw_rows_ablated(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, const TriTable &tb, uint8_t *out, int16_t *map_out, int rpx, int rg,
+static bool launch_pw_rows_ablated(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int rpx, int rg,
                                    int32_t *status_next, dim3 grid, hipStream_t stream)
 {
     static const int abl = getenv("HG_ABLATE") ? atoi(getenv("HG_ABLATE")) : 0;
-#define HG_ABL(N) case N: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, Ablate<N>, false>), grid, dim3(256), 0, stream, mesh, fr, rl, tb, out, map_out, rpx, rg, status_next); return true
+#define HG_ABL(N) case N: hipLaunchKernelGGL((k_pw_rows<kRowSpanCapFast, Ablate<N>, false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); return true
     switch (abl) {
     HG_ABL(1); HG_ABL(2); HG_ABL(4); HG_ABL(6); HG_ABL(8); HG_ABL(14); HG_ABL(16);
     default: return false;

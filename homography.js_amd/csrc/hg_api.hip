@@ -61,7 +61,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
-    void *ptrs[] = { c->d_src, c->d_tris, c->d_set, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent, c->d_tbl,
+    void *ptrs[] = { c->d_src, c->d_tris, c->d_set, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent,
                      c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_fwd_status, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -169,7 +169,7 @@ extern "C" int hg_copy_to_device(hg_ctx *c, void *dst, const void *src, size_t b
 extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kernel : 0; }
 extern "C" int hg_last_forward_kernel(hg_ctx *c) { return c ? c->fwd_last_kernel : 0; }
 
-extern "C" int hg_last_piecewise_table(hg_ctx *c) { return c && c->pw_table ? 1 : 0; }
+extern "C" int hg_last_piecewise_self(hg_ctx *c) { return c && c->pw_self ? 1 : 0; }
 extern "C" long hg_redone_frames(hg_ctx *c) { return c ? c->pw_redone : 0; }
 extern "C" long hg_layout_walks(hg_ctx *c) { return c ? c->pw_layout_walks : 0; }
 
@@ -185,7 +185,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
     else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
     else if (!std::strcmp(key, "compact")) c->opt_compact = value < 0 ? -1 : (value ? 1 : 0);
-    else if (!std::strcmp(key, "table")) { c->opt_table = value; c->pw_table_disabled = false; }
+    else if (!std::strcmp(key, "self_spans")) { c->opt_self = value < 0 ? -1 : (value ? 1 : 0); c->pw_self_disabled = false; }
     else if (!std::strcmp(key, "tri_threads")) c->opt_tri_threads = (value == 64 || value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "tri_group")) c->opt_tri_group = value < 0 ? -1 : (value >= 64 ? 64 : (value ? 16 : 0));
     else if (!std::strcmp(key, "rows1_threads")) c->opt_rows1_threads = (value == 128 || value == 256) ? value : -1;

@@ -36,6 +36,7 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
     c->have_mesh = true;
     c->mesh_gen++;
     c->fwd_pw_tiles_disabled = false; c->fwd_pw_cap = 64;     // (learned on the previous mesh)
+    c->pw_self_disabled = false;
     c->pw_frames.clear(); c->pw_setup_done = false;
     return HG_OK;
 }
@@ -229,7 +230,8 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     {   // few rows in total (a single 4K frame has 560 four-row groups for 256 CUs): one row per workgroup fills the chip better
         int64_t groups = 0;
         for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + kRowGroup - 1) / kRowGroup;
-        if (groups < c->opt_min_row_groups) c->pw_row_group = 1;
+        c->pw_small_set = groups < c->opt_min_row_groups;
+        if (c->pw_small_set) c->pw_row_group = 1;
     }
     // dense rows that still fit the patch kernel's LDS budget, sheared enough for 2-D gather patches to pay.  Measured
     // (k_pw_rows one row per workgroup -> k_pw_patch): C5, shear 0.39, cover 190: 0.63 -> 0.50 ms; 4K 60x60 grid, 0.15, 148:
@@ -289,7 +291,8 @@ PwFrames frames_of(const hg_ctx *c)
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     f.max_obj_h = mh;
     f.row_group = c->pw_row_group;
-    f.tri_threads = c->pw_table ? (c->pw_tri_rows_max <= 64 ? 64 : 128) : c->pw_tri_threads;
+    f.tri_threads = c->pw_tri_threads;
+    f.self_spans = c->pw_self ? (c->pw_small_set ? 2 : 1) : 0;       // (2: a launch that cannot fill the chip takes the short-latency prologue)
     // k_tri_spans_grouped where the per-workgroup solves of k_tri_spans dominate the producer (measured round 3, producer us, 64 frames of
     // 4K unless noted, k_tri_spans -> grouped 16 -> 64): 512 triangles 89 -> 68 -> 68, 3200: 222 -> 151 -> 114, 4608: 342 -> 238 -> 169,
     // C5 (8 frames of 5000) 80 -> 57 -> 57; but C3 (200 triangles of 216 rows) 47.7 -> 51.2 and C4 37.1 -> 38.7: their cost is the
@@ -363,27 +366,28 @@ static int run_setup(hg_ctx *c)
         // entry format of the span lists (hg_kernels.h): 8 bytes for dense rows and whenever k_pw_patch will read them
         const bool compact = c->opt_compact >= 0 ? c->opt_compact != 0 : (patch_preferred(c, nullptr) || c->pw_cover > 56);
         if (compact != c->pw_compact) { c->pw_compact = compact; c->rows_clean = false; }
-        // Table path (k_tri_table -> k_pw_rows<TBL>), option "table" = 1 only: sparse meshes -- where the row lists would carry
-        // 32-byte entries -- whose triangles a workgroup can afford to scan (every 4-row group tests all of them); the tallest
-        // triangle sizes the table.  Layout choice only: what does not fit (a taller triangle, more spans per row than a packed
-        // block holds) flags its frame.  NOT the default: measured round 3 (same box, 64 frames): the producer gets faster (C3
-        // k_tri_spans 42 -> k_tri_table 35 us; without its table stores 22) but the consumer's prologue -- scan, candidate list,
-        // two more barriers -- costs more than that (C3 warp kernel 583 -> 604 us, C4 244 -> 249, F = 1 step 23.4 -> 24.9 us).
-        const size_t T = (size_t)std::max(c->n_tris, 1);
-        c->pw_table = !compact && !c->pw_table_disabled && c->opt_table == 1 && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 &&
-                      c->pw_tri_rows_max > 0 && c->pw_tri_rows_max <= 8192 && (c->pw_row_group == 1 || c->pw_cover <= 56);
-        if (c->pw_table) {
-            const int want = ((c->pw_tri_rows_max + 8 + 15) / 16) * 16 << c->pw_table_grown;
-            if (want > c->tbl_stride) c->tbl_stride = want;
-            if (F * T * (size_t)c->tbl_stride > ((size_t)1 << 28)) c->pw_table = false;          // (2 GiB of table: not this path)
-        }
-        if (c->pw_table) HG_TRY(ensure(c, c->d_tbl, c->tbl_cap, F * T * (size_t)c->tbl_stride));
+        // Self-span path (k_tri_setup -> k_pw_rows<SELF>, round 4): sparse meshes -- where the row lists would carry 32-byte entries --
+        // whose triangles a workgroup can afford to scan (every row group tests all of them, 16 bytes each).  No producer kernel
+        // beyond the per-triangle solves, no lists, no slot atomics.  Layout choice only: what does not fit (more candidate
+        // triangles than the LDS list, more spans per row than a packed block holds) flags its frame -> map path, and the context
+        // returns to row lists for this mesh.  The prologue's int32 arithmetic wants windows below 2^24 rows near the origin.
+        bool small_geom = true;
+        for (const FrameDesc &d : c->pw_frames)
+            if (d.obj_w > 0 && d.obj_h > 0 && (d.obj_h > (1 << 24) || d.obj_w < 16 || std::abs((int64_t)d.y_off) > (1 << 26))) small_geom = false;
+        // Policy (measured round 4, same box, row lists -> own spans): C3 x 64 frames step 0.624 -> 0.588 ms (warp kernel + 7 us, the 47 us
+        // producer gone), C4 0.258 -> 0.236-0.242, 8 frames of C3 0.104 -> 0.093; a single 4K frame 22.8 -> 23.1 us per queued step (one
+        // row per workgroup: every one of 2239 workgroups scans all triangles, and k_tri_setup's 4 us are one workgroup's dependent
+        // chain): small frame sets keep the row lists unless the option forces it.
+        const bool self = !compact && !c->pw_self_disabled && (c->opt_self >= 0 ? c->opt_self == 1 : !c->pw_small_set) && c->row_cap <= kRowSpanCapFast &&
+                          c->n_tris <= 1024 && small_geom && (c->pw_row_group == 1 || c->pw_cover <= 56);
+        // (its warp kernel neither reads nor zeroes the row counters: a change of path starts from freshly zeroed counter sets)
+        if (self != c->pw_self) { c->pw_self = self; c->rows_clean = false; }
         RowLists rl = rows_of(c);
         // Two sets of row counters (ping-pong) + kStatusRing sets of per-frame status words share one allocation.  It is zeroed by a
         // memset only when the layout changes (or after a setup whose warp never ran): the warp kernel of a step zeroes the OTHER
         // counter set -- the one the previous step consumed, the one the next step counts into -- and the next status set.
         const int32_t *before = c->d_rowcnt;
-        const size_t ent_bytes = c->pw_table ? 0 : F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt));
+        const size_t ent_bytes = c->pw_self ? 0 : F * (size_t)rl.row_stride * rl.cap * (c->pw_compact ? sizeof(RowEnt8) : sizeof(RowEnt));
         if (2 * F * rl.row_stride + kStatusRing * F > c->rowcnt_cap || ent_bytes > c->rowent_cap) HG_TRY(hg_sync(c));   // (queued runs flag into the old ring)
         HG_TRY(ensure(c, c->d_rowcnt, c->rowcnt_cap, 2 * F * rl.row_stride + kStatusRing * F));
         HG_TRY(ensure(c, c->d_rowent, c->rowent_cap, ent_bytes));
@@ -400,14 +404,9 @@ static int run_setup(hg_ctx *c)
         c->status_base = c->d_rowcnt + 2 * F * rl.row_stride;
         c->status_ptr = c->status_base + (size_t)c->status_slot * F;
         c->status_next = c->status_base + (size_t)((c->status_slot + 1) % (int)kStatusRing) * F;
-        if (c->pw_table) {                                   // (the counters stay untouched: clean for whichever path runs next)
-            c->rows_clean = true;
-            TriTable tb; tb.ent = c->d_tbl; tb.stride = c->tbl_stride;
-            launch_tri_table(mesh_of(c), frames_of(c), tb, c->stream);
-        } else {
-            c->rows_clean = false;                           // dirty until the warp kernel has consumed them
-            launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
-        }
+        c->rows_clean = false;                               // dirty until the warp kernel has run: it consumes the counters and clears the next status set
+        if (c->pw_self) launch_tri_setup(mesh_of(c), frames_of(c), c->stream);     // solves, edge equations, row reach; the counters stay untouched (zero)
+        else            launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
     } else {
         HG_TRY(hg_sync(c));                                  // (queued fast-path runs are settled against their own status ring first)
         c->status_ptr = c->d_status;
@@ -427,8 +426,7 @@ static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
     c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
     if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
     else if (c->pw_fast) {
-        TriTable tb; tb.ent = c->pw_table ? c->d_tbl : nullptr; tb.stride = c->tbl_stride;
-        launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), tb, d_out, map_out, c->status_next, c->stream); c->rows_clean = true;
+        launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true;
     }
     else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
 }
@@ -622,9 +620,7 @@ extern "C" int hg_sync(hg_ctx *c)
             if (c->pw_fast && c->row_cap < kRowSpanCapDense)      // denser mesh than assumed: larger lists next time
                 c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
             c->layout_age = 1 << 30;                             // ... and a fresh layout estimate for the next frame set
-            if (c->pw_table) {                                   // the table path flagged: taller triangles than estimated (or denser rows): once more with twice the stride, then row lists
-                if (c->pw_table_grown >= 1) c->pw_table_disabled = true; else c->pw_table_grown++;
-            }
+            if (c->pw_self) c->pw_self_disabled = true;          // the self-span path flagged: more candidates / spans than its LDS blocks hold -> row lists for this mesh
         }
     }
     if (!c->fwd_pending.empty()) {

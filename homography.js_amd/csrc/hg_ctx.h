@@ -107,14 +107,12 @@ struct hg_ctx {
     int32_t *d_redo_status = nullptr; size_t redo_status_cap = 0;
     // layout of the row counters / status ring as of their last memset (a frame set with the same layout reuses them as they are)
     size_t rows_F = 0; int rows_stride = 0, rows_cap = 0;
-    // table path (k_tri_table -> k_pw_rows<TBL>, hg_kernels.h): spans per (frame, triangle, source row), no row lists
-    int2 *d_tbl = nullptr; size_t tbl_cap = 0;
-    int tbl_stride = 0;                                        // entries per triangle (>= the tallest triangle of the frame set; doubles after an overflow)
+    // self-span path (k_tri_setup -> k_pw_rows<SELF>, hg_kernels.h): the row workgroups evaluate their own spans, no row lists
     int pw_tri_rows_max = 0;                                   // tallest triangle of the uploaded frames, in rows (host estimate)
-    bool pw_table = false;                                     // the current step uses the table path
-    bool pw_table_disabled = false;                            // it overflowed twice: row lists from now on
-    int pw_table_grown = 0;
-    int opt_table = -1;                                        // 1: the table path whenever eligible; -1 / 0: row lists (the default, see run_setup)
+    bool pw_small_set = false;                                 // fewer 4-row groups than "min_row_groups": one row per workgroup, short-latency prologues
+    bool pw_self = false;                                      // the current step uses the self-span path
+    bool pw_self_disabled = false;                             // a run on it flagged a frame (more candidates / spans than its LDS blocks hold): row lists for this mesh
+    int opt_self = -1;                                         // option "self_spans": 1 whenever eligible, 0 never, -1 by policy (run_setup)
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
     int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate
     int opt_tri_group = -1;                                    // k_tri_spans_grouped: 16 / 64 triangles per workgroup, 0 never, -1 by mesh size

@@ -23,7 +23,7 @@ struct NoExperiment {
     // k_tri_spans
     __device__ static __forceinline__ int slot(int32_t *cnt, int, int64_t) { return atomicAdd(cnt, 1); }
     static constexpr bool store_entries = true;
-    static constexpr bool tri_solve = true;                 // k_tri_table: thread 0 solves the triangle and writes the taps
+    static constexpr bool tri_solve = true;                 // k_tri_spans_grouped: the per-triangle solves run
 };
 
 // ------------------------------------------------------------------------------------------------ bounds on the high dwords

@@ -46,6 +46,15 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
     TriRange tr;
     tri_rows(d[1], d[3], d[5], tr.y_min, tr.y_end);
     tr.a = 0; tr.b = 0;
+    const bool too_tall = (tr.y_end - (int64_t)tr.y_min) > (1 << 24);
+    {   // rows that cannot write a cell are dropped from the range (hg_math.h): every consumer -- k_pw_fused, k_map_fill, the
+        // span prologue of k_pw_rows<SELF> -- walks [y_min, y_end) and none of those rows has a span
+        int64_t y_first = tr.y_min, y_stop = tr.y_end;
+        if (fd.obj_w > 0 && fd.obj_h > 0) clamp_rows(y_first, y_stop, fd.y_off, fd.obj_w, (int64_t)fd.obj_w * fd.obj_h);
+        else y_stop = y_first;
+        if (y_stop < y_first) y_stop = y_first;
+        tr.y_min = (int32_t)y_first; tr.y_end = (int32_t)y_stop;
+    }
     if (tr.y_end > tr.y_min && fd.obj_w > 0 && fd.obj_h > 0) {
         // Conservative cell extent of any span of this triangle relative to its row base (y - yOff) * W:
         // intersections lie between the vertex x's (+-1 for rounding).  Absurd / non-finite input or a triangle wider
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
         const double x0 = d[0], x1 = d[2], x2 = d[4];
         const bool finite = fabs(x0) < 1.0e9 && fabs(x1) < 1.0e9 && fabs(x2) < 1.0e9 &&
                             fabs((double)d[1]) < 1.0e9 && fabs((double)d[3]) < 1.0e9 && fabs((double)d[5]) < 1.0e9;
-        bool irregular = !finite || (tr.y_end - (int64_t)tr.y_min) > (1 << 24);
+        bool irregular = !finite || too_tall;
         if (!irregular) {
             const int64_t lo = (int64_t)floor(fmin(fmin(x0, x1), x2)) - 1;
             const int64_t hi = (int64_t)ceil(fmax(fmax(x0, x1), x2)) + 1;
@@ -366,99 +375,8 @@ __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh m
 }
 
 
-// ------------------------------------------------------------------------------------------------ k_tri_table (round 3)
-// The same work as k_tri_spans -- per (frame, triangle): solves, edge equations, one thread per source row y evaluating
-// predictXLimits + the two flat fill() indices exactly -- but the result is NOT filed under output rows.  Row y's cells
-// [k, fin) (after TypedArray.fill's index rules) go to  tbl[frame][triangle][y - y_first]  as two int32: consecutive threads
-// write consecutive 8-byte entries and nobody needs a slot, so the 3.2 M returning atomics + scattered 32-byte stores that are
-// 35 of k_tri_spans' 48 us on C3 (ablation, round 3: neither 13 us) disappear.  Which triangles (and which of their rows) reach
-// an output row is decided by the consumer from the per-triangle TriRange {y_first, y_stop, a, b} written here (k_pw_rows<TBL>):
-// row y's cells lie in output rows (y - yOff) + b .. (y - yOff) + a, or objH further down when fill() wrapped a negative
-// index -- the enumeration k_pw_fused has always used.  A triangle with more rows than the table stride, or one the bounds
-// cannot describe (non-finite / absurd coordinates, wider than the whole map), flags the frame: redone through the map path.
-template <class X>
-__global__ __launch_bounds__(128) void k_tri_table(PwMesh mesh, PwFrames fr, TriTable tb)
-{
-    const int t = blockIdx.x, f = blockIdx.y;
-    const FrameDesc fd = fr.frames[f];
-    const float *dp = fr.dst_pts + (size_t)f * mesh.n_pts * 2;
-    float d[6];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint32_t v = mesh.tris[3 * (size_t)t + k];
-        if (v < (uint32_t)mesh.n_pts) { d[2 * k] = dp[2 * (size_t)v]; d[2 * k + 1] = dp[2 * (size_t)v + 1]; }
-        else d[2 * k] = d[2 * k + 1] = NAN;         // typed-array read past the end: undefined -> NaN in the Float32Array(6)
-    }
-    Seg seg[3];
-    define_seg(d[0], d[1], d[2], d[3], seg[0]);     // p0->p1
-    define_seg(d[0], d[1], d[4], d[5], seg[1]);     // p0->p2
-    define_seg(d[2], d[3], d[4], d[5], seg[2]);     // p1->p2
-    int32_t y_min, y_end;
-    tri_rows(d[1], d[3], d[5], y_min, y_end);
-    const size_t ft = (size_t)f * mesh.n_tris + t;
-    const int W = fd.obj_w;
-    const int64_t len = (int64_t)W * fd.obj_h;
-    int64_t y_first = y_min, y_stop = y_end;
-    if (W > 0 && fd.obj_h > 0) clamp_rows(y_first, y_stop, fd.y_off, W, len);     // rows that cannot write a cell are skipped (hg_math.h)
-    else y_stop = y_first;
-    // The matrices (forward :1265-1306, inverse :1345-1365: taps, map path, the consumer's records) are solved one triangle per
-    // THREAD by the first ceil(T / blockDim) workgroups of every frame, before their own row work: ~400 dependent fp64
-    // instructions on a single lane of every workgroup cost 17 of the kernel's 42 us on C3 (ablation, round 3), spread over
-    // all lanes of two workgroups per frame they cost nothing measurable.
-    if (X::tri_solve && blockIdx.x * blockDim.x < (unsigned)mesh.n_tris) {
-        const int ts = blockIdx.x * blockDim.x + threadIdx.x;
-        if (ts < mesh.n_tris) {
-            float ss[6], dd[6];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const uint32_t v = mesh.tris[3 * (size_t)ts + k];
-                if (v < (uint32_t)mesh.n_pts) {
-                    ss[2 * k] = mesh.src_pts[2 * (size_t)v]; ss[2 * k + 1] = mesh.src_pts[2 * (size_t)v + 1];
-                    dd[2 * k] = dp[2 * (size_t)v];           dd[2 * k + 1] = dp[2 * (size_t)v + 1];
-                } else {
-                    ss[2 * k] = ss[2 * k + 1] = dd[2 * k] = dd[2 * k + 1] = NAN;
-                }
-            }
-            float fwd[6], inv[6];
-            solve_affine(ss, dd, fwd);
-            invert_affine(fwd, inv);
-            const size_t fs = (size_t)f * mesh.n_tris + ts;
-#pragma unroll
-            for (int k = 0; k < 6; k++) fr.fwd[fs * 6 + k] = fwd[k];
-            *reinterpret_cast<float4 *>(fr.inv + fs * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
-            *reinterpret_cast<float4 *>(fr.inv + fs * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
-        }
-    }
-    if (threadIdx.x == 0) {                        // edge equations (map path) + the triangle's row / column reach (the consumer's candidate test)
-        fr.segs[ft * 3] = seg[0]; fr.segs[ft * 3 + 1] = seg[1]; fr.segs[ft * 3 + 2] = seg[2];
-        TriRange tr; tr.y_min = (int32_t)y_first; tr.y_end = (int32_t)y_stop; tr.a = 0; tr.b = 0;
-        if (y_stop > y_first) {
-            // cells of a row y lie in [(y - yOff) W + lo, (y - yOff) W + hi): intersections are between the vertex x's (+-1 for
-            // the rounding); same bounds and the same "irregular" rule as k_tri_setup
-            const double x0 = d[0], x1 = d[2], x2 = d[4];
-            const bool finite = fabs(x0) < 1.0e9 && fabs(x1) < 1.0e9 && fabs(x2) < 1.0e9;
-            bool irregular = !finite;
-            if (!irregular) {
-                const int64_t lo = (int64_t)floor(fmin(fmin(x0, x1), x2)) - 1, hi = (int64_t)ceil(fmax(fmax(x0, x1), x2)) + 1;
-                if (hi - lo >= len) irregular = true;
-                else { tr.a = (int32_t)floordiv64(hi - 1, W); tr.b = (int32_t)floordiv64(lo, W); }
-            }
-            if (irregular) atomicOr(&fr.status[f], FRAME_IRREGULAR);
-            if (y_stop - y_first > tb.stride) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);      // table stride too small: the host grows it
-        }
-        fr.trir[ft] = tr;
-    }
-    int2 *__restrict__ row = tb.ent + ft * (size_t)tb.stride;
-    const int64_t n = y_stop - y_first < tb.stride ? y_stop - y_first : tb.stride;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        int64_t k, fin;
-        span_cells(seg, (double)(y_first + i), (double)fd.y_off, (double)W, len, k, fin);
-        if (X::store_entries || k == 0x7fffffffffffffffll) row[i] = k < fin ? make_int2((int)k, (int)fin) : make_int2(0, 0);          // (len < 2^31: fill_frames)
-    }
-}
-
-template <int CAP, class X, bool MAP, int PH, bool COMPACT, bool HIB, bool TBL>
-__device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, const TriTable &tb, uint8_t *__restrict__ out,
+template <int CAP, class X, bool MAP, int PH, bool COMPACT, bool HIB, int SELF>      // SELF: 0 row lists, 1 own spans, 2 the same with all three edges in flight (small frame sets)
+__device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *__restrict__ out,
                                              int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
                                              int32_t *__restrict__ status_next)
 {
@@ -486,7 +404,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += nthreads) status_next[i] = 0;
     // (every row of the frame's counter block, not only the rows of THIS step's window: the other set was filled under the
     //  previous step's geometry, whose frame may have been a row taller)
-    if (!TBL && (int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
+    if (!SELF && (int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_m[CAP * 6];
@@ -507,12 +425,13 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // lists are loaded at once, one barrier, then wave j walks row r0 + j alone -- the list-load latency is paid once per
     // four rows and a row's span scan is a single ballot.  Otherwise the rows are taken one after the other with the
     // whole LDS (up to CAP - 1 spans) and the windows of a row are dealt to the four waves.
-    // TBL (k_tri_table produced the spans, hg_kernels.h): no row lists exist; the counts come out of the table prologue below,
-    // which files the spans straight into the LDS blocks (4-row groups are always "packed", one-row groups use the whole LDS).
+    // SELF (round 4, hg_kernels.h): no row lists exist; the workgroup evaluates the spans of its own rows in the prologue below
+    // (4-row groups are always "packed", one-row groups use the whole LDS) and the counts come out of it.
+    constexpr int kCandCap = SELF ? 256 : 1;
     __shared__ int s_cnt[kRowGroup], s_ncand;
-    __shared__ int s_cand[TBL ? 256 : 1], s_cand_y[TBL ? 256 : 1], s_cand_n[TBL ? 256 : 1];
+    __shared__ int s_cand_tn[kCandCap], s_cand_y[kCandCap];      // candidate: triangle | rows << 16, first source row
     int cnts[kRowGroup], cmax = 0;
-    if (!TBL) {
+    if (!SELF) {
         const int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
 #pragma unroll
         for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
@@ -521,7 +440,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
             return;
         }
     }
-    const bool packed = TBL ? rows_per_group == kRowGroup : (rows_per_group == kRowGroup && __builtin_amdgcn_readfirstlane(cmax) <= 63);
+    const bool packed = SELF ? rows_per_group == kRowGroup : (rows_per_group == kRowGroup && __builtin_amdgcn_readfirstlane(cmax) <= 63);
 
     // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
     // from the hardware range check == the JS `undefined` -> 0 of :1051.
@@ -568,12 +487,16 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         if (t0 < 3) reinterpret_cast<double2 *>(s_m + (base + nan_slot) * 6)[t0] = make_double2(NAN, NAN);
     };
 
-    // TBL prologue: (1) every thread tests triangles t = tid, tid + nthreads, ... : can a row of t write into this group's output
-    // rows?  Row y's cells lie in output rows (y - yOff) + b .. + a (k_tri_table), objH further down when fill() wrapped a negative
-    // index ("image" 1); hits go to a candidate list in LDS.  (2) one thread per candidate loads the <= 8 table entries of its
-    // source rows (one round trip, with the triangle's inverse matrix) and files every piece that falls into a row of the group
-    // into that row's LDS block, exactly what load_row copies from a list.  Spans arrive in arbitrary order, like from the lists.
-    auto table_prologue = [&]() -> bool {
+    // SELF prologue: the spans of this group's rows, computed here instead of being filed into row lists by a producer kernel.
+    // Input: what k_tri_setup wrote per (frame, triangle) -- edge equations, inverse matrix, the clamped row range [y_min, y_end)
+    // of fillTriangle's loop :1113-1120 and the bounds a, b on the output rows a row-y span can reach ((y - yOff) + b .. + a, objH
+    // further down when fill() wrapped a negative index: "image" 1; the enumeration k_pw_fused has always used).
+    //  (1) scan: thread t tests triangle t (16 bytes each, one round trip for T <= 256): can one of its rows write into rows
+    //      r0 .. r0 + nrows - 1?  Hits are compacted into an LDS candidate list with one ballot + one LDS atomic per wave.
+    //  (2) spans: 8 lanes per candidate (2 for one-row groups), one source row each: predictXLimits :1172-1197 + the two flat
+    //      fill() indices :1124 exactly (span_cells, hg_math.h), cut at output-row boundaries, every piece that falls into a row
+    //      of the group filed into that row's LDS block -- exactly what load_row copies from a list.  Arbitrary order, like there.
+    auto self_prologue = [&]() -> bool {
         if ((int)threadIdx.x < kRowGroup) s_cnt[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_ncand = 0;
         if ((int)threadIdx.x < 3 * nrows) {                 // the NaN record of every row block ("no triangle")
@@ -584,62 +507,100 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         __syncthreads();
         const int T = mesh.n_tris;
         const TriRange *__restrict__ trir = fr.trir + (size_t)f * T;
-        const int64_t g_lo = r0, g_hi = r0 + nrows - 1;
-        for (int t0 = threadIdx.x; t0 < T; t0 += 4 * nthreads) {       // four triangles per thread and round: their ranges are requested together
-            TriRange trs[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int t = t0 + q * nthreads;
-                trs[q] = t < T ? trir[t] : TriRange{0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const TriRange tr = trs[q];
-                if (tr.y_end <= tr.y_min) continue;
-#pragma unroll
-                for (int image = 0; image < 2; image++) {
-                    const int64_t shift = image ? fd.obj_h : 0;
-                    int64_t ylo = g_lo - tr.a - shift + fd.y_off, yhi = g_hi - tr.b - shift + fd.y_off;
-                    if (ylo < tr.y_min) ylo = tr.y_min;
-                    if (yhi > (int64_t)tr.y_end - 1) yhi = (int64_t)tr.y_end - 1;
-                    if (ylo > yhi) continue;
-                    const int slot = atomicAdd(&s_ncand, 1);
-                    if (slot < 256) { s_cand[slot] = t0 + q * nthreads; s_cand_y[slot] = (int)(ylo - tr.y_min); s_cand_n[slot] = (int)(yhi - ylo + 1); }
-                }
+        // (int32 throughout: |yOff|, objH and the clamped row ranges are below 2^26 -- coordinates are limited to 2^24, hg_math.h --
+        //  and a, b are cell offsets / W of a map with fewer than 2^31 cells)
+        const int g_lo = r0 + fd.y_off, g_hi = r0 + nrows - 1 + fd.y_off;
+        // Candidate entries carry up to `chunk` source rows (4 for 4-row groups, 1 for one-row groups: one lane per row below); a
+        // triangle that reaches more rows -- window borders, spans spilling over the row end (x-offset quirk) -- files a second entry
+        // for the rest, whose lanes loop if that is still more than `chunk` (a - b > 1: triangles wider than the map; rare).
+        const int chunk_log2 = packed ? 2 : 0, chunk = 1 << chunk_log2;
+        for (int t0 = 0; t0 < T; t0 += nthreads) {
+            const int t = t0 + (int)threadIdx.x;
+            const TriRange tr = t < T ? trir[t] : TriRange{0, 0, 0, 0};
+            const int ylo0 = max(g_lo - tr.a, tr.y_min), n0 = min(g_hi - tr.b, tr.y_end - 1) - ylo0 + 1;
+            const int ylo1 = max(g_lo - tr.a - fd.obj_h, tr.y_min), n1 = min(g_hi - tr.b - fd.obj_h, tr.y_end - 1) - ylo1 + 1;
+            const unsigned long long m0 = __ballot(n0 > 0), m1 = __ballot(n1 > 0);
+            if ((m0 | m1) == 0ull) continue;                // (wave-uniform)
+            const unsigned long long m0b = __ballot(n0 > chunk), m1b = __ballot(n1 > chunk);
+            const int c0 = __popcll(m0), c0b = __popcll(m0b), c1 = __popcll(m1), c1b = __popcll(m1b);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncand, c0 + c0b + c1 + c1b);
+            base = __builtin_amdgcn_readfirstlane(base);
+            auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+            auto file = [&](int at, int y0, int n) { if (at < kCandCap) { s_cand_tn[at] = t | (min(n, 0xffff) << 16); s_cand_y[at] = y0; } };
+            if (n0 > 0) file(base + below(m0), ylo0, min(n0, chunk));
+            if (n0 > chunk) file(base + c0 + below(m0b), ylo0 + chunk, n0 - chunk);
+            if (m1) {
+                if (n1 > 0) file(base + c0 + c0b + below(m1), ylo1, min(n1, chunk));
+                if (n1 > chunk) file(base + c0 + c0b + c1 + below(m1b), ylo1 + chunk, n1 - chunk);
             }
         }
         __syncthreads();
         const int nc = s_ncand;
-        if (nc > 256) return false;
+        if (nc > kCandCap) return false;
         const int capr = packed ? 63 : CAP - 1;
-        // eight threads per candidate, one source row each (a candidate has nrows + a - b rows: 4 or 5 as a rule; more are taken in
-        // rounds): every thread's single table entry and the triangle's matrix are requested at once
-        for (int c0 = 0; c0 < nc; c0 += nthreads >> 3) {
-            const int c = c0 + ((int)threadIdx.x >> 3), jj = threadIdx.x & 7;
+        const int lpc_log2 = chunk_log2, lpc = chunk;       // lanes per candidate entry
+        const double flen = (double)((int64_t)W * fd.obj_h), fW = (double)W;      // (len < 2^31: fill_frames)
+        const Seg *__restrict__ gseg = fr.segs + (size_t)f * T * 3;
+        for (int c0 = 0; c0 < nc; c0 += nthreads >> lpc_log2) {
+            const int c = c0 + ((int)threadIdx.x >> lpc_log2), jj = threadIdx.x & (lpc - 1);
             if (c >= nc) continue;
-            const int t = s_cand[c], i0 = s_cand_y[c], n = s_cand_n[c];      // i0: the first candidate row's index in the triangle's table block
-            const size_t ft = (size_t)f * T + t;
-            const int2 *__restrict__ erow = tb.ent + ft * (size_t)tb.stride + i0;
-            const int avail = tb.stride - i0;                // (a taller triangle flagged the frame in k_tri_table: never read past its block)
+            const int tn = s_cand_tn[c], t = tn & 0xffff, n = (int)((uint32_t)tn >> 16), ylo = s_cand_y[c];
+            if (n >= 0xffff) { atomicAdd(&s_cnt[0], 1 << 20); continue; }      // (absurd reach: the count check below fails, the map path takes the frame)
+            if (jj >= n) continue;
+            const Seg *__restrict__ sg = gseg + (size_t)t * 3;
             const float4 ma = *reinterpret_cast<const float4 *>(ginv + (size_t)t * kInvStride);
             const float2 mb = *reinterpret_cast<const float2 *>(ginv + (size_t)t * kInvStride + 4);
-            for (int j = jj; j < n && j < avail; j += 8) {
-                const int2 e = erow[j];
-                if (e.x >= e.y) continue;
-                const int64_t k = e.x, fin = e.y;
-                for (int row = 0; row < nrows; row++) {
-                    const int64_t rb = (int64_t)(r0 + row) * W;
-                    const int64_t lo = (k > rb ? k : rb) - rb, hi = (fin < rb + W ? fin : rb + W) - rb;
+            for (int j = jj; j < n; j += lpc) {
+                const int ys = ylo + j;
+                const double y = (double)ys;
+                // predictXLimits :1172-1197, the lean form of span_cells (hg_math.h; same comparisons, same division, same results for
+                // every input -- NaN compares false and leaves mn / mx alone, a division by m = 0 is computed and discarded)
+                double mn = INFINITY, mx = -INFINITY;
+                auto edge = [&](const Seg &q) {
+                    const double x = q.m == INFINITY ? q.b : (y - q.b) / q.m;
+                    const bool use = (y >= q.minY) & (y <= q.maxY) & !(q.m == 0.0);
+                    mn = (use & (x < mn)) ? x : mn;
+                    mx = (use & (x > mx)) ? x : mx;
+                };
+                if constexpr (SELF == 2) {                  // small frame sets: one round trip for all three edge equations (72 VGPRs, which
+                    const Seg q0 = sg[0], q1 = sg[1], q2 = sg[2];       // a launch that does not fill the chip can afford)
+                    edge(q0); edge(q1); edge(q2);
+                } else {
+                    // one edge at a time: with all three in flight the prologue would need 14 registers more than the pixel loop does
+                    // (72 instead of 56-58: 7 waves per SIMD instead of 8)
+#pragma unroll 1
+                    for (int e = 0; e < 3; e++) edge(sg[e]);
+                }
+                // the two flat fill() indices :1124 = (y - yOffset) * W + Math.round(x) under TypedArray.fill's index rules: NaN -> 0,
+                // trunc, negative counts from the end, clamp to [0, len] (js_fill_index, hg_math.h; maxNum / minNum absorb the NaN)
+                const double base = (y - (double)fd.y_off) * fW;
+                double rk = floor(mn); rk += (mn - rk >= 0.5) ? 1.0 : 0.0;      // Math.round (floor of +-Inf / NaN / |x| >= 2^52 is the value itself)
+                double rf = floor(mx); rf += (mx - rf >= 0.5) ? 1.0 : 0.0;
+                double vk = trunc(base + rk), vf = trunc(base + rf);
+                vk = vk < 0.0 ? flen + vk : vk; vf = vf < 0.0 ? flen + vf : vf;
+                const int k = (int)fmin(fmax(vk, 0.0), flen), fin = (int)fmin(fmax(vf, 0.0), flen);
+                if (k >= fin) continue;
+                // usual case: the span sits in output row (y - yOff) (+objH when it wrapped); otherwise divide
+                int r = ys - fd.y_off;
+                if (r < 0) r += fd.obj_h;
+                if ((unsigned)r >= (unsigned)fd.obj_h || (unsigned)(k - r * W) >= (unsigned)W) r = k / W;
+                if (r < r0) r = r0;                          // (pieces in rows above the group belong to other workgroups)
+                for (; r < r0 + nrows; r++) {
+                    const int rb = r * W;
+                    if (rb >= fin) break;
+                    const int lo = max(k - rb, 0), hi = min(fin - rb, W);
                     if (lo >= hi) continue;
+                    const int row = r - r0;
                     const int slot = atomicAdd(&s_cnt[row], 1);
                     if (slot >= capr) continue;
                     const int at = (packed ? row * 64 : 0) + slot;
-                    const double y = (double)(r0 + row + fd.y_off);
-                    s_lo[at] = (int)lo; s_hi[at] = (int)hi; s_len[at] = (int)(hi - lo); s_key[at] = (t << KS) | (at * 48);
+                    const double yr = (double)(r + fd.y_off);
+                    s_lo[at] = lo; s_hi[at] = hi; s_len[at] = hi - lo; s_key[at] = (t << KS) | (at * 48);
                     double2 *mrec = reinterpret_cast<double2 *>(s_m + at * 6);
-                    mrec[0] = make_double2((double)ma.x, (double)ma.z * y);      // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
+                    mrec[0] = make_double2((double)ma.x, (double)ma.z * yr);     // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
                     mrec[1] = make_double2((double)mb.x, (double)ma.y);
-                    mrec[2] = make_double2((double)ma.w * y, (double)mb.y);
+                    mrec[2] = make_double2((double)ma.w * yr, (double)mb.y);
                 }
             }
         }
@@ -753,8 +714,8 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // One window per wave iteration.  Measured alternatives: two windows in flight per wave (74 VGPRs, 6
     // waves/SIMD) and a phased variant (4 windows resolved, then 16 gathers, then 16 stores) are both ~4 % slower: with
     // 8 waves/SIMD the other waves already cover a window's memory latency, and reads + writes together run at ~5.2 TB/s.
-    if (TBL) {
-        if (!table_prologue()) {                             // more candidates / spans than the LDS holds: the host redoes the frame through the map
+    if (SELF) {
+        if (!self_prologue()) {                             // more candidates / spans than the LDS holds: the host redoes the frame through the map
             if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
             return;
         }
@@ -775,11 +736,11 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     }
 }
 
-template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, bool TBL = false>
-__global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, TriTable tb, uint8_t *__restrict__ out, int16_t *__restrict__ map_out,
+template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, int SELF = 0>
+__global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int16_t *__restrict__ map_out,
                                                  int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
 {
-    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, TBL>(mesh, fr, rl, tb, out, map_out, groups_per_xcd, rows_per_group, status_next);
+    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, SELF>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
 }
 
 // The same kernel held to 80 SGPRs.  A 256-thread workgroup puts one wave on each SIMD and a SIMD has 800 SGPRs, allocated in
@@ -787,11 +748,11 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
 // 8; capped, ~20 scalars move into VGPR lanes and 8 workgroups fit.  Measured on one box (round 3): with a shared,
 // cache-resident source (instruction-bound) 2 windows per phase 0.555 -> 0.543 ms on C3; with one source per frame (HBM-bound) the
 // extra waves LOSE 1-3 %, and C4's 4-windows-per-phase layout loses 6 % -- so only the shared-source PH = 2 layout takes it.
-template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, bool TBL = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_pw_rows_s80(PwMesh mesh, PwFrames fr, RowLists rl, TriTable tb, uint8_t *__restrict__ out,
+template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, int SELF = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_pw_rows_s80(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
 {
-    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, TBL>(mesh, fr, rl, tb, out, map_out, groups_per_xcd, rows_per_group, status_next);
+    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, SELF>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -847,17 +808,7 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
     else            hipLaunchKernelGGL((k_tri_spans<NoExperiment, false>), grid, block, 0, stream, mesh, fr, rl);
 }
 
-void launch_tri_table(const PwMesh &mesh, const PwFrames &fr, const TriTable &tb, hipStream_t stream)
-{
-    if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
-    const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads == 64 ? 64 : 128);
-#ifdef HG_EXPERIMENTS
-    if (launch_tri_table_ablated(mesh, fr, tb, grid, block, stream)) return;
-#endif
-    hipLaunchKernelGGL(k_tri_table<NoExperiment>, grid, block, 0, stream, mesh, fr, tb);
-}
-
-void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, const TriTable &tb, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
+void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
 {
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
     const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
@@ -870,19 +821,20 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     // one-row workgroups of a SMALL frame set may run with 2 waves instead of 4 (option rows1_threads; measured round 3: no gain)
     const dim3 block(rg == 1 && fr.rows1_threads == 128 ? 128 : 256);
     const size_t pad = (size_t)fr.lds_pad_kb * 1024;
-#define HG_ROWS(CAP, MAPF, PHV, CMP, HB, TB) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB, TB>), grid, block, pad, stream, mesh, fr, rl, tb, out, map_out, rpx, rg, status_next)
-#define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true, false); else HG_ROWS(CAP, false, 1, CMP, false, false); } while (0)
-    if (tb.ent) {                                            // spans from k_tri_table (sparse meshes, 32-byte-entry territory: CAP 256, no row lists)
-        if (map_out) { HG_ROWS(kRowSpanCapFast, true, 1, false, false, true); return; }
-        if (!hib) { HG_ROWS(kRowSpanCapFast, false, 1, false, false, true); return; }
+#define HG_ROWS(CAP, MAPF, PHV, CMP, HB, SF) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
+#define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true, 0); else HG_ROWS(CAP, false, 1, CMP, false, 0); } while (0)
+    if (fr.self_spans) {                                     // spans evaluated by the row workgroups themselves (sparse meshes: CAP 256, no row lists, k_tri_setup in front)
+        if (map_out) { HG_ROWS(kRowSpanCapFast, true, 1, false, false, 1); return; }
+        if (!hib) { HG_ROWS(kRowSpanCapFast, false, 1, false, false, 1); return; }
+        if (fr.self_spans == 2) { HG_ROWS(kRowSpanCapFast, false, 2, false, true, 2); return; }      // small frame sets: the short-latency prologue
         switch (fr.phase) {
-        case 4:  HG_ROWS(kRowSpanCapFast, false, 4, false, true, true); break;
+        case 4:  HG_ROWS(kRowSpanCapFast, false, 4, false, true, 1); break;
         case 2:
-            if (fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true, true>), grid, block, pad, stream,
-                                                mesh, fr, rl, tb, out, map_out, rpx, rg, status_next);
-            else HG_ROWS(kRowSpanCapFast, false, 2, false, true, true);
+            if (fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true, 1>), grid, block, pad, stream,
+                                                mesh, fr, rl, out, map_out, rpx, rg, status_next);
+            else HG_ROWS(kRowSpanCapFast, false, 2, false, true, 1);
             break;
-        default: HG_ROWS(kRowSpanCapFast, false, 1, false, true, true); break;
+        default: HG_ROWS(kRowSpanCapFast, false, 1, false, true, 1); break;
         }
         return;
     }
@@ -899,13 +851,13 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
 #ifdef HG_EXPERIMENTS
     // Timing experiments of DESIGN.md §6 (ablated variants produce WRONG pixels): only in the separate experiments build
     // (`make experiments` -> lib/libhgwarp_exp.so); the shipped library has neither the instantiations nor the switch.
-    if (launch_pw_rows_ablated(mesh, fr, rl, tb, out, map_out, rpx, rg, status_next, grid, stream)) return;     // experiments/hg_ablate.h
+    if (launch_pw_rows_ablated(mesh, fr, rl, out, map_out, rpx, rg, status_next, grid, stream)) return;     // experiments/hg_ablate.h
 #endif
     switch (fr.phase) {
     case 4:  HG_ROWS_B(kRowSpanCapFast, 4, false); break;
     case 2:
         if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true, false>), grid, block, pad, stream,
-                                                   mesh, fr, rl, tb, out, map_out, rpx, rg, status_next);
+                                                   mesh, fr, rl, out, map_out, rpx, rg, status_next);
         else HG_ROWS_B(kRowSpanCapFast, 2, false);
         break;
     default: HG_ROWS_B(kRowSpanCapFast, 1, false); break;

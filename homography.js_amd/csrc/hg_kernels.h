@@ -72,6 +72,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t lds_pad_patch_kb;       // the same for k_pw_patch (explicit option only: it loses with fewer workgroups)
     int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only
     int32_t no_hi_bounds;           // option "hi_bounds" = 0: keep the fp64 bounds compares (parity suite runs both forms)
+    int32_t self_spans;             // 1 / 2 (small frame sets: the prologue with all three edge equations in flight): no row lists -- k_tri_setup ran, k_pw_rows<SELF> evaluates the spans of its own rows in its prologue
 };
 
 // Per-output-row span lists of the fast path (k_tri_spans -> k_pw_rows), in global memory.
@@ -94,10 +95,6 @@ struct RowLists {
     int32_t cap;             // entries per row
 };
 
-// Spans of the table path (k_tri_table -> k_pw_rows<TBL>): tbl[frame][triangle][y - y_first] = cells {k, fin} row y of the triangle
-// writes (after TypedArray.fill's index rules; {0, 0} = nothing), `stride` entries per triangle.  ent == nullptr: row lists.
-struct TriTable { int2 *ent; int32_t stride; };
-
 // k_tri_setup: per (frame, triangle): forward affine (:785-804, :1265-1306), its inverse (:1036-1038, :1345-1365),
 // edge equations (:1141-1151) and row range (:1113-1115).
 void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream);
@@ -110,8 +107,7 @@ void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16
 // Fast path (see hg_k_piecewise.hip): eligibility, span-list build (includes the per-triangle solves), row warp.
 bool pw_fast_ok(const PwMesh &mesh, int max_obj_w);
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream);
-void launch_tri_table(const PwMesh &mesh, const PwFrames &fr, const TriTable &tb, hipStream_t stream);
-void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, const TriTable &tb, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream);
+void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream);
 // Dense meshes (64..199 spans per row, obj_w <= 8192): 4 rows per workgroup, 16 x 4 pixel gather patches, one matrix record
 // per triangle of the group.  Same row lists, same status protocol as launch_pw_rows; no map tap.
 // (limits on the HOST ESTIMATES, which run ~10 % above the real counts the kernel enforces: 199 spans per row, 208 triangles

@@ -260,8 +260,9 @@ int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, 
 /* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
  * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general). */
 int hg_last_piecewise_kernel(hg_ctx *ctx);
-/* 1 if that run took its spans from the per-triangle span table (k_tri_table: no row lists, no slot atomics), 0 if from row lists. */
-int hg_last_piecewise_table(hg_ctx *ctx);
+/* 1 if that run's row workgroups evaluated their own spans (k_tri_setup + k_pw_rows<SELF>: no row lists, no slot atomics, option
+ * "self_spans"), 0 if they read the per-output-row span lists of k_tri_spans. */
+int hg_last_piecewise_self(hg_ctx *ctx);
 /* Which kernels ran the last forward warp: 0 = none yet, 1 = scatter (atomicMax on a winner buffer) + gather, 2 = the
  * tile-binned gather (output tiles gather their source pixels, winners resolved in LDS, one or two launches for the whole
  * batch): k_fwd_tiles for affine / projective matrices that pass the admissibility bounds, k_fwd_pw_bins + k_fwd_pw_tiles
@@ -287,10 +288,10 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "phase" (default -1 = 2 for a shared source -- 4 when the rows carry 3 or more spans per window --, 1 with one source per frame):
  *           windows per k_pw_rows gather/store phase, 1, 2 or 4;
  *   "geo_windows" (default 8): 256-pixel windows per wave of the affine / projective kernel, 1, 2, 4 or 8;
- *   "table" (default off; 1 = whenever eligible: sparse meshes of up to 1024 triangles): the producer kernel writes every
- *           triangle's row spans into a per-triangle table (coalesced stores, no slot atomics: k_tri_table) and the warp kernel's
- *           workgroups pick the triangles that reach their rows from the per-triangle row / column reach, instead of reading
- *           per-output-row span lists.  Bit-identical; measured slower end to end on this part, kept as an option;
+ *   "self_spans" (default -1 = by policy; 1 = whenever eligible: sparse meshes of up to 1024 triangles; 0 never): no span
+ *           producer kernel and no per-output-row span lists -- k_tri_setup writes every triangle's edge equations, inverse matrix
+ *           and row reach, and each row workgroup of the warp kernel picks the triangles that reach its rows and evaluates
+ *           predictXLimits + the fill() indices for exactly those rows in its prologue.  Bit-identical;
  *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
  *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
  *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;
@@ -303,7 +304,16 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "xcc_rotate" (default -1 = by estimate): 1: XCD x walks row band (x + frame) mod XCCs instead of band x -- even load where
  *           rows differ in cost or the frames share no source; 0: fixed bands (a shared source's band stays in that XCD's L2);
  *   "xcc" (default: hipDeviceAttributeNumberOfXccs of the device, 8 on an unpartitioned MI355X): number of XCCs the
- *           block id -> row band mapping of the warp kernels assumes; a power of two in 1..64. */
+ *           block id -> row band mapping of the warp kernels assumes; a power of two in 1..64;
+ *   "sgpr_cap" (default -1 = only with a shared source): 1 / 0: the k_pw_rows instantiation held to 80 scalar registers (8 instead
+ *           of 7 workgroups per CU) for the 2-windows-per-phase layout / never;
+ *   "tri_threads" (default -1 = by the triangles' height and the set size): 64, 128 or 256 threads per k_tri_spans workgroup;
+ *   "rows1_threads" (default -1 = 256): 128 or 256 threads per one-row k_pw_rows workgroup (small frame sets);
+ *   "col_split" (default -1 = 1): 1, 2 or 4 k_pw_rows workgroups per row group, each taking a contiguous share of its windows;
+ *   "lds_pad" (default -1 = 12-16 KB with one source per frame on 4-row groups, else 0): KB of unused dynamic LDS per k_pw_rows
+ *           workgroup, 0..40: fewer, deeper-queued workgroups per CU where the kernel is HBM-bound;
+ *   "fwd_tiles": see hg_last_forward_kernel.
+ * Unknown keys are refused (HG_ERR_INVALID). */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);
 /* Number of XCCs the ctx maps row bands to (what hg_create read from the device, or the "xcc" option). */
 int hg_xcc_count(const hg_ctx *ctx);

@@ -27,7 +27,7 @@ for t in range(trials):
     ctx.set_option("geo_windows", int(rng.choice([1, 2, 4, 8])))
     ctx.set_option("fwd_tiles", int(rng.choice([-1, 0, 1, 1])))
     ctx.set_option("hi_bounds", int(rng.choice([1, 1, 0])))
-    ctx.set_option("table", int(rng.choice([-1, 1, 0])))
+    ctx.set_option("self_spans", int(rng.choice([-1, 1, 0])))
     ctx.set_option("xcc_rotate", int(rng.choice([-1, 0, 1])))
     ctx.set_option("tri_group", int(rng.choice([-1, 0, 16, 64])))
     ctx.set_option("compact", int(rng.choice([-1, -1, 0, 1])))

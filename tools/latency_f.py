@@ -2,7 +2,7 @@
 """Single-launch latency of small frame sets (F = 1, 2, 4, 8 4K frames of C3, device-resident in and out).
    python tools/latency_f.py            host view: ms per step with a sync after every step, and queued back to back
    rocprofv3 --kernel-trace -d DIR -o t -- python tools/latency_f.py --trace ; python tools/latency_f.py --parse DIR
-                                        device view: k_tri_spans start -> warp kernel end of the synced steps, and each kernel alone"""
+                                        device view: k_tri_spans / k_tri_setup start -> warp kernel end of the synced steps, and each kernel alone"""
 import glob, importlib.util, json, os, sqlite3, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -59,7 +59,7 @@ def parse(d):
     steps = []                                             # (tri_start, tri_end, warp_start, warp_end)
     i = 0
     while i + 1 < len(rows):
-        if "k_tri_spans" in rows[i][0] and ("k_pw_rows" in rows[i + 1][0] or "k_pw_patch" in rows[i + 1][0]):
+        if ("k_tri_spans" in rows[i][0] or "k_tri_setup" in rows[i][0]) and ("k_pw_rows" in rows[i + 1][0] or "k_pw_patch" in rows[i + 1][0]):
             steps.append((rows[i][1], rows[i][2], rows[i + 1][1], rows[i + 1][2], rows[i + 1][0])); i += 2
         else: i += 1
     per = 20 + REPS                                        # warmup + synced steps per F
