@@ -282,6 +282,8 @@ PwMesh mesh_of(const hg_ctx *c)
     return m;
 }
 
+static RowLists rows_of(const hg_ctx *c);
+
 PwFrames frames_of(const hg_ctx *c)
 {
     PwFrames f;
@@ -293,6 +295,11 @@ PwFrames frames_of(const hg_ctx *c)
     f.row_group = c->pw_row_group;
     f.tri_threads = c->pw_tri_threads;
     f.self_spans = c->pw_self ? (c->pw_small_set ? 2 : 1) : 0;       // (2: a launch that cannot fill the chip takes the short-latency prologue)
+    f.band_ent = nullptr; f.band_cnt = nullptr; f.band_stride = 0; f.n_bands = 0; f.band_cap = 0; f.band_rows_log2 = 6;
+    if (c->pw_self && c->pw_bands && c->d_rowcnt) {
+        const RowLists rl = rows_of(c);
+        f.band_ent = c->d_bands; f.band_cnt = rl.cnt; f.band_stride = rl.row_stride; f.n_bands = c->n_bands; f.band_cap = c->band_cap;
+    }
     // k_tri_spans_grouped where the per-workgroup solves of k_tri_spans dominate the producer (measured round 3, producer us, 64 frames of
     // 4K unless noted, k_tri_spans -> grouped 16 -> 64): 512 triangles 89 -> 68 -> 68, 3200: 222 -> 151 -> 114, 4608: 342 -> 238 -> 169,
     // C5 (8 frames of 5000) 80 -> 57 -> 57; but C3 (200 triangles of 216 rows) 47.7 -> 51.2 and C4 37.1 -> 38.7: their cost is the
@@ -356,7 +363,7 @@ static bool patch_preferred(const hg_ctx *c, bool *global_records)
 
 // per-frame solves; status words are reset first.  Fast path: k_tri_spans (solves + per-row span lists);
 // general path (more than 32767 triangles, huge sources, negative source minimum): k_tri_setup.
-static int run_setup(hg_ctx *c)
+static int run_setup(hg_ctx *c, bool for_tap = false)
 {
     const size_t F = c->pw_frames.size();
     int mw = 0;
@@ -364,22 +371,47 @@ static int run_setup(hg_ctx *c)
     c->pw_fast = pw_fast_ok(mesh_of(c), mw);
     if (c->pw_fast) {
         // entry format of the span lists (hg_kernels.h): 8 bytes for dense rows and whenever k_pw_patch will read them
-        const bool compact = c->opt_compact >= 0 ? c->opt_compact != 0 : (patch_preferred(c, nullptr) || c->pw_cover > 56);
+        bool global_records = false;
+        const bool want_patch = patch_preferred(c, &global_records) && !for_tap;     // (the parity tap passes a map: never k_pw_patch)
+        const bool compact = c->opt_compact >= 0 ? c->opt_compact != 0 : (want_patch || c->pw_cover > 56);
         if (compact != c->pw_compact) { c->pw_compact = compact; c->rows_clean = false; }
-        // Self-span path (k_tri_setup -> k_pw_rows<SELF>, round 4): sparse meshes -- where the row lists would carry 32-byte entries --
-        // whose triangles a workgroup can afford to scan (every row group tests all of them, 16 bytes each).  No producer kernel
-        // beyond the per-triangle solves, no lists, no slot atomics.  Layout choice only: what does not fit (more candidate
-        // triangles than the LDS list, more spans per row than a packed block holds) flags its frame -> map path, and the context
-        // returns to row lists for this mesh.  The prologue's int32 arithmetic wants windows below 2^24 rows near the origin.
+        // Self-span path (round 4): k_tri_setup in front (solves, edge equations, row reach), and the row workgroups of the warp kernel
+        // evaluate the spans of their own rows in their prologue.  No span producer kernel, no lists, no slot atomics.
+        //   * k_pw_rows<SELF>: sparse meshes -- where the row lists would carry 32-byte entries -- whose triangles a workgroup can afford
+        //     to scan (every row group tests all of them, 16 bytes each);
+        //   * k_pw_patch<SELF>: whatever that kernel takes (dense / sheared meshes, one source per frame); beyond 256 triangles the
+        //     workgroups scan the candidate band k_tri_setup filed for their rows instead of the whole mesh.
+        // Layout choice only: what does not fit (more candidate triangles than the LDS list, more spans per row than a block holds, an
+        // overfull band) flags its frame -> map path, and the context returns to row lists for this mesh.  The prologue's int32 arithmetic
+        // wants windows below 2^24 rows near the origin.
         bool small_geom = true;
-        for (const FrameDesc &d : c->pw_frames)
+        int max_h = 0;
+        for (const FrameDesc &d : c->pw_frames) {
             if (d.obj_w > 0 && d.obj_h > 0 && (d.obj_h > (1 << 24) || d.obj_w < 16 || std::abs((int64_t)d.y_off) > (1 << 26))) small_geom = false;
+            if (d.obj_w > 0) max_h = std::max(max_h, d.obj_h);
+        }
         // Policy (measured round 4, same box, row lists -> own spans): C3 x 64 frames step 0.624 -> 0.588 ms (warp kernel + 7 us, the 47 us
         // producer gone), C4 0.258 -> 0.236-0.242, 8 frames of C3 0.104 -> 0.093; a single 4K frame 22.8 -> 23.1 us per queued step (one
         // row per workgroup: every one of 2239 workgroups scans all triangles, and k_tri_setup's 4 us are one workgroup's dependent
         // chain): small frame sets keep the row lists unless the option forces it.
-        const bool self = !compact && !c->pw_self_disabled && (c->opt_self >= 0 ? c->opt_self == 1 : !c->pw_small_set) && c->row_cap <= kRowSpanCapFast &&
-                          c->n_tris <= 1024 && small_geom && (c->pw_row_group == 1 || c->pw_cover <= 56);
+        const bool self_ok = !c->pw_self_disabled && small_geom && (c->opt_self >= 0 ? c->opt_self == 1 : !c->pw_small_set);
+        const bool self_patch = self_ok && want_patch && !global_records && (c->n_tris <= 256 || c->pw_tri_rows_max > 0);
+        const bool self_rows = self_ok && !want_patch && !compact && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 && (c->pw_row_group == 1 || c->pw_cover <= 56);
+        c->pw_self_patch = self_patch;
+        c->pw_bands = self_patch && c->n_tris > 256;
+        if (c->pw_bands && (std::max(max_h, 1) + 63) / 64 > 2048) { c->pw_bands = false; c->pw_self_patch = false; }      // (kBandMax; frames taller than 131 072 rows)
+        if (c->pw_bands) {
+            // bands of 64 output rows; capacity from the tallest triangle of the frame set (host estimate; an overfull band flags its frame)
+            c->n_bands = (std::max(max_h, 1) + 63) / 64;
+            const double per_band = (double)c->n_tris * ((double)c->pw_tri_rows_max + 64.0 + 8.0) / (double)std::max(max_h, 64);
+            int cap = (int)std::min<double>((double)c->n_tris, std::max(256.0, 2.0 * per_band));
+            cap = (cap + 63) & ~63;
+            if (cap > c->band_cap) c->band_cap = cap;
+            const size_t need = F * (size_t)c->n_bands * (size_t)c->band_cap;
+            if (need > c->bands_cap) HG_TRY(hg_sync(c));
+            HG_TRY(ensure(c, c->d_bands, c->bands_cap, need));
+        }
+        const bool self = c->pw_self_patch || self_rows;
         // (its warp kernel neither reads nor zeroes the row counters: a change of path starts from freshly zeroed counter sets)
         if (self != c->pw_self) { c->pw_self = self; c->rows_clean = false; }
         RowLists rl = rows_of(c);
@@ -405,7 +437,7 @@ static int run_setup(hg_ctx *c)
         c->status_ptr = c->status_base + (size_t)c->status_slot * F;
         c->status_next = c->status_base + (size_t)((c->status_slot + 1) % (int)kStatusRing) * F;
         c->rows_clean = false;                               // dirty until the warp kernel has run: it consumes the counters and clears the next status set
-        if (c->pw_self) launch_tri_setup(mesh_of(c), frames_of(c), c->stream);     // solves, edge equations, row reach; the counters stay untouched (zero)
+        if (c->pw_self) launch_tri_setup(mesh_of(c), frames_of(c), c->stream);     // solves, edge equations, row reach (+ candidate bands, counted in the row counters' place)
         else            launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
     } else {
         HG_TRY(hg_sync(c));                                  // (queued fast-path runs are settled against their own status ring first)
@@ -421,7 +453,7 @@ static int run_setup(hg_ctx *c)
 static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
 {
     bool global_records = false;
-    const bool patch = patch_preferred(c, &global_records) && !map_out && c->pw_compact;
+    const bool patch = c->pw_self ? (c->pw_self_patch && !map_out) : (patch_preferred(c, &global_records) && !map_out && c->pw_compact);
     c->pw_used_patch = patch;
     c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
     if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
@@ -609,7 +641,7 @@ extern "C" int hg_sync(hg_ctx *c)
         if (c->status_base) HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < pending.size(); i++)
             for (size_t f = 0; f < F; f++)
-                if (c->h_status[(size_t)pending[i].slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; }
+                if (c->h_status[(size_t)pending[i].slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; c->pw_last_flag = c->h_status[(size_t)pending[i].slot * F + f]; }
         if (redo)
             HG_TRY(replay_queued(c, pending, [&](size_t) { return (int)F; },
                                  [&](size_t i, int f) { return c->h_status[(size_t)pending[i].slot * F + f] != FRAME_OK; },
@@ -741,7 +773,7 @@ extern "C" int hg_get_tri_map_fused(hg_ctx *c, int16_t *out, size_t len)
     HG_TRY(hg_sync(c));
     HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));
     HG_TRY(ensure(c, c->d_map16, c->map16_cap, n));
-    HG_TRY(run_setup(c));
+    HG_TRY(run_setup(c, true));
     run_warp(c, c->d_out_tmp, c->d_map16);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

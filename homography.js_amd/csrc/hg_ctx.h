@@ -75,6 +75,7 @@ struct hg_ctx {
     bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
     bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
+    int32_t pw_last_flag = 0;                                  // status word of the last frame a fused run flagged (bits 4..: which limit, see k_pw_patch<SELF>)
     long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
     int opt_min_row_groups = 1536, opt_patch = -1, opt_phase = -1, opt_geo_nw = 8;   // hg_set_option()
     int xcc_log2 = 3;                                          // log2(XCCs of the device): hipDeviceAttributeNumberOfXccs at hg_create, option "xcc"
@@ -112,6 +113,10 @@ struct hg_ctx {
     bool pw_small_set = false;                                 // fewer 4-row groups than "min_row_groups": one row per workgroup, short-latency prologues
     bool pw_self = false;                                      // the current step uses the self-span path
     bool pw_self_disabled = false;                             // a run on it flagged a frame (more candidates / spans than its LDS blocks hold): row lists for this mesh
+    bool pw_self_patch = false;                                // ... through k_pw_patch (dense / sheared meshes, one source per frame)
+    bool pw_bands = false;                                     // ... with candidate bands (meshes too large for every workgroup to scan)
+    int4 *d_bands = nullptr; size_t bands_cap = 0;             // F x n_bands x band_cap entries (hg_kernels.h)
+    int band_cap = 0, n_bands = 0;
     int opt_self = -1;                                         // option "self_spans": 1 whenever eligible, 0 never, -1 by policy (run_setup)
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
     int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate

@@ -26,8 +26,16 @@ static_assert(kPatchHash * 4 <= kPatchRows * kPatchBins * kPatchBinSlots, "the h
 // records in LDS at all -- a pixel reads its triangle's inverse matrix (6 floats, the tap array k_tri_spans fills, L2
 // resident) from global memory and widens it itself; the LDS then holds 4 x 512 spans (30.4 KB, five workgroups per CU).
 constexpr int kPatchCapDense = 512;
+// SELF: one record per CANDIDATE triangle of the group -- the triangles whose row range reaches it, a slightly larger set than the
+// triangles with a span in it (a triangle's last partial row, chunked entries at the window borders); 30.8 KB, five workgroups per CU,
+// which is what the 86 registers of the 8-blocks-per-phase main loop allow anyway
+constexpr int kPatchRecsSelf = 288;
 
-template <bool GLOBALREC, bool HIB, int PB = 1>      // PB: column blocks whose gathers are in flight before the first is stored
+// SELF (round 4): no row lists behind this kernel -- k_tri_setup ran, and the workgroup evaluates the spans of its four rows itself, like
+// k_pw_rows<SELF> (hg_k_piecewise.hip): candidates from the frame's per-triangle row reach (scanned directly, or -- large meshes --
+// from the entries k_tri_setup filed under this band of rows), one matrix record per CANDIDATE (no hash table: a candidate is a
+// triangle), 4 lanes per candidate evaluating predictXLimits + the fill() indices of one source row each.
+template <bool GLOBALREC, bool HIB, int PB = 1, bool SELF = false>      // PB: column blocks whose gathers are in flight before the first is stored
 __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                   int groups_per_xcd, int32_t *__restrict__ status_next)
 {
@@ -43,7 +51,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     if ((int)threadIdx.x < kPatchRows && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
-    __shared__ __align__(16) double s_rec[GLOBALREC ? 6 : (kPatchRecs + 1) * 6];   // {m0, m2, m4, m1, m3, m5} per triangle; last = NaN record
+    constexpr int RECS = SELF ? kPatchRecsSelf : kPatchRecs;
+    __shared__ __align__(16) double s_rec[GLOBALREC ? 6 : (RECS + 1) * 6];   // {m0, m2, m4, m1, m3, m5} per triangle; last = NaN record
     __shared__ uint32_t s_lohi[kPatchRows * CAPR];                          // span cells [lo, hi) of the row, 16 bits each
     __shared__ int s_key[kPatchRows * CAPR];                                // id << 14 | byte offset of the triangle's record (GLOBALREC: the id)
     __shared__ int s_bincnt[kPatchRows * kPatchBins];
@@ -55,8 +64,124 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     const int W = fd.obj_w;
     const int nbins = (W + 63) >> 6;
     const int nrows = min(kPatchRows, fd.obj_h - r0);
-    const int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
+    const float *__restrict__ ginv0 = fr.inv + (size_t)f * mesh.n_tris * kInvStride;     // this frame's inverse matrices (tap array)
     int cnts[kPatchRows], cmax = 0;
+    bool bad1;
+    if constexpr (SELF) {
+        static_assert(!GLOBALREC, "the self-span prologue keeps one record per candidate in LDS");
+        __shared__ int s_ncand, s_rowcnt[kPatchRows];
+        int *s_cand_tn = reinterpret_cast<int *>(s_tile), *s_cand_y = s_cand_tn + RECS;      // (the transpose tiles are idle until the main loop)
+        static_assert(2 * RECS <= 4 * kPatchRows * kPatchTilePitch, "candidate list fits the tile area");
+        for (int i = threadIdx.x; i < kPatchRows * kPatchBins; i += 256) s_bincnt[i] = 0;
+        if (threadIdx.x < kPatchRows) s_rowcnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { s_ncand = 0; s_fail = nbins > kPatchBins ? 1 : 0; }
+        if (threadIdx.x < 3) reinterpret_cast<double2 *>(s_rec + RECS * 6)[threadIdx.x] = make_double2(NAN, NAN);
+        __syncthreads();
+        // (1) candidates: can a row of the triangle write into rows r0 .. r0 + nrows - 1?  (see k_pw_rows<SELF>; int32 throughout)
+        const int lane_ = threadIdx.x & 63;
+        const int g_lo = r0 + fd.y_off, g_hi = r0 + nrows - 1 + fd.y_off;
+        const int T = mesh.n_tris;
+        int n_src = T;
+        const int4 *__restrict__ bent = nullptr;
+        if (fr.band_ent) {
+            const int band = r0 >> fr.band_rows_log2;
+            n_src = min(fr.band_cnt[(size_t)f * fr.band_stride + band], fr.band_cap);      // (an overfull band flagged the frame in k_tri_setup)
+            bent = fr.band_ent + ((size_t)f * fr.n_bands + band) * fr.band_cap;
+        }
+        const TriRange *__restrict__ trir = fr.trir + (size_t)f * T;
+        for (int i0 = 0; i0 < n_src; i0 += 256) {
+            const int i = i0 + (int)threadIdx.x;
+            int t = i; TriRange tr = TriRange{0, 0, 0, 0};
+            if (i < n_src) {
+                if (bent) { const int4 e = bent[i]; t = e.x; tr.y_min = e.y; tr.y_end = e.z; tr.a = (int16_t)(e.w & 0xffff); tr.b = e.w >> 16; }
+                else tr = trir[i];
+            }
+            const int ylo0 = max(g_lo - tr.a, tr.y_min), n0 = min(g_hi - tr.b, tr.y_end - 1) - ylo0 + 1;
+            const int ylo1 = max(g_lo - tr.a - fd.obj_h, tr.y_min), n1 = min(g_hi - tr.b - fd.obj_h, tr.y_end - 1) - ylo1 + 1;
+            const unsigned long long m0 = __ballot(n0 > 0), m1 = __ballot(n1 > 0);
+            if ((m0 | m1) == 0ull) continue;                // (wave-uniform)
+            const unsigned long long m0b = __ballot(n0 > 4), m1b = __ballot(n1 > 4);
+            const int c0 = __popcll(m0), c0b = __popcll(m0b), c1 = __popcll(m1), c1b = __popcll(m1b);
+            int base = 0;
+            if (lane_ == 0) base = atomicAdd(&s_ncand, c0 + c0b + c1 + c1b);
+            base = __builtin_amdgcn_readfirstlane(base);
+            auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+            auto file = [&](int at, int y0, int n) { if (at < RECS) { s_cand_tn[at] = t | (min(n, 0xffff) << 16); s_cand_y[at] = y0; } };
+            if (n0 > 0) file(base + below(m0), ylo0, min(n0, 4));
+            if (n0 > 4) file(base + c0 + below(m0b), ylo0 + 4, n0 - 4);
+            if (m1) {
+                if (n1 > 0) file(base + c0 + c0b + below(m1), ylo1, min(n1, 4));
+                if (n1 > 4) file(base + c0 + c0b + c1 + below(m1b), ylo1 + 4, n1 - 4);
+            }
+        }
+        __syncthreads();
+        const int nc = s_ncand;
+        if (nc > RECS) { if (threadIdx.x == 0) s_fail = 1 | (nc << 8); }
+        // (2) spans: 4 lanes per candidate entry, one source row each; lane 0 of the entry also writes the candidate's matrix record
+        const double flen = (double)((int64_t)W * fd.obj_h), fW = (double)W;      // (len < 2^31: fill_frames)
+        const Seg *__restrict__ gseg = fr.segs + (size_t)f * T * 3;
+        if (nc <= RECS) for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int c = c0 + ((int)threadIdx.x >> 2), jj = threadIdx.x & 3;
+            if (c >= nc) continue;
+            const int tn = s_cand_tn[c], t = tn & 0xffff, n = (int)((uint32_t)tn >> 16), ylo = s_cand_y[c];
+            if (n >= 0xffff) { s_fail = 1; continue; }      // (absurd reach: the map path takes the frame)
+            if (jj == 0) {
+                const float4 ma = *reinterpret_cast<const float4 *>(ginv0 + (size_t)t * kInvStride);
+                const float2 mb = *reinterpret_cast<const float2 *>(ginv0 + (size_t)t * kInvStride + 4);
+                double2 *mrec = reinterpret_cast<double2 *>(s_rec + c * 6);
+                mrec[0] = make_double2((double)ma.x, (double)ma.z);    // m0, m2
+                mrec[1] = make_double2((double)mb.x, (double)ma.y);    // m4, m1
+                mrec[2] = make_double2((double)ma.w, (double)mb.y);    // m3, m5
+            }
+            const Seg *__restrict__ sg = gseg + (size_t)t * 3;
+            for (int j = jj; j < n; j += 4) {
+                const int ys = ylo + j;
+                const double y = (double)ys;
+                double mn = INFINITY, mx = -INFINITY;       // predictXLimits :1172-1197 (the lean form of span_cells, see k_pw_rows<SELF>)
+                auto edge = [&](const Seg &q) {
+                    const double x = q.m == INFINITY ? q.b : (y - q.b) / q.m;
+                    const bool use = (y >= q.minY) & (y <= q.maxY) & !(q.m == 0.0);
+                    mn = (use & (x < mn)) ? x : mn;
+                    mx = (use & (x > mx)) ? x : mx;
+                };
+                if constexpr (PB >= 8) {                    // the 8-blocks-per-phase main loop holds 86 registers anyway: all three edge
+                    const Seg q0 = sg[0], q1 = sg[1], q2 = sg[2];       // equations in one round trip
+                    edge(q0); edge(q1); edge(q2);
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < 3; e++) edge(sg[e]);
+                }
+                const double base = (y - (double)fd.y_off) * fW;               // :1124 under TypedArray.fill's index rules
+                double rk = floor(mn); rk += (mn - rk >= 0.5) ? 1.0 : 0.0;
+                double rf = floor(mx); rf += (mx - rf >= 0.5) ? 1.0 : 0.0;
+                double vk = trunc(base + rk), vf = trunc(base + rf);
+                vk = vk < 0.0 ? flen + vk : vk; vf = vf < 0.0 ? flen + vf : vf;
+                const int k = (int)fmin(fmax(vk, 0.0), flen), fin = (int)fmin(fmax(vf, 0.0), flen);
+                if (k >= fin) continue;
+                int r = ys - fd.y_off;
+                if (r < 0) r += fd.obj_h;
+                if ((unsigned)r >= (unsigned)fd.obj_h || (unsigned)(k - r * W) >= (unsigned)W) r = k / W;
+                if (r < r0) r = r0;
+                for (; r < r0 + nrows; r++) {
+                    const int rb = r * W;
+                    if (rb >= fin) break;
+                    const int lo = max(k - rb, 0), hi = min(fin - rb, W);
+                    if (lo >= hi) continue;
+                    const int row = r - r0;
+                    const int slot = atomicAdd(&s_rowcnt[row], 1);
+                    if (slot >= CAPR - 1) continue;         // (counted: the check below fails the group)
+                    s_lohi[row * CAPR + slot] = (uint32_t)lo | ((uint32_t)hi << 16);
+                    s_key[row * CAPR + slot] = (t << kKeyShift) | (c * 48);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPatchRows; j++) { cnts[j] = j < nrows ? s_rowcnt[j] : 0; cmax = max(cmax, cnts[j]); }
+        bad1 = s_fail != 0 || cmax > CAPR - 1;
+        if (bad1 && threadIdx.x == 0 && s_fail == 0) s_fail = 2 | (cmax << 8);
+    } else {
+    const int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
 #pragma unroll
     for (int j = 0; j < kPatchRows; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
     for (int i = threadIdx.x; i < kPatchRows * kPatchBins; i += 256) s_bincnt[i] = 0;
@@ -67,7 +192,6 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
 
     // ---- phase 1: span lists -> LDS; each triangle of the group gets ONE matrix record (hash on the id: the thread that
     // claims the bucket writes the record and publishes its index; the others remember the bucket and read it later)
-    const float *__restrict__ ginv0 = fr.inv + (size_t)f * mesh.n_tris * kInvStride;     // this frame's inverse matrices (tap array)
     int my_bucket[(kPatchRows * CAPR + 255) / 256];
     int n_mine = 0;
     if (!bad0) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
@@ -103,16 +227,17 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
         }
         my_bucket[n_mine++] = bucket;
     }
-    if (!GLOBALREC && threadIdx.x < 3) reinterpret_cast<double2 *>(s_rec + kPatchRecs * 6)[threadIdx.x] = make_double2(NAN, NAN);
+    if (!GLOBALREC && threadIdx.x < 3) reinterpret_cast<double2 *>(s_rec + RECS * 6)[threadIdx.x] = make_double2(NAN, NAN);
     __syncthreads();
     // ---- phase 2: keys (id << 14 | record offset), once every record index is published
-    const bool bad1 = s_fail != 0;
+    bad1 = s_fail != 0;
     n_mine = 0;
     if (!GLOBALREC && !bad1) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
         const int bucket = my_bucket[n_mine++];
         if (bucket >= 0) s_key[e] = (s_key[e] << kKeyShift) | (int)(((s_hash[bucket] & 0xffffu) - 1u) * 48u);
     }
     if (!GLOBALREC) __syncthreads();
+    }
     // ---- phase 3: the hash table is dead, its memory becomes the bins: span index -> every 64-pixel column it overlaps
     if (!bad1) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
         const int rr = e / CAPR, i = e - rr * CAPR;
@@ -128,7 +253,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     }
     __syncthreads();
     if (s_fail) {                                           // the host redoes the frame through the materialised map
-        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+        // (SELF: bits 4.. say which limit -- 1 | candidates << 8, or 2 | longest row << 8 -- for whoever reads the status word in a debugger)
+        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW | (SELF ? (s_fail << 4) : 0));
         return;
     }
 
@@ -147,7 +273,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     const double by_lo = (double)mesh.min_src_y + 0.5, by_hi = (double)mesh.H + (double)mesh.min_src_y + 0.5;
     const HiBounds hb = make_hi_bounds(bx_lo, bx_hi, by_lo, by_hi);      // HIB: :1047 on the high dwords of h (hg_dev.h)
     const int pitch4 = mesh.W * 4;
-    const int nan_key = GLOBALREC ? -1 : ((int)0x80000000u | (kPatchRecs * 48));
+    const int nan_key = GLOBALREC ? -1 : ((int)0x80000000u | (RECS * 48));
     const int row_base = rr * CAPR;
     const int my_cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
     uint32_t *tile = s_tile + wave * (kPatchRows * kPatchTilePitch);
@@ -248,13 +374,21 @@ void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl,
     const int gpx = ((fr.max_obj_h + kPatchRows - 1) / kPatchRows + nx - 1) / nx;
     const dim3 grid((unsigned)gpx * (unsigned)nx * (unsigned)fr.n_frames);
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-#define HG_PATCH(G, HB, PBV) hipLaunchKernelGGL((k_pw_patch<G, HB, PBV>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, status_next)
-    if (global_records) { if (hib) HG_PATCH(true, true, 1); else HG_PATCH(true, false, 1); }
-    else if (!hib) HG_PATCH(false, false, 1);
-    else if (fr.patch_blocks >= 8) HG_PATCH(false, true, 8);  // (option "phase" / the layout policy: blocks per phase)
-    else if (fr.patch_blocks >= 4) HG_PATCH(false, true, 4);
-    else if (fr.patch_blocks >= 2) HG_PATCH(false, true, 2);
-    else HG_PATCH(false, true, 1);
+#define HG_PATCH(G, HB, PBV, SF) hipLaunchKernelGGL((k_pw_patch<G, HB, PBV, SF>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, status_next)
+    if (fr.self_spans && !global_records) {                  // own spans (k_tri_setup in front, no row lists)
+        if (!hib) HG_PATCH(false, false, 1, true);
+        else if (fr.patch_blocks >= 8) HG_PATCH(false, true, 8, true);
+        else if (fr.patch_blocks >= 4) HG_PATCH(false, true, 4, true);
+        else if (fr.patch_blocks >= 2) HG_PATCH(false, true, 2, true);
+        else HG_PATCH(false, true, 1, true);
+        return;
+    }
+    if (global_records) { if (hib) HG_PATCH(true, true, 1, false); else HG_PATCH(true, false, 1, false); }
+    else if (!hib) HG_PATCH(false, false, 1, false);
+    else if (fr.patch_blocks >= 8) HG_PATCH(false, true, 8, false);  // (option "phase" / the layout policy: blocks per phase)
+    else if (fr.patch_blocks >= 4) HG_PATCH(false, true, 4, false);
+    else if (fr.patch_blocks >= 2) HG_PATCH(false, true, 2, false);
+    else HG_PATCH(false, true, 1, false);
 #undef HG_PATCH
 }
 

@@ -9,12 +9,11 @@ namespace hg {
 // ------------------------------------------------------------------------------------------------ k_tri_setup
 // Per (frame, triangle).  Replaces _calculatePiecewiseAffineTransformMatrices :785-804, the inverseAffineMatrix loop
 // :1036-1038 and the per-triangle head of fillTriangle :1113-1118.
-__global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
+constexpr int kBandMax = 2048;                 // candidate bands per frame the filing below can aggregate in LDS (host: self-span path only below that)
+
+// One triangle of one frame: solves, edge equations, row range, column reach; returns false when the triangle has no rows or is irregular.
+__device__ __forceinline__ bool tri_setup_one(const PwMesh &mesh, const PwFrames &fr, int f, int t, const FrameDesc &fd, TriRange &tr)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = blockIdx.y;
-    if (t >= mesh.n_tris) return;
-    const FrameDesc fd = fr.frames[f];
     const float *dp = fr.dst_pts + (size_t)f * mesh.n_pts * 2;
     float s[6], d[6];
 #pragma unroll
@@ -43,18 +42,18 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
     define_seg(d[2], d[3], d[4], d[5], c);          // p1->p2
     sg[0] = a; sg[1] = b; sg[2] = c;
 
-    TriRange tr;
-    tri_rows(d[1], d[3], d[5], tr.y_min, tr.y_end);
+    tri_rows_tight(d[1], d[3], d[5], tr.y_min, tr.y_end);    // (without the leading row that cannot have a span, hg_math.h)
     tr.a = 0; tr.b = 0;
     const bool too_tall = (tr.y_end - (int64_t)tr.y_min) > (1 << 24);
     {   // rows that cannot write a cell are dropped from the range (hg_math.h): every consumer -- k_pw_fused, k_map_fill, the
-        // span prologue of k_pw_rows<SELF> -- walks [y_min, y_end) and none of those rows has a span
+        // span prologues of k_pw_rows<SELF> / k_pw_patch<SELF> -- walks [y_min, y_end) and none of those rows has a span
         int64_t y_first = tr.y_min, y_stop = tr.y_end;
         if (fd.obj_w > 0 && fd.obj_h > 0) clamp_rows(y_first, y_stop, fd.y_off, fd.obj_w, (int64_t)fd.obj_w * fd.obj_h);
         else y_stop = y_first;
         if (y_stop < y_first) y_stop = y_first;
         tr.y_min = (int32_t)y_first; tr.y_end = (int32_t)y_stop;
     }
+    bool regular = false;
     if (tr.y_end > tr.y_min && fd.obj_w > 0 && fd.obj_h > 0) {
         // Conservative cell extent of any span of this triangle relative to its row base (y - yOff) * W:
         // intersections lie between the vertex x's (+-1 for rounding).  Absurd / non-finite input or a triangle wider
@@ -74,8 +73,73 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
             }
         }
         if (irregular) atomicOr(&fr.status[f], FRAME_IRREGULAR);
+        regular = !irregular;
     }
     fr.trir[ft] = tr;
+    return regular;
+}
+
+__global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const FrameDesc fd = fr.frames[f];
+    TriRange tr = TriRange{0, 0, 0, 0};
+    const bool regular = t < mesh.n_tris && tri_setup_one(mesh, fr, f, t, fd, tr);
+    if (!fr.band_ent) return;                               // (uniform)
+
+    // Self-span path, large meshes: the triangle is filed under every band of output rows one of its spans can reach -- rows
+    // (y - yOff) + b .. + a for its rows y, and objH further down for spans whose fill() index wrapped (image 1).  Slots are handed
+    // out through LDS (two passes over the thread's bands: count, then file), one global atomic per (workgroup, band): a per-entry
+    // device-scope atomic on a few hundred counters cost 55 us on C5 and 150 us on 64 frames of 3200 triangles.
+    __shared__ int s_cnt[kBandMax], s_base[kBandMax];
+    const int nb = fr.n_bands;                              // (<= kBandMax: host)
+    for (int i = threadIdx.x; i < nb; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    int64_t lo0 = 1, hi0 = 0, lo1 = 1, hi1 = 0;
+    bool file = regular;
+    if (file) {
+        const int64_t H = fd.obj_h;
+        lo0 = (int64_t)tr.y_min - fd.y_off + tr.b; hi0 = (int64_t)tr.y_end - 1 - fd.y_off + tr.a;
+        lo1 = lo0 + H; hi1 = hi0 + H;
+        lo0 = lo0 < 0 ? 0 : lo0; hi0 = hi0 > H - 1 ? H - 1 : hi0;
+        lo1 = lo1 < 0 ? 0 : lo1; hi1 = hi1 > H - 1 ? H - 1 : hi1;
+        if (lo1 <= hi1 && lo0 <= hi0 && lo1 <= hi0 + 1) { hi0 = hi1 > hi0 ? hi1 : hi0; lo0 = lo1 < lo0 ? lo1 : lo0; hi1 = lo1 - 1; }      // overlapping: one range
+        if (tr.a < -32768 || tr.a > 32767 || tr.b < -32768 || tr.b > 32767) { atomicOr(&fr.status[f], FRAME_IRREGULAR); file = false; }
+    }
+    const int4 ent = make_int4(t, tr.y_min, tr.y_end, (tr.a & 0xffff) | (int)((uint32_t)tr.b << 16));
+    // (an image-1 range that shares a band with the image-0 range files the triangle twice there: harmless, a duplicate candidate
+    //  produces duplicate spans of the same id)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        if (file) {
+#pragma unroll 1
+            for (int image = 0; image < 2; image++) {
+                const int64_t lo = image ? lo1 : lo0, hi = image ? hi1 : hi0;
+                if (lo > hi) continue;
+                for (int band = (int)(lo >> fr.band_rows_log2); band <= (int)(hi >> fr.band_rows_log2); band++) {
+                    const int local = atomicAdd(&s_cnt[band], 1);
+                    if (pass == 1) {
+                        const int slot = s_base[band] + local;
+                        if (slot < fr.band_cap) fr.band_ent[((size_t)f * fr.n_bands + band) * fr.band_cap + slot] = ent;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            for (int i = threadIdx.x; i < nb; i += 256) {
+                const int n = s_cnt[i];
+                if (n > 0) {
+                    const int base = atomicAdd(&fr.band_cnt[(size_t)f * fr.band_stride + i], n);
+                    s_base[i] = base;
+                    if (base + n > fr.band_cap) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+                }
+                s_cnt[i] = 0;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_pw_fused
@@ -404,7 +468,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += nthreads) status_next[i] = 0;
     // (every row of the frame's counter block, not only the rows of THIS step's window: the other set was filled under the
     //  previous step's geometry, whose frame may have been a row taller)
-    if (!SELF && (int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
+    if ((int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
 
     __shared__ __align__(16) double s_m[CAP * 6];

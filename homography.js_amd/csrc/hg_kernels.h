@@ -72,7 +72,14 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t lds_pad_patch_kb;       // the same for k_pw_patch (explicit option only: it loses with fewer workgroups)
     int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only
     int32_t no_hi_bounds;           // option "hi_bounds" = 0: keep the fp64 bounds compares (parity suite runs both forms)
-    int32_t self_spans;             // 1 / 2 (small frame sets: the prologue with all three edge equations in flight): no row lists -- k_tri_setup ran, k_pw_rows<SELF> evaluates the spans of its own rows in its prologue
+    int32_t self_spans;             // 1 / 2 (small frame sets: the prologue with all three edge equations in flight): no row lists -- k_tri_setup ran, the
+                                    // warp kernel's workgroups evaluate the spans of their own rows in their prologue
+    // Candidate bands of the self-span path for meshes too large to scan per workgroup (k_tri_setup files every triangle under the
+    // bands of 1 << band_rows_log2 output rows it can reach; a row workgroup tests only its band's entries).  band_ent == nullptr:
+    // workgroups scan trir[frame][0 .. n_tris).  Counters: the row-counter arrays (unused without row lists), index frame * band_stride + band.
+    int4 *band_ent;                 // F x n_bands x band_cap entries {triangle, y_min, y_end, a & 0xffff | b << 16}
+    int32_t *band_cnt;
+    int32_t band_stride, n_bands, band_cap, band_rows_log2;
 };
 
 // Per-output-row span lists of the fast path (k_tri_spans -> k_pw_rows), in global memory.

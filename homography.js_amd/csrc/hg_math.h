@@ -227,6 +227,16 @@ HG_HD void tri_rows(double y0, double y1, double y2, int32_t &y_min, int32_t &y_
     y_end = top > 1073741824.0 ? 1073741824 : (top < -1073741824.0 ? -1073741824 : (int32_t)top);
 }
 
+// The rows of that loop that can have a span at all: predictXLimits :1179 only takes edges with minY <= y <= maxY, and every edge's
+// minY is at least the triangle's, so the loop's first row trunc(minY) is a no-op whenever minY is not an integer (mn = +Inf,
+// mx = -Inf -> fill(idx, len, 0)).  Consumers that enumerate candidate rows (the self-span prologues) start at ceil(minY).
+HG_HD void tri_rows_tight(double y0, double y1, double y2, int32_t &y_min, int32_t &y_end)
+{
+    tri_rows(y0, y1, y2, y_min, y_end);
+    const double mn = js_min2(js_min2(y0, y1), y2);
+    if (fabs(mn) < 1073741824.0) { const int32_t c = (int32_t)ceil(mn); if (c > y_min) y_min = c; }
+}
+
 // Rows of fillTriangle's loop that can overwrite a cell at all.  A row y writes cells (y - yOff) * W + round(x) (after
 // TypedArray.fill's index rules: indices <= -len and >= len write nothing) with x between the triangle's vertex x's, and
 // the library only accepts coordinates up to kMaxCoord in magnitude (hg_piecewise_set_frames / _set_mesh; NaN vertices
