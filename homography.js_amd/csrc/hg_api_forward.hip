@@ -74,7 +74,6 @@ extern "C" int hg_warp_forward_geometric_batch_device(hg_ctx *c, int kind, const
     HG_TRY(bind(c));
     if ((kind != HG_AFFINE && kind != HG_PROJECTIVE) || !m || !geoms || n <= 0 || !d_out) return fail(c, HG_ERR_INVALID, "hg_warp_forward_geometric: bad arguments");
     if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
-    if (c->n_imgs > 1) return fail(c, HG_ERR_STATE, "the forward warps take ONE source image (hg_set_images_device with n_images > 1 serves the inverse warps only)");
     HG_TRY(forward_limits(c, c->W, c->H, "the source image"));
     std::vector<FrameDesc> fds;
     HG_TRY(fill_frames(c, fds, geoms, offs, n));
@@ -112,7 +111,7 @@ extern "C" int hg_warp_forward_geometric_batch_device(hg_ctx *c, int kind, const
                 batch.params = reinterpret_cast<const FwdParam *>(c->d_fwd_par);
                 batch.frames = reinterpret_cast<const FrameDesc *>(c->d_fwd_par + sizeof(FwdParam) * n);
             }
-            launch_fwd_tiles(kind, batch, n, mw, mh, c->d_img, c->W, c->H, static_cast<uint8_t *>(d_out), c->stream);
+            launch_fwd_tiles(kind, batch, n, mw, mh, c->d_img, c->n_imgs, c->img_stride, c->W, c->H, static_cast<uint8_t *>(d_out), c->stream);
             HIP_TRY(c, hipGetLastError());
             c->fwd_last_kernel = 2;
             return HG_OK;
@@ -125,7 +124,7 @@ extern "C" int hg_warp_forward_geometric_batch_device(hg_ctx *c, int kind, const
     HIP_TRY(c, hipStreamSynchronize(c->stream));         // caller memory is not retained
     c->geo_frames.clear();                               // the uploaded geometric frame set was overwritten
     for (int f = 0; f < n; f++)                          // frames run back to back on the stream (one winner buffer, reused in order)
-        launch_fwd_geo(kind, c->d_mats + 8 * (size_t)f, c->d_img, c->W, c->H, fds[f], c->d_win32, static_cast<uint8_t *>(d_out), c->stream);
+        launch_fwd_geo(kind, c->d_mats + 8 * (size_t)f, frame_img(mesh_of(c), f), c->W, c->H, fds[f], c->d_win32, static_cast<uint8_t *>(d_out), c->stream);
     HIP_TRY(c, hipGetLastError());
     return HG_OK;
 }
@@ -185,7 +184,6 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
     HG_TRY(bind(c));
     if (!dst_points || !geoms || n <= 0 || !d_out) return fail(c, HG_ERR_INVALID, "hg_warp_forward_piecewise: bad arguments");
     if (!c->d_img) return fail(c, HG_ERR_STATE, "no source image: call hg_set_image first");
-    if (c->n_imgs > 1) return fail(c, HG_ERR_STATE, "the forward warps take ONE source image (hg_set_images_device with n_images > 1 serves the inverse warps only)");
     if (!c->have_mesh) return fail(c, HG_ERR_STATE, "no mesh: call hg_piecewise_set_mesh first");
     const int64_t map_w = (int64_t)max_src_x - c->min_src_x, map_h = (int64_t)max_src_y - c->min_src_y;
     HG_TRY(forward_limits(c, map_w, map_h, "the source-point bounding box"));
@@ -260,7 +258,7 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
             p.tile_cnt = c->d_ftile_cnt; p.tile_ent = c->d_ftile_ent; p.status = c->d_fwd_status + (size_t)c->fwd_slot * c->fwd_status_stride;
             p.T = c->n_tris; p.min_src_x = c->min_src_x; p.min_src_y = c->min_src_y; p.map_w = (int)map_w; p.map_h = (int)map_h;
             p.tsx = tsx; p.tsy = tsy; p.cap = c->fwd_pw_cap;
-            launch_fwd_pw_tiles(p, n, mw, mh, c->d_img, c->W, c->H, static_cast<uint8_t *>(d_out), c->stream);
+            launch_fwd_pw_tiles(p, n, mw, mh, c->d_img, c->n_imgs, c->img_stride, c->W, c->H, static_cast<uint8_t *>(d_out), c->stream);
             HIP_TRY(c, hipGetLastError());
             { hg_ctx::FwdPending fp;
               fp.out = static_cast<uint8_t *>(d_out); fp.n = n; fp.slot = c->fwd_slot; fp.stage = c->stage_cur; fp.max_src_x = max_src_x; fp.max_src_y = max_src_y;
@@ -273,7 +271,7 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
         HG_TRY(settle_output_conflicts(c, d_out, out_extent, 0));      // (this path keeps no pending record: nothing queued may be redone over it later)
         HG_TRY(ensure(c, c->d_win32, c->win32_cap, max_px));
         for (int f = 0; f < n; f++)
-            launch_fwd_pw(c->d_fmap, c->d_fwd + (size_t)f * c->n_tris * 6, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, (int)map_w, (int)map_h,
+            launch_fwd_pw(c->d_fmap, c->d_fwd + (size_t)f * c->n_tris * 6, frame_img(mesh_of(c), f), c->W, c->H, c->min_src_x, c->min_src_y, (int)map_w, (int)map_h,
                           c->pw_frames[f], c->d_win32, static_cast<uint8_t *>(d_out), c->stream);
     }
     HIP_TRY(c, hipGetLastError());

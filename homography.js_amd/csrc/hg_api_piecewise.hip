@@ -548,7 +548,7 @@ int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int ma
     fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
     fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
     launch_tri_setup(mesh_of(c), fr, c->stream);
-    launch_fwd_pw(c->d_fmap, c->d_redo_fwd, c->d_img, c->W, c->H, c->min_src_x, c->min_src_y, max_src_x - c->min_src_x, max_src_y - c->min_src_y,
+    launch_fwd_pw(c->d_fmap, c->d_redo_fwd, frame_img(mesh_of(c), f), c->W, c->H, c->min_src_x, c->min_src_y, max_src_x - c->min_src_x, max_src_y - c->min_src_y,
                   fd, c->d_win32, d_out, c->stream);
     HIP_TRY(c, hipGetLastError());
     return HG_OK;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_fwd_gather(const int32_t *__restrict__ 
 // the host only takes this path when no source pixel can land further out).  Then each cell copies its winner's pixel.
 // Traffic per frame: source once + output once (scatter path: + 4 x the winner buffer).
 template <int KIND, bool ONE>      // ONE: a single frame whose parameters travel in the kernel arguments (no upload, no sync)
-__global__ __launch_bounds__(256) void k_fwd_tiles(FwdBatch batch, const uint8_t *__restrict__ img, int W, int H, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k_fwd_tiles(FwdBatch batch, const uint8_t *__restrict__ img, int n_imgs, uint64_t img_stride, int W, int H, uint8_t *__restrict__ out)
 {
     __shared__ int s_win[kFwdTileW * kFwdTileH];
     __shared__ int s_xa[256], s_pre[256], s_wsum[4];
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void k_fwd_tiles(FwdBatch batch, const uint8_t
         }
     }
     __syncthreads();
-    const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(img);
+    // (one source per frame -- the loop `for (f) warp(frame_f)` -- : frame f reads image f mod n_imgs, like the inverse kernels)
+    const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(n_imgs > 1 ? img + (uint64_t)(f % n_imgs) * img_stride : img);
     uint32_t *__restrict__ o32 = reinterpret_cast<uint32_t *>(out + fd.out_off);
     const int cx = tid & (kFwdTileW - 1);
     for (int cy = tid >> 6; cy < ty1 - ty0; cy += 4) {
@@ -368,7 +369,7 @@ constexpr int kPwSegCap = 1024;            // segments per round (16 384 candida
 constexpr int kPwUnroll = 2;               // candidates in flight per lane (4: 70 VGPRs, 7 waves per SIMD; 2 with the cap below: 8)
 static_assert(kFwdPwCapMax <= kPwT && kPwT == 512, "row records carry the row's slot in 9 bits");
 
-__global__ __launch_bounds__(kPwT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fwd_pw_tiles(FwdPwTiles p, const uint8_t *__restrict__ img, int W, int H, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(kPwT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fwd_pw_tiles(FwdPwTiles p, const uint8_t *__restrict__ img, int n_imgs, uint64_t img_stride, int W, int H, uint8_t *__restrict__ out)
 {
     __shared__ uint32_t s_win[kFwdTileW * kFwdTileH];                  // 0 = no writer, else ((map row << 16) | map column) + 1
     __shared__ float s_m[kFwdPwCapMax][6];                             // (the matrices ARE floats: _trianglesTransforms is a Float32Array)
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(kPwT) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         }
     }
     __syncthreads();
-    const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(img);
+    const uint32_t *__restrict__ img32 = reinterpret_cast<const uint32_t *>(n_imgs > 1 ? img + (uint64_t)(f % n_imgs) * img_stride : img);      // (frame f reads image f mod n_imgs)
     uint32_t *__restrict__ o32 = reinterpret_cast<uint32_t *>(out + fd.out_off);
     const int cxl = tid & (kFwdTileW - 1);
     if (tx0 + cxl >= tx1) return;
@@ -551,16 +552,16 @@ void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, in
 }
 
 void launch_fwd_tiles(int kind, const FwdBatch &batch, int n_frames, int max_w, int max_h,
-                      const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream)
+                      const uint8_t *img, int n_imgs, uint64_t img_stride, int W, int H, uint8_t *out, hipStream_t stream)
 {
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     const dim3 grid((max_w + kFwdTileW - 1) / kFwdTileW, (max_h + kFwdTileH - 1) / kFwdTileH, n_frames);
     if (batch.params) {
-        if (kind == 0) hipLaunchKernelGGL((k_fwd_tiles<0, false>), grid, dim3(256), 0, stream, batch, img, W, H, out);
-        else           hipLaunchKernelGGL((k_fwd_tiles<1, false>), grid, dim3(256), 0, stream, batch, img, W, H, out);
+        if (kind == 0) hipLaunchKernelGGL((k_fwd_tiles<0, false>), grid, dim3(256), 0, stream, batch, img, n_imgs, img_stride, W, H, out);
+        else           hipLaunchKernelGGL((k_fwd_tiles<1, false>), grid, dim3(256), 0, stream, batch, img, n_imgs, img_stride, W, H, out);
     } else {
-        if (kind == 0) hipLaunchKernelGGL((k_fwd_tiles<0, true>), grid, dim3(256), 0, stream, batch, img, W, H, out);
-        else           hipLaunchKernelGGL((k_fwd_tiles<1, true>), grid, dim3(256), 0, stream, batch, img, W, H, out);
+        if (kind == 0) hipLaunchKernelGGL((k_fwd_tiles<0, true>), grid, dim3(256), 0, stream, batch, img, n_imgs, img_stride, W, H, out);
+        else           hipLaunchKernelGGL((k_fwd_tiles<1, true>), grid, dim3(256), 0, stream, batch, img, n_imgs, img_stride, W, H, out);
     }
 }
 
@@ -580,11 +581,11 @@ void launch_fmap_rowext(const int32_t *fmap, int map_w, int map_h, const int32_t
         hipLaunchKernelGGL(k_fmap_rowext, dim3((map_w + 32 * 256 - 1) / (32 * 256), map_h), dim3(256), 0, stream, fmap, map_w, map_h, bbox, rowoff, rowext, T);
 }
 
-void launch_fwd_pw_tiles(const FwdPwTiles &p, int n_frames, int max_w, int max_h, const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream)
+void launch_fwd_pw_tiles(const FwdPwTiles &p, int n_frames, int max_w, int max_h, const uint8_t *img, int n_imgs, uint64_t img_stride, int W, int H, uint8_t *out, hipStream_t stream)
 {
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     if (p.T > 0) hipLaunchKernelGGL(k_fwd_pw_bins, dim3((p.T + 3) / 4, n_frames), dim3(64, 4), 0, stream, p);
-    hipLaunchKernelGGL(k_fwd_pw_tiles, dim3(p.tsx, p.tsy, n_frames), dim3(kPwT), 0, stream, p, img, W, H, out);
+    hipLaunchKernelGGL(k_fwd_pw_tiles, dim3(p.tsx, p.tsy, n_frames), dim3(kPwT), 0, stream, p, img, n_imgs, img_stride, W, H, out);
 }
 
 void launch_fwd_pw(const int32_t *fmap, const float *fwd, const uint8_t *img, int W, int H, int min_src_x, int min_src_y, int map_w, int map_h,

@@ -152,8 +152,9 @@ struct FwdParam { double m[8]; double inv[9]; int32_t use_inv, pad; };
 constexpr int kFwdTileW = 64, kFwdTileH = 64, kFwdWrap = 32;
 // params == nullptr: one frame, carried by value (p0, f0) in the kernel arguments
 struct FwdBatch { const FwdParam *params; const FrameDesc *frames; FwdParam p0; FrameDesc f0; };
+// n_imgs / img_stride (all forward launchers that take them): frame f reads the source at img + (f % n_imgs) * img_stride
 void launch_fwd_tiles(int kind, const FwdBatch &batch, int n_frames, int max_w, int max_h,
-                      const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
+                      const uint8_t *img, int n_imgs, uint64_t img_stride, int W, int H, uint8_t *out, hipStream_t stream);
 // Tile-binned forward PIECEWISE warp: k_fmap_bbox (once per mesh: bounding box, in map cells, of the cells the forward
 // triangle map assigns to each matrix index), k_fwd_pw_bins (per frame and triangle: which output tiles its pixels can reach,
 // per aliasing shift k of the flat index; frames it cannot bound are flagged for the scatter path), k_fwd_pw_tiles (per tile:
@@ -169,7 +170,7 @@ struct FwdPwTiles {
 };
 void launch_fmap_bbox(const int32_t *fmap, int map_w, int map_h, int32_t *bbox, int T, hipStream_t stream);
 void launch_fmap_rowext(const int32_t *fmap, int map_w, int map_h, const int32_t *bbox, const uint32_t *rowoff, int32_t *rowext, size_t total_rows, int T, hipStream_t stream);
-void launch_fwd_pw_tiles(const FwdPwTiles &p, int n_frames, int max_w, int max_h, const uint8_t *img, int W, int H, uint8_t *out, hipStream_t stream);
+void launch_fwd_pw_tiles(const FwdPwTiles &p, int n_frames, int max_w, int max_h, const uint8_t *img, int n_imgs, uint64_t img_stride, int W, int H, uint8_t *out, hipStream_t stream);
 void launch_fwd_geo(int kind, const double *d_mat, const uint8_t *img, int W, int H, const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);
 void launch_fwd_pw(const int32_t *fmap, const float *fwd, const uint8_t *img, int W, int H, int min_src_x, int min_src_y, int map_w, int map_h,
                    const FrameDesc &fd, int32_t *win, uint8_t *out, hipStream_t stream);

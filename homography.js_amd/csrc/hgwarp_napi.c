@@ -767,6 +767,89 @@ static napi_value fn_warp_inverse_geometric_batch(napi_env env, napi_callback_in
     return arr;
 }
 
+/* Shared tail of the forward batches: room for the frames in the handle's device buffer, the launch through `run`, then every
+ * frame's copy queued behind the kernels (pinned pool memory: asynchronous DMA) and one sync (which also settles frames the
+ * tile kernels flagged). */
+typedef int (*batch_run_fn)(handle_t *h, const hg_geom *geoms, const size_t *offs, int F, void *d_out, void *arg);
+static napi_value run_frame_batch(napi_env env, handle_t *h, const int32_t *gv, int F, batch_run_fn run, void *arg, const char *what)
+{
+    size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
+    size_t total = 0;
+    hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
+    int rc = HG_OK;
+    if (total > h->d_batch_cap) {
+        if (h->d_batch) hg_device_free(h->ctx, h->d_batch);
+        h->d_batch = NULL; h->d_batch_cap = 0;
+        rc = hg_device_alloc(h->ctx, total, &h->d_batch);
+        if (rc == HG_OK) h->d_batch_cap = total;
+    }
+    if (rc == HG_OK) rc = run(h, (const hg_geom *)gv, offs, F, h->d_batch, arg);
+    napi_value arr = NULL;
+    if (rc == HG_OK && napi_create_array_with_length(env, F, &arr) == napi_ok) {
+        for (int f = 0; f < F && rc == HG_OK; f++) {
+            const hg_geom *g = (const hg_geom *)gv + f;
+            const size_t px = (g->obj_w > 0 && g->obj_h > 0) ? (size_t)g->obj_w * g->obj_h : 0;
+            void *out; napi_value ta = make_pixels(env, px * 4, NULL, 0, &out);
+            if (!ta) { rc = HG_ERR_NOMEM; break; }
+            if (px) rc = hg_copy_to_host_async(h->ctx, out, (const uint8_t *)h->d_batch + offs[f], px * 4);
+            napi_set_element(env, arr, f, ta);
+        }
+        const int rc2 = hg_sync(h->ctx);
+        if (rc == HG_OK) rc = rc2;
+    }
+    free(offs);
+    if (rc != HG_OK) return throw_hg(env, h->ctx, what, rc);
+    return arr;
+}
+
+/* The caller loop `setDestinyPoints(dst_f); warp()` for the frames warp() sends down the FORWARD piecewise path (:421-422: output
+ * not larger than the input and at least input / 1.2), one device pass: dst = F x 2N float32, maxSrcX / maxSrcY (:758),
+ * geoms = Int32Array F x 4; returns an Array of F Uint8ClampedArray. */
+typedef struct { const float *dst; int mx, my; } fwd_pw_arg;
+static int run_fwd_pw(handle_t *h, const hg_geom *geoms, const size_t *offs, int F, void *d_out, void *arg)
+{
+    const fwd_pw_arg *a = (const fwd_pw_arg *)arg;
+    return hg_warp_forward_piecewise_batch_device(h->ctx, a->dst, a->mx, a->my, geoms, offs, F, d_out);
+}
+static napi_value fn_warp_forward_piecewise_batch(napi_env env, napi_callback_info info)
+{
+    napi_value a[5];
+    if (!get_args(env, info, 5, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    size_t nd, ng; fwd_pw_arg arg;
+    arg.dst = (const float *)get_typed(env, a[1], napi_float32_array, &nd, "dstPoints"); if (!arg.dst) return NULL;
+    if (!get_i32(env, a[2], &arg.mx) || !get_i32(env, a[3], &arg.my)) return NULL;
+    int32_t *gv = (int32_t *)get_typed(env, a[4], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
+    const int F = (int)(ng / 4);
+    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
+    if (h->n_pts == 0 || nd < (size_t)F * 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold frames x mesh points x,y pairs (piecewiseSetMesh first)");
+    return run_frame_batch(env, h, gv, F, run_fwd_pw, &arg, "warpForwardPiecewiseBatch");
+}
+
+/* The same for the affine frames warp() sends forward (:426-427: output of the source's size): mats = Float64Array F x 8, the
+ * FORWARD matrices (6 used). */
+typedef struct { int kind; const double *m; } fwd_geo_arg;
+static int run_fwd_geo(handle_t *h, const hg_geom *geoms, const size_t *offs, int F, void *d_out, void *arg)
+{
+    const fwd_geo_arg *a = (const fwd_geo_arg *)arg;
+    return hg_warp_forward_geometric_batch_device(h->ctx, a->kind, a->m, geoms, offs, F, d_out);
+}
+static napi_value fn_warp_forward_geometric_batch(napi_env env, napi_callback_info info)
+{
+    napi_value a[4];
+    if (!get_args(env, info, 4, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    size_t nm, ng; fwd_geo_arg arg;
+    if (!get_i32(env, a[1], &arg.kind)) return NULL;
+    if (arg.kind != HG_AFFINE && arg.kind != HG_PROJECTIVE) return throw_str(env, "hgwarp: kind must be 0 (affine) or 1 (projective)");
+    arg.m = (const double *)get_typed(env, a[2], napi_float64_array, &nm, "matrices"); if (!arg.m) return NULL;
+    int32_t *gv = (int32_t *)get_typed(env, a[3], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
+    const int F = (int)(ng / 4);
+    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
+    if (nm < (size_t)F * 8) return throw_str(env, "hgwarp: matrices must hold 8 doubles per frame");
+    return run_frame_batch(env, h, gv, F, run_fwd_geo, &arg, "warpForwardGeometricBatch");
+}
+
 /* ---------------------------------------------------------------- several GPUs (hg_multi_*) */
 typedef struct { hg_multi *m; size_t n_pts; } mhandle_t;
 
@@ -975,6 +1058,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "warpInversePiecewise", fn_warp_inverse_piecewise }, { "getTriMap", fn_get_tri_map }, { "getMatrices", fn_get_matrices },
         { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch }, { "warpInverseGeometricBatch", fn_warp_inverse_geometric_batch },
         { "warpForwardGeometric", fn_warp_forward_geometric }, { "warpForwardPiecewise", fn_warp_forward_piecewise },
+        { "warpForwardPiecewiseBatch", fn_warp_forward_piecewise_batch }, { "warpForwardGeometricBatch", fn_warp_forward_geometric_batch },
         { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },
         { "multiCreate", fn_multi_create }, { "multiDestroy", fn_multi_destroy }, { "multiSetImage", fn_multi_set_image },
         { "multiSetMesh", fn_multi_set_mesh }, { "multiWarpBatch", fn_multi_warp_batch }, { "multiWarpGeometricBatch", fn_multi_warp_geometric_batch },

@@ -227,95 +227,155 @@ class Homography {
     }
 
     /**
-     * The benchmarked caller loop `for (f) { setDestinyPoints(dst[f]); warp(); }` (test/benchmark.js:107-110) for a
-     * piecewise mesh, as ONE GPU pass.  dstPointSets: array of point sets (pixel coordinates).  Returns an array of
-     * ImageData-shaped frames, each identical to what the loop would return with applyAlwaysInverse = true.
+     * The benchmarked caller loop `for (f) { setDestinyPoints(dst[f]); warp(); }` (test/benchmark.js:107-110) as GPU batches.
+     * dstPointSets: array of point sets.  Returns an array of ImageData-shaped frames, frame f identical to what the loop returns
+     * for it -- INCLUDING warp()'s choice between the inverse and the forward (scatter-semantics) loop, made per frame on that
+     * frame's output window exactly as warp() makes it (:421-422 piecewise, :426-427 affine, :431 projective): the frames that
+     * dispatch inverse go through one inverse batch, the ones that dispatch forward through one forward batch.
+     * options: {inverse: true} = the loop with warp(null, false, true) (applyAlwaysInverse: every frame through the inverse loop);
+     *          {images: [...]} = the loop warp(image_f) (frame f reads images[f % images.length]); {devices: [...]} = the inverse
+     *          frames spread over several GPUs of this node (forward frames run on this instance's own device);
+     *          {pointsAreNormalized: bool} = the second argument of every setDestinyPoints (default: the reference's auto-detect).
+     * Every setDestinyPoints(dst[f]) runs on the host exactly as in the loop (normalisation auto-detect, in-place scaling of typed
+     * arrays, window derivation), so the instance ends in the state the loop would leave it in.
      */
     warpBatch(dstPointSets, options = {}) {
         if (this.transform === 'affine' || this.transform === 'projective') return this._warpBatchGeometric(dstPointSets, options);
         if (this.transform !== 'piecewiseaffine') throw ("hgwarp: warpBatch() needs a transform (set the source points first)");
         if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
         const F = dstPointSets.length, n = this._srcPoints.length;
-        const all = new Float32Array(F * n), geoms = new Int32Array(F * 4);
+        const all = new Float32Array(F * n), geoms = new Int32Array(F * 4), forward = new Array(F).fill(false), blank = new Array(F).fill(false);
         for (let f = 0; f < F; f++) {
-            const p = toF32(dstPointSets[f]);
-            if (p.length !== n) throw (`It must be the same amount of destiny points (${p.length / 2}) than source points (${n / 2})`);
-            all.set(p, f * n);
-            const mm = this._native.minmaxXY(asF32(p));                                                 // :706-710
-            geoms.set([mm[0], mm[1], mm[2] - mm[0], mm[3] - mm[1]], f * 4);
+            this.setDestinyPoints(dstPointSets[f], options.pointsAreNormalized === undefined ? null : options.pointsAreNormalized);   // :337-380, as the loop does
+            all.set(asF32(this._dstPoints), f * n);
+            const [xo, yo, ow, oh] = this._window();
+            if (!(ow * oh >= 1)) { blank[f] = true; continue; }                                         // :440: a 1 x 1 blank frame
+            checkedLength(ow * oh * 4);
+            geoms.set([xo, yo, ow, oh], f * 4);
+            forward[f] = !(options.inverse === true || ow > this._width || oh > this._height || ow * 1.2 < this._width || oh * 1.2 < this._height);   // :421-422
         }
-        let largest = 0;
-        for (let f = 0; f < F; f++) largest = Math.max(largest, checkedLength(geoms[4 * f + 2] * geoms[4 * f + 3] * 4));
-        makeRoomFor(this._native, largest, F);
-        let datas;
-        if (options.devices !== undefined && options.devices !== null) {
-            // several GPUs of this node: device i of G warps a contiguous block of the frames (hg_multi_*: no collective on the
-            // data path; the shared source is fanned out once over xGMI peer copies -- or, with {images}, every device uploads the
-            // sources of its own block and nothing is exchanged at all)
-            const multi = this._multiFor(options.devices);
-            const tris = this._triangles instanceof Uint32Array ? this._triangles : Uint32Array.from(this._triangles);
-            this._native.multiSetMesh(multi, asF32(this._srcPoints), tris, this._minSrcX, this._minSrcY);
-            if (options.images) {
-                datas = this._native.multiWarpBatch(multi, all, geoms, this._checkedSources(options.images), this._width, this._height);
-                this._multiImage = null;                                                                 // (the devices now hold the per-frame sources)
-            } else {
-                if (!(this.staticImage && this._multiImage === this._image)) {
-                    this._native.multiSetImage(multi, this._image, this._width, this._height);
-                    this._multiImage = this._image;
+        const frames = new Array(F).fill(null);
+        const pick = (want) => { const ids = []; for (let f = 0; f < F; f++) if (!blank[f] && forward[f] === want) ids.push(f); return ids; };
+        const subset = (ids) => {                                                                       // points / windows / sources of a subset of the frames
+            if (ids.length === F) return { pts: all, g: geoms, images: options.images };
+            const pts = new Float32Array(ids.length * n), g = new Int32Array(ids.length * 4);
+            ids.forEach((f, k) => { pts.set(all.subarray(f * n, (f + 1) * n), k * n); g.set(geoms.subarray(4 * f, 4 * f + 4), 4 * k); });
+            const images = options.images ? ids.map((f) => options.images[f % options.images.length]) : options.images;
+            return { pts, g, images };
+        };
+        const room = (g) => { let largest = 0; for (let k = 0; k < g.length / 4; k++) largest = Math.max(largest, g[4 * k + 2] * g[4 * k + 3] * 4); makeRoomFor(this._native, largest, g.length / 4); };
+        const inv = pick(false), fwd = pick(true);
+        if (inv.length) {
+            const { pts, g, images } = subset(inv);
+            room(g);
+            let datas;
+            if (options.devices !== undefined && options.devices !== null) {
+                // several GPUs of this node: device i of G warps a contiguous block of the frames (hg_multi_*: no collective on the
+                // data path; the shared source is fanned out once over xGMI peer copies -- or, with {images}, every device uploads the
+                // sources of its own block and nothing is exchanged at all)
+                const multi = this._multiFor(options.devices);
+                const tris = this._triangles instanceof Uint32Array ? this._triangles : Uint32Array.from(this._triangles);
+                this._native.multiSetMesh(multi, asF32(this._srcPoints), tris, this._minSrcX, this._minSrcY);
+                if (images) {
+                    datas = this._native.multiWarpBatch(multi, pts, g, this._checkedSources(images), this._width, this._height);
+                    this._multiImage = null;                                                             // (the devices now hold the per-frame sources)
+                } else {
+                    if (!(this.staticImage && this._multiImage === this._image)) {
+                        this._native.multiSetImage(multi, this._image, this._width, this._height);
+                        this._multiImage = this._image;
+                    }
+                    datas = this._native.multiWarpBatch(multi, pts, g);
                 }
-                datas = this._native.multiWarpBatch(multi, all, geoms);
+            } else {
+                this._uploadSources(images);
+                this._uploadMesh();
+                datas = this._native.warpInversePiecewiseBatch(this._ctx, pts, g);
             }
-        } else {
-            this._uploadSources(options.images);
-            this._uploadMesh();
-            datas = this._native.warpInversePiecewiseBatch(this._ctx, all, geoms);
+            inv.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
-        return datas.map((d, f) => makeImageData(d, geoms[4 * f + 2], geoms[4 * f + 3]));
+        if (fwd.length) {                                                                               // _piecewiseAffineWarp :948-972 for the frames warp() sends there
+            if (!this._native.warpForwardPiecewiseBatch) throw ("hgwarp: the forward (source-to-destiny) piecewise batch is not built into this addon; call warpBatch(sets, {inverse: true})");
+            const { pts, g, images } = subset(fwd);
+            room(g);
+            this._uploadSources(images);
+            this._uploadMesh();
+            const datas = this._native.warpForwardPiecewiseBatch(this._ctx, pts, this._maxSrcX, this._maxSrcY, g);
+            fwd.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
+        }
+        for (let f = 0; f < F; f++) if (blank[f]) frames[f] = makeImageData(new Uint8ClampedArray(4), 1, 1);
+        if (F > 0 && !blank[F - 1]) {                                                                   // what the last warp() of the loop leaves behind
+            this._lastPath = forward[F - 1] ? '_piecewiseAffineWarp' : '_inversePiecewiseAffineWarp';
+            this._mapState = forward[F - 1] ? 'forward' : 'inverse';
+        }
+        return frames;
     }
 
     /**
      * warpBatch() for affine / projective: every `setDestinyPoints(dst_f)` of the loop runs on the host exactly as in the loop
-     * (normalisation auto-detect, in-place range alignment, forward matrix, output window); the inverse matrices the reference
-     * re-solves inside every warp (:994) are solved on the GPU, one lane per frame, and all frames are warped in one launch.
-     * Frames equal `warp(null, false, true)` of the loop; the instance ends in the state the loop would leave it in.
+     * (normalisation auto-detect, in-place range alignment, forward matrix, output window).  Frames that warp() sends down the inverse
+     * loop (projective always :431; affine when the output size differs from the source's :426, or with {inverse: true}): the inverse
+     * matrices the reference re-solves inside every warp (:994) are solved on the GPU, one lane per frame, all frames in one launch.
+     * Affine frames of the source's size go through the forward loop _geometricWarp (:427) with their forward matrices, as one batch.
      */
     _warpBatchGeometric(dstPointSets, options = {}) {
         if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
         const F = dstPointSets.length, per = this.transform === 'affine' ? 6 : 8;
-        const from = new Float32Array(F * per), to = new Float32Array(F * per), geoms = new Int32Array(F * 4);
-        const blank = [];
-        let largest = 0;
+        const from = new Float32Array(F * per), to = new Float32Array(F * per), geoms = new Int32Array(F * 4), mats = new Float64Array(F * 8);
+        const blank = new Array(F).fill(false), forward = new Array(F).fill(false);
         for (let f = 0; f < F; f++) {
-            this.setDestinyPoints(dstPointSets[f]);
-            this._alignRanges();                                                                         // :993
-            from.set(asF32(this._dstPoints).subarray(0, per), f * per);                                  // inverse: dst -> src (:994)
-            to.set(asF32(this._srcPoints).subarray(0, per), f * per);
+            this.setDestinyPoints(dstPointSets[f], options.pointsAreNormalized === undefined ? null : options.pointsAreNormalized);
             const [xo, yo, ow, oh] = this._window();
-            if (!(ow * oh >= 1)) { blank.push(f); geoms.set([0, 0, 0, 0], f * 4); continue; }
-            largest = Math.max(largest, checkedLength(ow * oh * 4));
+            forward[f] = this.transform === 'affine' && options.inverse !== true && ow === this._width && oh === this._height;      // :426-427, :431
+            if (forward[f]) mats.set(Array.from(this._transformMatrix), f * 8);                          // _geometricWarp uses _transformMatrix as it stands (:915)
+            else {
+                this._alignRanges();                                                                     // :993
+                from.set(asF32(this._dstPoints).subarray(0, per), f * per);                              // inverse: dst -> src (:994)
+                to.set(asF32(this._srcPoints).subarray(0, per), f * per);
+            }
+            if (!(ow * oh >= 1)) { blank[f] = true; geoms.set([0, 0, 0, 0], f * 4); continue; }
+            checkedLength(ow * oh * 4);
             geoms.set([xo, yo, ow, oh], f * 4);
         }
-        this._lastPath = '_inverseGeometricWarp';
-        makeRoomFor(this._native, largest, F);
         const kind = this.transform === 'affine' ? AFFINE : PROJECTIVE;
-        let datas;
-        if (options.devices !== undefined && options.devices !== null) {                              // frames spread over several GPUs
-            const multi = this._multiFor(options.devices);
-            if (options.images) {
-                datas = this._native.multiWarpGeometricBatch(multi, kind, from, to, geoms, this._checkedSources(options.images), this._width, this._height);
-                this._multiImage = null;
-            } else {
-                if (!(this.staticImage && this._multiImage === this._image)) {
-                    this._native.multiSetImage(multi, this._image, this._width, this._height);
-                    this._multiImage = this._image;
+        const frames = new Array(F).fill(null);
+        const pick = (want) => { const ids = []; for (let f = 0; f < F; f++) if (!blank[f] && forward[f] === want) ids.push(f); return ids; };
+        const room = (g) => { let largest = 0; for (let k = 0; k < g.length / 4; k++) largest = Math.max(largest, g[4 * k + 2] * g[4 * k + 3] * 4); makeRoomFor(this._native, largest, g.length / 4); };
+        const sub = (arr, ids, w) => { if (ids.length === F) return arr; const o = new arr.constructor(ids.length * w); ids.forEach((f, k) => o.set(arr.subarray(f * w, (f + 1) * w), k * w)); return o; };
+        const subImages = (ids) => (options.images && ids.length !== F ? ids.map((f) => options.images[f % options.images.length]) : options.images);
+        const inv = pick(false), fwd = pick(true);
+        if (inv.length) {
+            const g = sub(geoms, inv, 4), fr = sub(from, inv, per), tt = sub(to, inv, per), images = subImages(inv);
+            room(g);
+            let datas;
+            if (options.devices !== undefined && options.devices !== null) {                          // frames spread over several GPUs
+                const multi = this._multiFor(options.devices);
+                if (images) {
+                    datas = this._native.multiWarpGeometricBatch(multi, kind, fr, tt, g, this._checkedSources(images), this._width, this._height);
+                    this._multiImage = null;
+                } else {
+                    if (!(this.staticImage && this._multiImage === this._image)) {
+                        this._native.multiSetImage(multi, this._image, this._width, this._height);
+                        this._multiImage = this._image;
+                    }
+                    datas = this._native.multiWarpGeometricBatch(multi, kind, fr, tt, g);
                 }
-                datas = this._native.multiWarpGeometricBatch(multi, kind, from, to, geoms);
+            } else {
+                this._uploadSources(images);
+                datas = this._native.warpInverseGeometricBatch(this._ctx, kind, fr, tt, g);
             }
-        } else {
-            this._uploadSources(options.images);
-            datas = this._native.warpInverseGeometricBatch(this._ctx, kind, from, to, geoms);
+            inv.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
-        return datas.map((d, f) => (blank.includes(f) ? makeImageData(new Uint8ClampedArray(4), 1, 1) : makeImageData(d, geoms[4 * f + 2], geoms[4 * f + 3])));
+        if (fwd.length) {                                                                               // _geometricWarp :911-932
+            if (!this._native.warpForwardGeometricBatch) throw ("hgwarp: the forward (source-to-destiny) affine batch is not built into this addon; call warpBatch(sets, {inverse: true})");
+            const g = sub(geoms, fwd, 4), m = sub(mats, fwd, 8);
+            room(g);
+            this._uploadSources(subImages(fwd));
+            const datas = this._native.warpForwardGeometricBatch(this._ctx, kind, m, g);
+            fwd.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
+        }
+        for (let f = 0; f < F; f++) if (blank[f]) frames[f] = makeImageData(new Uint8ClampedArray(4), 1, 1);
+        if (F > 0) this._lastPath = forward[F - 1] ? '_geometricWarp' : '_inverseGeometricWarp';
+        return frames;
     }
 
     /** hg_multi handle for a device list (kept while the list stays the same). */

@@ -125,8 +125,8 @@ int hg_set_image(hg_ctx *ctx, const uint8_t *rgba, int width, int height);
 int hg_set_image_device(hg_ctx *ctx, const void *d_rgba, int width, int height);
 /* The video case `for (f) { warp(frame_f) }` (README.md:121-137: every warp() gets its own image, setImage :290 per
  * frame): n_images sources of identical size, `stride_bytes` apart in GPU memory (aliased).  Frame f of a frame set
- * (hg_*_set_frames) of the INVERSE warps then reads image f % n_images; n_images == 1 is hg_set_image_device.  The forward
- * (scatter-semantics) entry points hg_warp_forward_* warp one source only: with n_images > 1 they return HG_ERR_STATE. */
+ * (hg_*_set_frames), and frame f of a batch of the forward (scatter-semantics) entry points hg_warp_forward_*_batch_device, then
+ * reads image f % n_images; n_images == 1 is hg_set_image_device. */
 int hg_set_images_device(hg_ctx *ctx, const void *d_rgba, int width, int height, int n_images, size_t stride_bytes);
 
 /* ------------------------------------------------------------------------------------------------ affine / projective

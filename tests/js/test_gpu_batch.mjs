@@ -97,6 +97,42 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     nj2.warpBatch(nsets).forEach((b, f) => ok(b.width === nloop[f].width && sha(b.data) === sha(nloop[f].data), `normalised projective batch frame ${f} differs`));
     pj.close(); af.close(); nj.close(); nj2.close();
 }
+{   // warpBatch() applies warp()'s dispatch rule per frame (:421-422, :426-427): a MIXED set -- some frames go down the forward
+    // (scatter-semantics) loop, some down the inverse one -- equals the plain loop `setDestinyPoints(d); warp()` byte for byte;
+    // {inverse: true} equals the loop with applyAlwaysInverse
+    const mh = new Homography('piecewiseaffine');
+    mh.setSourcePoints(src, lcgImage(W, H, 21), W, H, false);
+    const scales = [0.95, 1.3, 0.9, 1.0, 0.6, 0.97];        // 0.95 / 0.9 / 0.97: not larger, >= input / 1.2 -> forward; 1.3 larger, 0.6 much smaller -> inverse
+    const mixed = scales.map((k, f) => src.map(([x, y]) => [x * k + 2 * f, (y + Math.sin((8 * x) / Math.PI) * 3) * (k === 1.0 ? 0.93 : k) + f]));
+    const paths = [];
+    const loop = mixed.map((d) => { mh.setDestinyPoints(d, false); const o = mh.warp(); paths.push(mh._lastPath); return o; });
+    ok(paths.includes('_piecewiseAffineWarp') && paths.includes('_inversePiecewiseAffineWarp'), `mixed set should take both loops, took ${paths}`);
+    const bat = mh.warpBatch(mixed, { pointsAreNormalized: false });
+    bat.forEach((b, f) => ok(b.width === loop[f].width && b.height === loop[f].height && sha(b.data) === sha(loop[f].data), `mixed piecewise batch frame ${f} (${paths[f]}) differs from the loop`));
+    ok(mh._lastPath === paths[paths.length - 1], 'warpBatch leaves the path of the last frame behind');
+    const loopInv = mixed.map((d) => { mh.setDestinyPoints(d, false); return mh.warp(null, false, true); });
+    mh.warpBatch(mixed, { inverse: true, pointsAreNormalized: false }).forEach((b, f) => ok(sha(b.data) === sha(loopInv[f].data), `{inverse: true} frame ${f} differs from warp(null, false, true)`));
+    ok(sha(loopInv[0].data) !== sha(loop[0].data), 'the forward and the inverse loop should differ on a shrunk frame (else this test proves nothing)');
+    // ... with one source per frame (the video loop warp(image_f)), forward frames included
+    const ims = [lcgImage(W, H, 81), lcgImage(W, H, 82), lcgImage(W, H, 83), lcgImage(W, H, 84)];
+    const vloop = mixed.map((d, f) => { mh.setDestinyPoints(d, false); return mh.warp(ims[f % 4]); });
+    mh.warpBatch(mixed, { images: ims, pointsAreNormalized: false }).forEach((b, f) => ok(sha(b.data) === sha(vloop[f].data), `mixed batch with per-frame sources: frame ${f} (${paths[f]}) differs from warp(image_f)`));
+    for (const devices of [[0], [0, 0, 0]])
+        mh.warpBatch(mixed, { images: ims, devices, pointsAreNormalized: false }).forEach((b, f) => ok(sha(b.data) === sha(vloop[f].data), `mixed batch over [${devices}]: frame ${f} differs`));
+    // affine: frames of the source's size go forward (:427), the others inverse (:426)
+    const im = lcgImage(480, 270, 33);
+    const af = new Homography('affine');
+    af.setSourcePoints([[0, 0], [0, 270], [480, 0]], im, 480, 270, false);
+    const asets = [[[5, 3], [5, 273], [485, 3]], [[0, 135], [240, 216], [240, 0]], [[-7, 10], [-7, 280], [473, 10]], [[0, 0], [0, 300], [500, 0]]];
+    const apaths = [];
+    const aloop = asets.map((d) => { af.setDestinyPoints(d, false); const o = af.warp(); apaths.push(af._lastPath); return o; });
+    ok(apaths.includes('_geometricWarp') && apaths.includes('_inverseGeometricWarp'), `mixed affine set should take both loops, took ${apaths}`);
+    af.warpBatch(asets, { pointsAreNormalized: false }).forEach((b, f) => ok(b.width === aloop[f].width && b.height === aloop[f].height && sha(b.data) === sha(aloop[f].data), `mixed affine batch frame ${f} (${apaths[f]}) differs from the loop`));
+    const aims = [lcgImage(480, 270, 91), lcgImage(480, 270, 92), lcgImage(480, 270, 93)];
+    const avloop = asets.map((d, f) => { af.setDestinyPoints(d, false); return af.warp(aims[f % 3]); });
+    af.warpBatch(asets, { images: aims, pointsAreNormalized: false }).forEach((b, f) => ok(sha(b.data) === sha(avloop[f].data), `mixed affine batch with per-frame sources: frame ${f} differs`));
+    mh.close(); af.close();
+}
 {   // one source per frame: warpBatch(sets, {images}) == the loop warp(image_f)
     const ims = [lcgImage(W, H, 71), lcgImage(W, H, 72), lcgImage(W, H, 73)];
     const vh = new Homography('piecewiseaffine');

@@ -502,6 +502,69 @@ def test_forward_scatter_batches_stay_on_the_device(ctx):
         ctx.free(d_out)
 
 
+def test_forward_warps_with_one_source_per_frame():
+    """The video loop `for (f) warp(frame_f)` when warp() dispatches FORWARD (Homography.js:421, :426, README.md:121-137): frame f of a
+    forward batch reads image f mod n_images (hg_set_images_device).  Affine and piecewise, scatter + gather and the tile kernels,
+    each frame against the oracle's sequential loop on ITS image."""
+    rng = np.random.default_rng(4242)
+    W, H, nx, ny, F, NI = 320, 256, 5, 4, 7, 3
+    imgs = [G.lcg_image(W, H, 500 + k) for k in range(NI)]
+    stride = W * H * 4 + 128
+    c = HG.Context(0)
+    d_src = c.alloc(stride * NI)
+    try:
+        for k in range(NI):
+            c.to_device(d_src, imgs[k], k * stride)
+        c.set_images_device(d_src, W, H, NI, stride)
+        # affine frames (same-size windows are what warp() sends forward, :426; any window is legal at the C ABI)
+        mats, geoms = [], []
+        for f in range(F):
+            m6 = np.array([0.9 + 0.03 * f, 0.05 * f - 0.1, -0.08, 0.95, 2.0 * f, 1.0], np.float32).astype(np.float64)
+            mats.append(np.concatenate([m6, [0, 0]]))
+            geoms.append(tuple(int(v) for v in O.transform_limits(0, m6, W, H)))
+        offs, total = HG.pack_offsets(geoms)
+        d_out = c.alloc(max(total, 256))
+        try:
+            for tiles in (0, 1):
+                c.set_option("fwd_tiles", tiles)
+                c.warp_forward_geometric_batch_device(0, np.concatenate(mats), geoms, offs, d_out)
+                c.sync()
+                assert c.last_forward_kernel() == 1 + tiles
+                for f in range(F):
+                    g = geoms[f]
+                    got = c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                    assert np.array_equal(got, O.warp_forward_geometric(0, mats[f][:6], imgs[f % NI], *g)), ("affine", tiles, f)
+        finally:
+            c.free(d_out)
+        # piecewise frames on one mesh (shrunk so that warp() would dispatch forward, :421)
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        ms = O.minmax_xy(sp)
+        frames = [(sp.reshape(-1, 2) * np.float32(0.95 - 0.01 * f) + rng.uniform(-2.0, 2.0, (sp.size // 2, 2)).astype(np.float32)).astype(np.float32).ravel() for f in range(F)]
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        c.piecewise_set_mesh(sp, tris, int(ms[0]), int(ms[1]))
+        offs, total = HG.pack_offsets(geoms)
+        d_out = c.alloc(max(total, 256))
+        try:
+            fmap = O.build_tri_map(sp, tris, int(ms[2] - ms[0]), int(ms[1]), int((ms[2] - ms[0]) * (ms[3] - ms[1])))
+            for tiles in (0, 1):
+                c.set_option("fwd_tiles", tiles)
+                c.warp_forward_piecewise_batch_device(np.concatenate(frames), int(ms[2]), int(ms[3]), geoms, offs, d_out)
+                c.sync()
+                assert c.last_forward_kernel() == 1 + tiles
+                for f in range(F):
+                    g = geoms[f]
+                    got = c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                    fwd = O.piecewise_matrices(sp, frames[f], tris)
+                    want = O.warp_forward_piecewise(fmap, fwd, imgs[f % NI], int(ms[0]), int(ms[1]), int(ms[2]), int(ms[3]), *g)
+                    assert np.array_equal(got, want), ("piecewise", tiles, f)
+        finally:
+            c.free(d_out)
+    finally:
+        c.set_image(imgs[0])                                 # drop the alias before the buffer goes away
+        c.free(d_src)
+        c.close()
+
+
 def test_batch_frames_equal_single_frames(ctx):
     """F destination point sets in one launch == F single-frame calls (frames differ in geometry and offsets)."""
     W, H, nx, ny, F = 320, 200, 10, 6, 5
