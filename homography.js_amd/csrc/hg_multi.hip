@@ -10,8 +10,10 @@
 //   1. H2D of the image into device 0;
 //   2. scatter: device 0 -> peer p, slice p (1/G of the image) -- every link 0->p carries 1/G;
 //   3. all-gather: every device sends the slice it owns to every other device -- every link p->q carries 1/G;
-// all as hipMemcpyPeerAsync on per-device streams ordered by events.  Without peer access (hipDeviceCanAccessPeer == 0)
-// every device gets its own H2D copy instead.
+// all as hipMemcpyPeerAsync on per-device streams ordered by events.  The plan is made PER PAIR (hg_multi_plan_fanout, a pure
+// function with a CPU test): where hipDeviceCanAccessPeer is 0 for a pair, that one copy falls back -- a slice whose owner the
+// reader cannot reach comes from the root instead, and from the caller's host buffer if the root is out of reach too; the pairs
+// without access are listed by hg_multi_peer_note.
 #include "../../include/hgwarp.h"
 #include <hip/hip_runtime.h>
 
@@ -33,7 +35,8 @@ struct hg_multi {
         std::vector<size_t> offs;                // their byte offsets in d_out
     };
     std::vector<Dev> devs;
-    bool peer = true;                            // every pair of distinct devices has peer access
+    std::vector<uint8_t> access;                 // access[p * G + q] = 1: device q copies from device p's memory directly (peer access enabled, or the same GPU)
+    std::string peer_note;                       // "" or the pairs without peer access, for diagnostics
     int W = 0, H = 0;
     int n_pts = 0;
     std::vector<hg_geom> geoms;                  // of the current batch
@@ -103,17 +106,25 @@ extern "C" int hg_multi_create(const int *device_ids, int n_devices, hg_multi **
             return mfail(nullptr, HG_ERR_HIP, "hg_multi_create: stream / event creation failed");
         }
     }
-    // peer access between every pair of distinct devices (a device listed twice talks to itself: plain device copies)
-    for (int i = 0; i < n_devices && m->peer; i++)
+    // peer access, pair by pair (a device listed twice talks to itself: plain device copies).  A pair without it does not switch the
+    // whole fan-out to per-device H2D copies any more: only the copies of that pair take another route (hg_multi_plan_fanout).
+    m->access.assign((size_t)n_devices * n_devices, 1);
+    for (int i = 0; i < n_devices; i++)
         for (int j = 0; j < n_devices; j++) {
             const int a = m->devs[i].id, b = m->devs[j].id;
             if (a == b) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) { m->peer = false; break; }
-            (void)hipSetDevice(a);
-            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { m->peer = false; break; }
-            (void)hipGetLastError();
+            bool ok = hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can;
+            if (ok) {
+                (void)hipSetDevice(a);
+                const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                (void)hipGetLastError();
+            }
+            if (!ok) {                                       // device a cannot map device b's memory: copies b -> a take another route
+                m->access[(size_t)j * n_devices + i] = 0;
+                m->peer_note += (m->peer_note.empty() ? "no peer access: " : ", ") + std::to_string(b) + "->" + std::to_string(a);
+            }
         }
     *out = m;
     return HG_OK;
@@ -128,6 +139,43 @@ static int ensure_dev(hg_multi *m, hg_multi::Dev &d, uint8_t *&p, size_t &cap, s
     if (hipMalloc(&q, need) != hipSuccess) return mfail(m, HG_ERR_NOMEM, "hg_multi: hipMalloc failed");
     p = static_cast<uint8_t *>(q); cap = need;
     return HG_OK;
+}
+
+// ---- the fan-out plan (pure host logic; tests/test_cabi_cpu.py runs it without a GPU)
+// access[p * G + q] != 0: device q can copy straight out of device p's memory.  Ops in issue order, 4 ints each:
+//   {dst device index, src device index or -1 = the caller's host buffer, slice, phase}   phase 0 = scatter, 1 = all-gather.
+// Scatter: slice q -> device q from the root (device 0), else from the host.  All-gather: device q takes slice p from its owner p
+// (staggered, so that the pulls of one step use different links), else from the root -- which holds every slice --, else from the
+// host.  With full access every ordered pair p -> q carries exactly one slice (1/G of the image per link).
+struct FanOp { int dst, src, slice, phase; };
+static void plan_fanout(int G, const uint8_t *access, std::vector<FanOp> &ops)
+{
+    auto can = [&](int p, int q) { return access[(size_t)p * G + q] != 0; };
+    ops.clear();
+    for (int q = 1; q < G; q++) ops.push_back({q, can(0, q) ? 0 : -1, q, 0});
+    for (int q = 1; q < G; q++)
+        for (int k = 1; k < G; k++) {
+            const int p = (q + k) % G;
+            if (p == q) continue;
+            ops.push_back({q, can(p, q) ? p : (can(0, q) ? 0 : -1), p, 1});
+        }
+}
+
+extern "C" int hg_multi_plan_fanout(int n_devices, const uint8_t *access, int32_t *ops, int max_ops)
+{
+    if (n_devices <= 0 || n_devices > 64 || !access) return -1;
+    std::vector<FanOp> plan;
+    plan_fanout(n_devices, access, plan);
+    if (ops) for (size_t i = 0; i < plan.size() && (int)i < max_ops; i++) { ops[4 * i] = plan[i].dst; ops[4 * i + 1] = plan[i].src; ops[4 * i + 2] = plan[i].slice; ops[4 * i + 3] = plan[i].phase; }
+    return (int)plan.size();
+}
+
+extern "C" const char *hg_multi_peer_note(const hg_multi *m) { return m ? m->peer_note.c_str() : ""; }
+extern "C" int hg_multi_peer_access(const hg_multi *m, int from_index, int to_index)
+{
+    const int G = m ? (int)m->devs.size() : 0;
+    if (from_index < 0 || to_index < 0 || from_index >= G || to_index >= G) return -1;
+    return m->access[(size_t)from_index * G + to_index];
 }
 
 // setImage (:290-316) for every device: the reference's single source image, shared by all frames of a batch.
@@ -160,11 +208,7 @@ extern "C" int hg_multi_set_image(hg_multi *m, const uint8_t *rgba, int w, int h
     }
     auto &root = m->devs[0];
     MHIP(m, hipSetDevice(root.id));
-    if (G == 1 || !m->peer) {
-        for (auto &d : m->devs) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipMemcpyAsync(d.d_img, rgba, bytes, hipMemcpyHostToDevice, d.copy)); MHIP(m, hipEventRecord(d.have_image, d.copy)); }
-        // caller memory is not retained: every H2D has left the host buffer before this returns
-        for (auto &d : m->devs) { MHIP(m, hipSetDevice(d.id)); MHIP(m, hipStreamSynchronize(d.copy)); }
-    } else {
+    {
         MHIP(m, hipMemcpyAsync(root.d_img, rgba, bytes, hipMemcpyHostToDevice, root.copy));
         MHIP(m, hipEventRecord(root.have_slice, root.copy));
         MHIP(m, hipEventRecord(root.have_image, root.copy));
@@ -172,32 +216,36 @@ extern "C" int hg_multi_set_image(hg_multi *m, const uint8_t *rgba, int w, int h
         const size_t slice = ((bytes / G) + 3) & ~(size_t)3;
         auto lo = [&](int k) { return std::min(bytes, slice * (size_t)k); };
         auto hi = [&](int k) { return k == G - 1 ? bytes : std::min(bytes, slice * (size_t)(k + 1)); };
-        // scatter: root -> p, slice p, on p's stream
-        for (int p = 1; p < G; p++) {
-            auto &d = m->devs[p];
-            MHIP(m, hipSetDevice(d.id));
-            MHIP(m, hipStreamWaitEvent(d.copy, root.have_slice, 0));
-            if (hi(p) > lo(p)) MHIP(m, hipMemcpyPeerAsync(d.d_img + lo(p), d.id, root.d_img + lo(p), root.id, hi(p) - lo(p), d.copy));
-            MHIP(m, hipEventRecord(d.have_slice, d.copy));
-        }
-        // all-gather: q pulls slice p from its owner p (the root owns every slice already and pulls nothing)
-        for (int q = 1; q < G; q++) {
-            auto &dq = m->devs[q];
+        std::vector<FanOp> plan;
+        plan_fanout(G, m->access.data(), plan);
+        std::vector<char> reads_host((size_t)G, 0);
+        int phase = 0;
+        auto close_scatter = [&]() -> int {                  // every peer's "own slice here" event, once its scatter copy is queued
+            for (int p = 1; p < G; p++) { auto &d = m->devs[p]; MHIP(m, hipSetDevice(d.id)); MHIP(m, hipEventRecord(d.have_slice, d.copy)); }
+            return HG_OK;
+        };
+        for (const FanOp &op : plan) {
+            if (op.phase == 1 && phase == 0) { phase = 1; const int rc = close_scatter(); if (rc != HG_OK) return rc; }
+            auto &dq = m->devs[op.dst];
+            if (hi(op.slice) <= lo(op.slice)) continue;
             MHIP(m, hipSetDevice(dq.id));
-            for (int k = 1; k < G; k++) {
-                const int p = (q + k) % G;                   // staggered so that the pulls of one step use different links
-                if (p == q || hi(p) <= lo(p)) continue;
-                auto &dp = m->devs[p];
-                MHIP(m, hipStreamWaitEvent(dq.copy, dp.have_slice, 0));
-                MHIP(m, hipMemcpyPeerAsync(dq.d_img + lo(p), dq.id, dp.d_img + lo(p), dp.id, hi(p) - lo(p), dq.copy));
+            if (op.src < 0) {                                // no route between the devices: this slice comes from the caller's buffer
+                MHIP(m, hipMemcpyAsync(dq.d_img + lo(op.slice), rgba + lo(op.slice), hi(op.slice) - lo(op.slice), hipMemcpyHostToDevice, dq.copy));
+                reads_host[(size_t)op.dst] = 1;
+            } else {
+                auto &dp = m->devs[op.src];
+                MHIP(m, hipStreamWaitEvent(dq.copy, dp.have_slice, 0));      // (the root's have_slice covers the whole image)
+                MHIP(m, hipMemcpyPeerAsync(dq.d_img + lo(op.slice), dq.id, dp.d_img + lo(op.slice), dp.id, hi(op.slice) - lo(op.slice), dq.copy));
             }
-            MHIP(m, hipEventRecord(dq.have_image, dq.copy));
         }
-        // The host waits for the H2D only (caller memory is not retained).  The fan-out over xGMI keeps running: every
-        // device's warp stream waits for ITS have_image event, so the root's first frames overlap the scatter + all-gather
-        //  instead of queueing behind a host-side barrier.
+        if (phase == 0) { const int rc = close_scatter(); if (rc != HG_OK) return rc; }
+        for (int q = 1; q < G; q++) { auto &dq = m->devs[q]; MHIP(m, hipSetDevice(dq.id)); MHIP(m, hipEventRecord(dq.have_image, dq.copy)); }
+        // The host waits for the copies that read ITS buffer only (caller memory is not retained): the root's H2D, and the streams of
+        // devices that had to take slices from the host.  The fan-out over xGMI keeps running: every device's warp stream waits for
+        // ITS have_image event, so the root's first frames overlap the scatter + all-gather.
         MHIP(m, hipSetDevice(root.id));
         MHIP(m, hipEventSynchronize(root.have_image));
+        for (int q = 1; q < G; q++) if (reads_host[(size_t)q]) { MHIP(m, hipSetDevice(m->devs[q].id)); MHIP(m, hipStreamSynchronize(m->devs[q].copy)); }
     }
     for (auto &d : m->devs) {
         MHG(m, d.ctx, hg_set_image_device(d.ctx, d.d_img, w, h));

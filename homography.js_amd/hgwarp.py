@@ -23,7 +23,7 @@ HG_AFFINE, HG_PROJECTIVE = 0, 1
 EXPORTS = [
     "hg_version", "hg_device_count", "hg_create", "hg_create_on_stream", "hg_destroy", "hg_last_error", "hg_sync",
     "hg_device_alloc", "hg_device_free", "hg_copy_to_host", "hg_copy_to_device", "hg_copy_to_host_async", "hg_host_alloc", "hg_host_free", "hg_ctx_device",
-    "hg_multi_create", "hg_multi_destroy", "hg_multi_last_error", "hg_multi_device_count", "hg_multi_ctx", "hg_multi_partition", "hg_multi_set_image",
+    "hg_multi_create", "hg_multi_destroy", "hg_multi_last_error", "hg_multi_device_count", "hg_multi_ctx", "hg_multi_partition", "hg_multi_plan_fanout", "hg_multi_peer_note", "hg_multi_peer_access", "hg_multi_set_image",
     "hg_multi_piecewise_set_mesh", "hg_multi_warp_piecewise_batch", "hg_multi_warp_geometric_batch", "hg_multi_warp_piecewise_batch_images",
     "hg_multi_warp_geometric_batch_images", "hg_multi_frame", "hg_enqueue_copy_to_host", "hg_stream_wait_event",
     "hg_solve_affine", "hg_invert_affine", "hg_solve_projective", "hg_transform_limits", "hg_minmax_xy", "hg_js_round",
@@ -72,6 +72,7 @@ def lib():
         "hg_multi_create": (i, [C.POINTER(i), i, C.POINTER(vp)]), "hg_multi_destroy": (None, [vp]), "hg_multi_last_error": (C.c_char_p, [vp]),
         "hg_multi_device_count": (i, [vp]), "hg_multi_ctx": (vp, [vp, i]),
         "hg_multi_partition": (i, [i, i, i, C.POINTER(i), C.POINTER(i)]),
+        "hg_multi_plan_fanout": (i, [i, vp, vp, i]), "hg_multi_peer_note": (C.c_char_p, [vp]), "hg_multi_peer_access": (i, [vp, i, i]),
         "hg_multi_set_image": (i, [vp, u8p, i, i]), "hg_multi_piecewise_set_mesh": (i, [vp, f32p, i, C.POINTER(C.c_uint32), i, i, i]),
         "hg_multi_warp_piecewise_batch": (i, [vp, f32p, C.POINTER(Geom), i, C.POINTER(vp)]),
         "hg_multi_warp_geometric_batch": (i, [vp, i, f32p, f32p, C.POINTER(Geom), i, C.POINTER(vp)]),
@@ -478,6 +479,20 @@ class Context:
 
 # ------------------------------------------------------------------ several GPUs, one host thread (hg_multi_*)
 
+def multi_plan_fanout(access):
+    """Copy plan of the shared-source fan-out (pure function, no GPU): access = G x G array, access[p, q] != 0 when device q copies
+    straight out of device p's memory.  Returns a list of (dst, src or -1 = host buffer, slice, phase)."""
+    a = np.ascontiguousarray(access, np.uint8)
+    G = a.shape[0]
+    assert a.shape == (G, G)
+    n = lib().hg_multi_plan_fanout(G, a.ctypes.data, None, 0)
+    if n < 0:
+        raise RuntimeError("hg_multi_plan_fanout: bad arguments")
+    ops = np.zeros((max(n, 1), 4), np.int32)
+    lib().hg_multi_plan_fanout(G, a.ctypes.data, ops.ctypes.data, n)
+    return [tuple(int(v) for v in ops[k]) for k in range(n)]
+
+
 def multi_partition(n_frames, n_devices, index):
     """(first, count): the contiguous block of frames device `index` of `n_devices` warps (pure function, no GPU)."""
     first, count = C.c_int(0), C.c_int(0)
@@ -522,6 +537,14 @@ class Multi:
         if code != 0:
             msg = lib().hg_multi_last_error(self._h)
             raise HgError(code, msg.decode() if msg else "?")
+
+    def peer_note(self):
+        """'' when every pair of distinct devices has peer access, else a text naming the pairs without it."""
+        msg = lib().hg_multi_peer_note(self._h)
+        return msg.decode() if msg else ""
+
+    def peer_access(self, from_index, to_index):
+        return lib().hg_multi_peer_access(self._h, int(from_index), int(to_index))
 
     def close(self):
         if self._h:

@@ -231,9 +231,20 @@ void hg_multi_destroy(hg_multi *multi);
 const char *hg_multi_last_error(const hg_multi *multi);
 int hg_multi_device_count(const hg_multi *multi);
 hg_ctx *hg_multi_ctx(hg_multi *multi, int index);                       /* the per-device context (options, taps) */
+/* Peer access is checked and enabled pair by pair at hg_multi_create.  hg_multi_peer_note: "" when every pair of distinct devices
+ * has it, else a text listing the pairs without ("no peer access: 2->3, 3->2"); hg_multi_peer_access: 1 / 0 for one ordered pair of
+ * indices into the device list (-1: bad index).  A pair without access only re-routes ITS copies of the source fan-out. */
+const char *hg_multi_peer_note(const hg_multi *multi);
+int hg_multi_peer_access(const hg_multi *multi, int from_index, int to_index);
+/* Pure function (no GPU): the copy plan of the source fan-out for n_devices devices and the access matrix access[p * n_devices + q]
+ * (non-zero: device q copies straight out of device p's memory).  Returns the number of copies and writes up to max_ops of them, 4
+ * ints each: {destination index, source index or -1 = the caller's host buffer, slice, phase 0 scatter / 1 all-gather}.  Scatter:
+ * slice q goes to device q from device 0; all-gather: q takes slice p from its owner p, else from device 0 (which holds every
+ * slice), else from the host.  With full access every ordered pair of devices carries exactly one 1/n slice. */
+int hg_multi_plan_fanout(int n_devices, const uint8_t *access, int32_t *ops, int max_ops);
 /* Pure function: frames [*first, *first + *count) of n_frames belong to device `index` of n_devices (sizes differ by <= 1). */
 int hg_multi_partition(int n_frames, int n_devices, int index, int *first, int *count);
-/* Returns once the host buffer has been read (H2D into device 0, or one H2D per device without peer access).  The fan-out
+/* Returns once the host buffer has been read (H2D into device 0, plus the slices of devices no other device can serve).  The fan-out
  * between the devices is NOT waited for: every device's warp stream waits for the event "whole image here", so device 0's
  * first frames overlap the scatter + all-gather. */
 int hg_multi_set_image(hg_multi *multi, const uint8_t *rgba, int width, int height);

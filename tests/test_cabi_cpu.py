@@ -108,6 +108,50 @@ def test_multi_device_partition_covers_every_frame_once():
         HG.multi_partition(8, 2, 2)
 
 
+def test_multi_device_fanout_plan_falls_back_per_pair():
+    """hg_multi_plan_fanout (pure function): the copy plan of the shared-source fan-out.  Full peer access: scatter of 1/G slices
+    from device 0, then an all-gather in which every ordered pair of devices carries exactly ONE slice (xGMI is point-to-point: no
+    link carries more than 1/G of the image) and the pulls of one step use different sources.  A pair without peer access re-routes
+    only ITS copies: to the root if the reader reaches it, else to the host buffer; every device still ends with every slice."""
+    for G in (1, 2, 3, 4, 8):
+        full = np.ones((G, G), np.uint8)
+        ops = HG.multi_plan_fanout(full)
+        assert len(ops) == (G - 1) + (G - 1) * (G - 1)
+        assert [o for o in ops if o[3] == 0] == [(q, 0, q, 0) for q in range(1, G)]            # scatter first, in order
+        gather = [o for o in ops if o[3] == 1]
+        assert ops[:G - 1] == [o for o in ops if o[3] == 0]                                      # ... before any all-gather copy
+        assert all(src == sl for _, src, sl, _ in gather)                                        # every slice from its owner
+        links = {}
+        for dst, src, sl, ph in ops:
+            links[(src, dst)] = links.get((src, dst), 0) + 1
+        assert all(v == 1 for (s, d), v in links.items() if s != 0), links                       # peer links: one slice each
+        assert all(links.get((0, q), 0) == (2 if G > 1 else 0) for q in range(1, G))             # root link: scatter slice q + slice 0
+        for q in range(1, G):                                                                     # device q ends up with every slice once
+            assert sorted(sl for dst, _, sl, _ in ops if dst == q) == list(range(G))
+        for k in range(G - 2):                                                                    # step k of the all-gather: distinct sources
+            step = [[o for o in gather if o[0] == q][k][1] for q in range(1, G)]
+            assert len(set(step)) == len(step), (G, k, step)
+    # one missing pair, both directions: 2 <-> 3 of 4
+    acc = np.ones((4, 4), np.uint8)
+    acc[2, 3] = acc[3, 2] = 0
+    ops = HG.multi_plan_fanout(acc)
+    assert (3, 0, 2, 1) in ops and (2, 0, 3, 1) in ops                                           # slice 2 for device 3 (and 3 for 2) from the root
+    assert not any((src, dst) in ((2, 3), (3, 2)) for dst, src, _, _ in ops)
+    assert sum(1 for dst, src, sl, ph in ops if src == -1) == 0
+    # device 3 cannot reach the root either: its own slice and slice 0 come from the host, the others from their owners
+    acc = np.ones((4, 4), np.uint8)
+    acc[0, 3] = 0
+    ops = HG.multi_plan_fanout(acc)
+    assert (3, -1, 3, 0) in ops and (3, -1, 0, 1) in ops and (3, 1, 1, 1) in ops and (3, 2, 2, 1) in ops
+    # no peer access at all: every device but the root reads the whole image from the host
+    none = np.eye(4, dtype=np.uint8)
+    ops = HG.multi_plan_fanout(none)
+    assert all(src == -1 for _, src, _, _ in ops)
+    for q in range(1, 4):
+        assert sorted(sl for dst, _, sl, _ in ops if dst == q) == [0, 1, 2, 3]
+    assert HG.lib().hg_multi_plan_fanout(0, none.ctypes.data, None, 0) < 0
+
+
 def test_pack_offsets():
     offs, total = HG.pack_offsets([(0, 0, 10, 3), (5, -2, 0, 7), (0, 0, 64, 64)])
     assert offs == [0, 256, 256] and total == 256 + 64 * 64 * 4

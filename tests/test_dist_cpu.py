@@ -77,6 +77,46 @@ def test_broadcast_source_gloo_world2(shape):
     assert sorted(f for _, _, fr in res for f in fr) == list(range(11))
 
 
+def _root_worker(rank, world, port, shape, src, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = _load("hg_dist", "dist.py")
+        WL = _load("hg_workloads", "workloads.py")
+        h, w = shape
+        want = torch.from_numpy(WL.lcg_image(w, h, 9))
+        img = want.clone() if rank == src else torch.full_like(want, 0xAB)      # only the root holds the texture; the others hold garbage
+        got = D.broadcast_source(img, rank, world, dist, src=src, verify=True)
+        agg = D.aggregate_step_stats(dist, world, torch.device("cpu"), elapsed_s=0.125 * (rank + 1), pixels_per_step=100.0, kernel_ms=1.0 + rank, verified=True)
+        q.put((rank, bool(torch.equal(got, want)), list(D.shard_frames(13, rank, world)), agg["elapsed_s_by_rank"], agg["kernel_ms_by_rank"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,src", [((37, 53), 2), ((64, 64), 3)])     # ragged and exact slice sizes, roots other than rank 0
+def test_broadcast_source_gloo_world4_nonzero_root(shape, src):
+    """The source fan-out (scatter of 1/N slices + all-gather) from a root that is NOT rank 0, world size 4: every rank ends with the
+    root's bytes, whatever it held before; the per-rank bookkeeping (elapsed / kernel ms by rank) arrives in rank order."""
+    world = 4
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_root_worker, args=(r, world, port, shape, src, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _, _ in res)
+    assert sorted(f for _, _, fr, _, _ in res for f in fr) == list(range(13))
+    for _, _, _, el, km in res:
+        assert el == [0.125, 0.25, 0.375, 0.5] and km == [1.0, 2.0, 3.0, 4.0]
+
+
 def _bookkeeping_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
