@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B: lib/libhgwarp_prev.so (HGWARP_LIB) against lib/libhgwarp.so, alternating; args: configs sources [sweep args]
 export TMPDIR=/tmp
-o=$PWD/gpurun_out/r3ab; mkdir -p $o; : > $o/ab.log
+o=$PWD/gpurun_out/ab_prev; mkdir -p $o; : > $o/ab.log
 for rep in 1 2; do
 for lib in prev cur; do
   if [ $lib = prev ]; then export HGWARP_LIB=$PWD/homography.js_amd/lib/libhgwarp_prev.so; else unset HGWARP_LIB; fi

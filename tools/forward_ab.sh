@@ -1,7 +1,7 @@
 #!/bin/bash
 # forward warps, same-box A/B: lib/libhgwarp_prev.so (HGWARP_LIB) against lib/libhgwarp.so; then a kernel trace of the 10x10 piecewise case
 export TMPDIR=/tmp
-o=$PWD/gpurun_out/r3fwd; rm -rf $o; mkdir -p $o
+o=$PWD/gpurun_out/forward_ab; rm -rf $o; mkdir -p $o
 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "forward" > $o/pytest.log 2>&1; tail -2 $o/pytest.log
 for rep in 1 2; do for lib in prev cur; do
   if [ $lib = prev ]; then export HGWARP_LIB=$PWD/homography.js_amd/lib/libhgwarp_prev.so; else unset HGWARP_LIB; fi

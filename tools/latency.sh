@@ -1,7 +1,7 @@
 #!/bin/bash
 # F = 1, 2, 4, 8 single-launch latency: host view + rocprofv3 device view, for each option string given ("self_spans=0" "self_spans=1" ...)
 export TMPDIR=/tmp
-o=$PWD/gpurun_out/r4lat; rm -rf $o; mkdir -p $o
+o=$PWD/gpurun_out/latency; rm -rf $o; mkdir -p $o
 for opt in "$@"; do
   tag=$(echo $opt | tr ' =' '__')
   python tools/latency_f.py $opt 2>&1 | grep "^{" | sed "s/^/$tag host /"
