@@ -19,7 +19,7 @@ namespace hg {
 // Limits (host picks the kernel from its estimate; a group that exceeds one flags the frame -> map path, and the context
 // stops using this kernel): <= 199 spans per row, <= 208 triangles per 4-row group, obj_w <= 8192.  A bin with more than
 // 8 spans is handled inside the kernel (the block tests the row's whole list).
-constexpr int kPatchRows = 4, kPatchCap = 200, kPatchRecs = 208, kPatchBins = 128, kPatchBinSlots = 8, kPatchHash = 1024, kPatchTilePitch = 68;
+constexpr int kPatchRows = 4, kPatchCap = 200, kPatchRecs = 208, kPatchBins = 128, kPatchBinSlots = 8, kPatchHash = 1024, kPatchTilePitch = 80;
 // (sized so that six workgroups fit a CU's 160 KB of LDS: 26.9 KB each)
 static_assert(kPatchHash * 4 <= kPatchRows * kPatchBins * kPatchBinSlots, "the hash table lives in the bin-slot area");
 // GLOBALREC variant for very dense meshes (up to 511 spans per row: README-scale, ~23 000 triangles on 4K): no matrix
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             const uint32_t lh = s_lohi[e];
             const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
             for (int b = lo >> 6; b <= (hi - 1) >> 6 && b < nbins; b++) {
-                const int pos = atomicAdd(&s_bincnt[rr * kPatchBins + b], 1);          // (a count beyond the slots marks the bin as overfull)
-                if (pos < kPatchBinSlots) s_bin[(rr * kPatchBins + b) * kPatchBinSlots + pos] = (slot_t)i;
+                const int pos = atomicAdd(&s_bincnt[b * kPatchRows + rr], 1);          // (a count beyond the slots marks the bin as overfull)
+                if (pos < kPatchBinSlots) s_bin[(b * kPatchRows + rr) * kPatchBinSlots + pos] = (slot_t)i;
             }
         }
     }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     auto resolve_gather = [&](int cw, uint32_t px[4]) {
         const int c0 = cw << 6;                             // pixel k of the lane: (c0 + ck[k], r0 + rr)
         int best[4] = { nan_key, nan_key, nan_key, nan_key };
-        const int bidx = rr * kPatchBins + cw;
+        const int bidx = cw * kPatchRows + rr;      // (bins of the four rows side by side: the four row groups of a wave read different banks)
         const int nb = s_bincnt[bidx];
         const slot_t *bin = s_bin + bidx * kPatchBinSlots;
         if (!__any(nb > kPatchBinSlots)) {
@@ -352,6 +352,10 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
         }
         __builtin_amdgcn_wave_barrier();
     };
+    // (Measured and dropped, round 4: a fast path for blocks no span reaches -- a third of C4's -- written as zeros without lookup,
+    //  transform, gather or transpose.  Per block, the branches make the compiler wait for each block's loads inside its branch: C3 with
+    //  one source per frame 0.82 -> 1.03 ms; per phase of 8 contiguous blocks it costs 120 instead of 86 registers: C4 0.33 -> 0.365,
+    //  C5 shared 0.423 -> 0.462.)
     // This wave's column blocks cw = wave, wave + 4, ..., PB of them per phase: all their gathers are in flight before the first
     // block is transposed and stored (loads and stores share vmcnt, see k_pw_rows).  Round 2 measured 2 blocks per phase on C5
     // with a shared source and found nothing (0.504 vs 0.503 ms); round 3, same box, blocks per phase 1 / 2 / 4 / 8 / 16:

@@ -3,7 +3,8 @@
 export TMPDIR=/tmp
 o=$PWD/gpurun_out/latency; rm -rf $o; mkdir -p $o
 for opt in "$@"; do
-  tag=$(echo $opt | tr ' =' '__')
+  tag=$(echo $opt | tr ' =' '__'); tag=${tag:-default}
+  tag=${tag:-default}
   python tools/latency_f.py $opt 2>&1 | grep "^{" | sed "s/^/$tag host /"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $o/trace_$tag -o t -- python $OLDPWD/tools/latency_f.py --trace $opt > $o/trace_$tag.log 2>&1)
   python tools/latency_f.py --parse $o/trace_$tag | sed "s/^/$tag device /" | tee -a $o/device.log
