@@ -325,7 +325,10 @@ PwFrames frames_of(const hg_ctx *c)
         f.rows1_threads = c->opt_rows1_threads > 0 ? c->opt_rows1_threads : 256;
         (void)groups;
     }
-    f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
+    // (self-span path: its instantiations fit 56 VGPRs / 78 SGPRs whatever the phase depth -- 8 workgroups per CU where the list-reading
+    //  4-window form admits 7 -- and 4 windows per phase then wins on every shared-source config measured, round 4 same box:
+    //  C3 step 0.603 -> 0.580 ms, 512-triangle grid 0.664 -> 0.640, 8 frames of C3 0.102 -> 0.091)
+    f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 || c->pw_self ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
     f.patch_blocks = c->opt_phase > 0 ? c->opt_phase : 8;    // (k_pw_patch: measured best in both source layouts, hg_k_patch.hip)
     return f;
 }
