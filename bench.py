@@ -16,7 +16,7 @@ RGBA, meshes, destination points) are resident in HBM before the timed region; o
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
 (one rank per GPU over RCCL); launched by torchrun directly it reads RANK/LOCAL_RANK/WORLD_SIZE as usual.
 
-Two source layouts are measured (DESIGN.md §6):
+Two source layouts are measured (DESIGN.md §7):
   shared    BASELINE.json's configuration: all F frames warp ONE source image (test/benchmark.js:107-110).  This is `value`
             and `roofline`.  Its source reads are largely served by L2 / the 256 MiB Infinity Cache, so `roofline` also
             carries `hbm_compulsory_frac` (output written once + source read once).

@@ -1,4 +1,4 @@
-// experiments/hg_ablate.h -- timing ablations of the warp kernels.  NOT part of libhgwarp.so: this header is
+// experiments/hg_ablate.h -- timing ablations of the warp kernels (EXPERIMENTS.md).  NOT part of libhgwarp.so: this header is
 // included only when hg_k_piecewise.hip is compiled with -DHG_EXPERIMENTS (`make experiments` -> lib/libhgwarp_exp.so, which
 // no binding ever loads).  Every policy below makes the kernel write WRONG pixels by design; they exist to measure what a
 // stage of the kernel costs.  Switches: HG_ABLATE (k_pw_rows) / HG_ABLATE_TRI (k_tri_spans) environment variables, bit sets:

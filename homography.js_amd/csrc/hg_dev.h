@@ -9,7 +9,7 @@
 namespace hg {
 
 // ------------------------------------------------------------------------------------------------ experiment hooks
-// The warp kernels call these hooks at the few places the timing ablations of DESIGN.md §6 alter.  The product translation
+// The warp kernels call these hooks at the few places the timing ablations of EXPERIMENTS.md alter.  The product translation
 // units only ever instantiate NoExperiment, whose hooks are identities; the ablation policies (which write WRONG pixels by
 // design) live in csrc/experiments/hg_ablate.h and are compiled only into lib/libhgwarp_exp.so (`make experiments`).
 struct NoExperiment {

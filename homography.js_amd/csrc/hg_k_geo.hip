@@ -203,7 +203,7 @@ void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double 
 // one lane per frame: projective = the 8x8 DLT system through numeric.js' LU in its exact operation order
 // (solve_projective_regs, hg_math.h: all in registers), affine = the closed form of affineMatrixFromTriangles (f32 result,
 // widened).  Also decides per projective frame whether the shared-reciprocal division is admissible for its window.
-// MFMA is not used on purpose: the order of the ~500 roundings of the LU is observable in the result (DESIGN.md §7).
+// MFMA is not used on purpose: the order of the ~500 roundings of the LU is observable in the result (DESIGN.md §8).
 __global__ __launch_bounds__(64) void k_solve_frames(int kind, const float *__restrict__ from, const float *__restrict__ to,
                                                      const FrameDesc *__restrict__ frames, double *__restrict__ mats, int32_t *__restrict__ plain, int n)
 {

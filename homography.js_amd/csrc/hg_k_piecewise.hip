@@ -775,7 +775,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         }
     };
 
-    // One window per wave iteration.  Measured alternatives: two windows in flight per wave (74 VGPRs, 6
+    // One window per wave iteration.  Measured alternatives (EXPERIMENTS.md): two windows in flight per wave (74 VGPRs, 6
     // waves/SIMD) and a phased variant (4 windows resolved, then 16 gathers, then 16 stores) are both ~4 % slower: with
     // 8 waves/SIMD the other waves already cover a window's memory latency, and reads + writes together run at ~5.2 TB/s.
     if (SELF) {
@@ -913,7 +913,7 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
         return;
     }
 #ifdef HG_EXPERIMENTS
-    // Timing experiments of DESIGN.md §6 (ablated variants produce WRONG pixels): only in the separate experiments build
+    // Timing experiments of EXPERIMENTS.md (ablated variants produce WRONG pixels): only in the separate experiments build
     // (`make experiments` -> lib/libhgwarp_exp.so); the shipped library has neither the instantiations nor the switch.
     if (launch_pw_rows_ablated(mesh, fr, rl, out, map_out, rpx, rg, status_next, grid, stream)) return;     // experiments/hg_ablate.h
 #endif

@@ -102,11 +102,11 @@ CONFIGS = {
     # 68-landmark face mesh, 512 frames in total; triangles from the host Delaunay (hg_triangulate)
     "C4": dict(kind="face", W=3840, H=2160, landmarks=68, total_frames=512),
     "C5": dict(kind="piecewise", W=7680, H=4320, nx=50, ny=50, A=80.0),
-    # experiments only: the same meshes (almost) without vertical displacement
+    # experiments only (EXPERIMENTS.md): the same meshes (almost) without vertical displacement
     "C3flat": dict(kind="piecewise", W=3840, H=2160, nx=10, ny=10, A=1.0),
     # C5's mesh density without its steep shear
     "C5flat": dict(kind="piecewise", W=7680, H=4320, nx=50, ny=50, A=8.0),
-    # 4K grids between C3's 200 and C5's 5 000 triangles (producer-kernel policy)
+    # 4K grids between C3's 200 and C5's 5 000 triangles (producer / self-span policy, EXPERIMENTS.md)
     "G16": dict(kind="piecewise", W=3840, H=2160, nx=16, ny=16, A=24.0),
     "G24": dict(kind="piecewise", W=3840, H=2160, nx=24, ny=24, A=16.0),
     "G40": dict(kind="piecewise", W=3840, H=2160, nx=40, ny=40, A=10.0),

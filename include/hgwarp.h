@@ -282,7 +282,7 @@ int hg_last_piecewise_self(hg_ctx *ctx);
 int hg_last_forward_kernel(hg_ctx *ctx);
 /* Host-side admission test of k_fwd_tiles (no GPU needed): 0 = this forward matrix (6 or 8 doubles) / source size / window
  * goes through scatter + gather; 1 = admissible; 2 = admissible and the inverse is trusted for the per-tile source row range.
- * Bounds: DESIGN.md §4.6 (matrix magnitudes, projective denominator >= 1e-2 at the source corners, no source pixel more than
+ * Bounds: DESIGN.md §4.7 / EXPERIMENTS.md (matrix magnitudes, projective denominator >= 1e-2 at the source corners, no source pixel more than
  * 30 columns outside the window, window at least 64 wide). */
 int hg_forward_tiles_admissible(int kind, const double *m, int W, int H, hg_geom geom);
 /* Frames the fused kernels only flagged (row lists / kernel limits exceeded, irregular spans) and hg_sync redid through the
@@ -302,7 +302,7 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "self_spans" (default -1 = by policy; 1 = whenever eligible: sparse meshes of up to 1024 triangles; 0 never): no span
  *           producer kernel and no per-output-row span lists -- k_tri_setup writes every triangle's edge equations, inverse matrix
  *           and row reach, and each row workgroup of the warp kernel picks the triangles that reach its rows and evaluates
- *           predictXLimits + the fill() indices for exactly those rows in its prologue (DESIGN.md §4.1c).  Bit-identical;
+ *           predictXLimits + the fill() indices for exactly those rows in its prologue (DESIGN.md §4.2).  Bit-identical;
  *   "hi_bounds" (default 1): the source-bounds tests of the pixel loops (:1047, :1001) as 32-bit compares on the high dwords
  *           of the rounded coordinates (exact whenever the source window starts at >= 0 and ends below 2^20; the kernels
  *           fall back to the fp64 compares by themselves otherwise), 0 = always the fp64 compares;

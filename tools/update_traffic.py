@@ -8,7 +8,10 @@ rnd = int(sys.argv[1])
 tag = f"r{rnd:02d}"
 path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 entries = json.load(open(path))
-old = {(e["config"], e["sources"]): e for e in entries if e.get("round") == rnd}
+old = {(e["config"], e.get("sources", "shared")): e for e in entries if e.get("round") == rnd}
+anyround = {}                                             # algorithmic bytes / frames per launch do not change with the round: the latest earlier entry carries them
+for e in sorted(entries, key=lambda e: e.get("round", 0)):
+    anyround[(e["config"], e.get("sources", "shared"))] = e
 entries = [e for e in entries if e.get("round") != rnd]
 for config in ("C3", "C4", "C5", "C2"):
     for sources in ("shared", "distinct"):
@@ -28,7 +31,7 @@ for config in ("C3", "C4", "C5", "C2"):
         wr = None
         for m in re.finditer(r"^\s+(void hg::)?(k_pw_rows_s80|k_pw_rows|k_pw_patch|k_geo_fast)\S*.*?WRITE_SIZE\s+n=\s*(\d+) avg=(\S+)", text, re.M):
             if m.group(2) == kern and (wr is None or int(m.group(3)) > wr[0]): wr = (int(m.group(3)), float(m.group(4)))
-        prev = old.get((config, sources), {})
+        prev = old.get((config, sources)) or anyround.get((config, sources), {})
         alg = prev.get("algorithmic_bytes_per_launch")
         hbm = int(round((2 * fetch + wr[1]) * 1024))
         e = {"round": rnd, "config": config, "frames_per_launch": prev.get("frames_per_launch", 8 if config == "C5" else 64), "sources": sources,
