@@ -827,6 +827,115 @@ def test_irregular_and_overflow_frames_fall_back_to_map_path(ctx):
     assert np.array_equal(ctx.warp_inverse_piecewise_via_map(), want2)
 
 
+def test_self_span_path_policy_flags_and_falls_back():
+    """The self-span path (k_tri_setup + k_pw_rows<SELF> / k_pw_patch<SELF>: the row workgroups evaluate the spans of their own rows, no
+    row lists): (a) taken by default for a frame set that fills the chip, not for a single frame, forced / forbidden by the option, same
+    bytes either way and equal to the oracle; (b) k_pw_patch<SELF> with candidate bands (a mesh beyond 256 triangles, one source per
+    frame) == row lists == oracle; (c) a mesh with more spans per row than its LDS blocks hold flags its frames: they are redone through
+    the map path (still bit-exact) and the context returns to row lists for that mesh."""
+    c = HG.Context(0)
+    try:
+        # (a) policy
+        W, H, nx, ny, F = 1024, 768, 8, 6, 12
+        img = G.lcg_image(W, H, 61)
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        frames = [WL.sin_dst(sp, 6.0 + f, 8 + (f % 4)) for f in range(F)]
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        ms = WL.src_min(sp)
+        offs, total = HG.pack_offsets(geoms)
+        c.set_image(img)
+        c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+        d_out = c.alloc(total)
+        try:
+            want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(F)]
+            seen = {}
+            for opt in (-1, 0, 1):
+                c.set_option("self_spans", opt)
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                seen[opt] = c.last_piecewise_self()
+                for f in range(F):
+                    g = geoms[f]
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), (opt, f)
+            assert seen == {-1: 1, 0: 0, 1: 1}, seen               # 12 frames x 192 four-row groups = 2304 >= min_row_groups: self-spans by default
+            c.set_option("self_spans", -1)
+            c.piecewise_prepare(frames[0], geoms[0])                 # a single frame: small set -> row lists by default
+            assert np.array_equal(c.warp_inverse_piecewise(), want[0]) and c.last_piecewise_self() == 0
+            c.set_option("self_spans", 1)
+            c.piecewise_prepare(frames[0], geoms[0])                 # ... forced: the short-latency prologue instantiation
+            assert np.array_equal(c.warp_inverse_piecewise(), want[0]) and c.last_piecewise_self() == 1
+            assert np.array_equal(c.get_tri_map(fused=True), O.warp_inverse_piecewise(sp, frames[0], tris, img, ms[0], ms[1], *geoms[0], taps=True)[1])
+            assert c.redone_frames() == 0
+        finally:
+            c.free(d_out)
+        # (b) k_pw_patch<SELF> with bands: 30 x 20 cells = 1200 triangles, one source per frame
+        W, H, nx, ny, F, NI = 1536, 1024, 30, 20, 6, 3
+        imgs = [G.lcg_image(W, H, 300 + k) for k in range(NI)]
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        frames = [WL.sin_dst(sp, 9.0 + f, 8 + (f % 4)) for f in range(F)]
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        ms = WL.src_min(sp)
+        offs, total = HG.pack_offsets(geoms)
+        stride = W * H * 4
+        d_src, d_out = c.alloc(stride * NI), c.alloc(total)
+        try:
+            for k in range(NI):
+                c.to_device(d_src, imgs[k], k * stride)
+            c.set_images_device(d_src, W, H, NI, stride)
+            c.set_option("min_row_groups", 0)
+            c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+            want = [O.warp_inverse_piecewise(sp, frames[f], tris, imgs[f % NI], ms[0], ms[1], *geoms[f]) for f in range(F)]
+            for opt in (1, 0):
+                c.set_option("self_spans", opt)
+                c.set_option("patch", 1)
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                assert c.last_piecewise_kernel() == 3 and c.last_piecewise_self() == opt, (opt, c.last_piecewise_kernel(), c.last_piecewise_self())
+                for f in range(F):
+                    g = geoms[f]
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), ("bands", opt, f)
+            assert c.redone_frames() == 0
+        finally:
+            c.set_image(imgs[0])
+            c.free(d_out)
+            c.free(d_src)
+        # (c) 320 x 1 cells, 7 small frames: the host skips its per-triangle walk for such sets and guesses ~63 spans per row, every row is
+        #     crossed by ~640 -> the one-row self-span blocks (255) overflow -> frames flagged -> map path; then row lists for this mesh
+        c.set_option("patch", 0); c.set_option("compact", 0); c.set_option("self_spans", 1); c.set_option("min_row_groups", 1 << 30)
+        W, H, F = 2560, 40, 7
+        img = G.lcg_image(W, H, 62)
+        sp, tris = WL.grid_points(W, H, 320, 1), WL.grid_triangles(320, 1)
+        frames = []
+        for f in range(F):
+            d = sp.copy(); d[1::2] *= np.float32(1.25 + 0.05 * f)
+            frames.append(d)
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        ms = WL.src_min(sp)
+        offs, total = HG.pack_offsets(geoms)
+        c.set_image(img)
+        c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+        want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(F)]
+        d_out = c.alloc(total)
+        try:
+            r0 = c.redone_frames()
+            for rnd, self_expected in ((0, 1), (1, 0)):
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                assert c.last_piecewise_self() == self_expected, (rnd, c.last_piecewise_self())
+                for f in range(F):
+                    g = geoms[f]
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), ("overflow", rnd, f)
+                if rnd == 0:
+                    assert c.redone_frames() == r0 + F               # every frame flagged, redone through the materialised map
+        finally:
+            c.free(d_out)
+    finally:
+        c.close()
+
+
 def test_fresh_point_sets_queue_without_settling_and_redo_from_their_own_set(ctx):
     """The reference's loop uploads new destination points before every warp (test/benchmark.js:107-110).  Here sets and runs
     are queued back to back with no sync in between, into different outputs; set 1 is a mesh too dense for the row lists (its
