@@ -61,13 +61,13 @@ extern "C" void hg_destroy(hg_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
-    void *ptrs[] = { c->d_src, c->d_tris, c->d_set, c->d_trir, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent, c->d_bands,
+    void *ptrs[] = { c->d_src, c->d_tris, c->d_set, c->d_trir, c->d_trix, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent, c->d_bands,
                      c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_fwd_status, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (hg_ctx::Stage &st : c->stage) { if (st.h) (void)hipHostFree(st.h); if (st.done) (void)hipEventDestroy(st.done); }
     for (hg_ctx::GeoStage &gs : c->geo_stage) { if (gs.h) (void)hipHostFree(gs.h); if (gs.done) (void)hipEventDestroy(gs.done); }
-    { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status };
+    { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_trix, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status };
       for (void *q : rp) if (q) (void)hipFree(q); }
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -185,6 +185,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
     else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
     else if (!std::strcmp(key, "compact")) c->opt_compact = value < 0 ? -1 : (value ? 1 : 0);
+    else if (!std::strcmp(key, "tile")) { c->opt_tile = value < 0 ? -1 : (value ? 1 : 0); c->pw_tile_disabled = false; }
     else if (!std::strcmp(key, "self_spans")) { c->opt_self = value < 0 ? -1 : (value ? 1 : 0); c->pw_self_disabled = false; }
     else if (!std::strcmp(key, "tri_threads")) c->opt_tri_threads = (value == 64 || value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "tri_group")) c->opt_tri_group = value < 0 ? -1 : (value >= 64 ? 64 : (value ? 16 : 0));

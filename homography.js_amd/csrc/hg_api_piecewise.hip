@@ -36,7 +36,7 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
     c->have_mesh = true;
     c->mesh_gen++;
     c->fwd_pw_tiles_disabled = false; c->fwd_pw_cap = 64;     // (learned on the previous mesh)
-    c->pw_self_disabled = false;
+    c->pw_self_disabled = false; c->pw_tile_disabled = false;
     c->pw_frames.clear(); c->pw_setup_done = false;
     return HG_OK;
 }
@@ -154,6 +154,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     HG_TRY(fill_frames(c, fresh, geoms, offs, n));
     HG_TRY(ensure(c, c->d_set, c->set_cap, sizeof(FrameDesc) * F + sizeof(float) * 2 * c->n_pts * F));
     HG_TRY(ensure(c, c->d_trir, c->trir_cap, F * T));
+    HG_TRY(ensure(c, c->d_trix, c->trix_cap, F * T));
     HG_TRY(ensure(c, c->d_segs, c->segs_cap, F * T * 3));
     HG_TRY(ensure(c, c->d_fwd, c->fwd_cap, F * T * 6));
     HG_TRY(ensure(c, c->d_inv, c->inv_cap, F * T * kInvStride));
@@ -287,7 +288,7 @@ static RowLists rows_of(const hg_ctx *c);
 PwFrames frames_of(const hg_ctx *c)
 {
     PwFrames f;
-    f.frames = c->d_pw_frames; f.dst_pts = c->d_dst; f.trir = c->d_trir; f.segs = c->d_segs; f.fwd = c->d_fwd; f.inv = c->d_inv;
+    f.frames = c->d_pw_frames; f.dst_pts = c->d_dst; f.trir = c->d_trir; f.trix = c->d_trix; f.segs = c->d_segs; f.fwd = c->d_fwd; f.inv = c->d_inv;
     f.status = c->status_ptr ? c->status_ptr : c->d_status; f.n_frames = (int)c->pw_frames.size();
     int mh = 0;
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
@@ -401,6 +402,12 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         const bool self_patch = self_ok && want_patch && !global_records && (c->n_tris <= 256 || c->pw_tri_rows_max > 0);
         const bool self_rows = self_ok && !want_patch && !compact && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 && (c->pw_row_group == 1 || c->pw_cover <= 56);
         c->pw_self_patch = self_patch;
+        // k_pw_tile instead of k_pw_patch<SELF> where every frame streams its own source (option "tile" forces either).  Measured
+        // same box, one source per frame, patch -> tile (EXPERIMENTS.md R4.7): C5 0.580 -> 0.502 ms, its mesh at 3/4, 1/2, 1/4, 1/8 of the
+        // shear 0.551 -> 0.486, 0.488 -> 0.449, 0.456 -> 0.440, 0.444 -> 0.430; C3 at 4x / 2x its shear 1.082 -> 0.980, 0.889 -> 0.860, C3
+        // itself 0.810 -> 0.814, C4 0.341 -> 0.336, 40x40 / 64x36 grids 0.895 -> 0.889, 0.991 -> 0.978.  With a shared source the source
+        // lines of a 4-row patch are L2 hits anyway and the taller tile only costs: C5 0.411 -> 0.413, 40x40 grid 0.741 -> 0.767.
+        c->pw_tile = self_patch && !c->pw_tile_disabled && mw >= 512 && (c->opt_tile >= 0 ? c->opt_tile == 1 : c->n_imgs > 1);
         c->pw_bands = self_patch && c->n_tris > 256;
         if (c->pw_bands && (std::max(max_h, 1) + 63) / 64 > 2048) { c->pw_bands = false; c->pw_self_patch = false; }      // (kBandMax; frames taller than 131 072 rows)
         if (c->pw_bands) {
@@ -410,7 +417,7 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
             int cap = (int)std::min<double>((double)c->n_tris, std::max(256.0, 2.0 * per_band));
             cap = (cap + 63) & ~63;
             if (cap > c->band_cap) c->band_cap = cap;
-            const size_t need = F * (size_t)c->n_bands * (size_t)c->band_cap;
+            const size_t need = F * (size_t)c->n_bands * (size_t)c->band_cap * 2;      // (two int4 per entry)
             if (need > c->bands_cap) HG_TRY(hg_sync(c));
             HG_TRY(ensure(c, c->d_bands, c->bands_cap, need));
         }
@@ -459,7 +466,14 @@ static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
     const bool patch = c->pw_self ? (c->pw_self_patch && !map_out) : (patch_preferred(c, &global_records) && !map_out && c->pw_compact);
     c->pw_used_patch = patch;
     c->pw_last_kernel = patch ? 3 : (c->pw_fast ? (c->pw_row_group == kRowGroup ? 1 : 2) : 4);
-    if (patch)           { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
+    if (patch && c->pw_self && c->pw_tile) {
+        int mw = 0;
+        for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
+        c->pw_last_kernel = 5;
+        c->pw_used_patch = false;                            // (a flagged tile run disables k_pw_tile for the mesh, not k_pw_patch)
+        launch_pw_tile(mesh_of(c), frames_of(c), rows_of(c), d_out, mw, c->status_next, c->stream); c->rows_clean = true;
+    }
+    else if (patch)      { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
     else if (c->pw_fast) {
         launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true;
     }
@@ -504,6 +518,7 @@ static int redo_frame_staged(hg_ctx *c, int stage, int f, uint8_t *d_out)
     HG_TRY(ensure(c, c->d_redo_frame, c->redo_frame_cap, (size_t)1));
     HG_TRY(ensure(c, c->d_redo_dst, c->redo_dst_cap, (size_t)c->n_pts * 2));
     HG_TRY(ensure(c, c->d_redo_trir, c->redo_trir_cap, T));
+    HG_TRY(ensure(c, c->d_redo_trix, c->redo_trix_cap, T));
     HG_TRY(ensure(c, c->d_redo_segs, c->redo_segs_cap, T * 3));
     HG_TRY(ensure(c, c->d_redo_fwd, c->redo_fwd_cap, T * 6));
     HG_TRY(ensure(c, c->d_redo_inv, c->redo_inv_cap, T * kInvStride));
@@ -516,7 +531,7 @@ static int redo_frame_staged(hg_ctx *c, int stage, int f, uint8_t *d_out)
     PwMesh mesh = mesh_of(c);
     mesh.img = frame_img(mesh, f); mesh.n_imgs = 1;          // this frame's own source
     PwFrames fr = frames_of(c);
-    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
+    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
     fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
     launch_tri_setup(mesh, fr, c->stream);
     launch_map_build(mesh, fr, 0, fd, c->d_map32, c->stream);
@@ -539,6 +554,7 @@ int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int ma
     HG_TRY(ensure(c, c->d_redo_frame, c->redo_frame_cap, (size_t)1));
     HG_TRY(ensure(c, c->d_redo_dst, c->redo_dst_cap, (size_t)c->n_pts * 2));
     HG_TRY(ensure(c, c->d_redo_trir, c->redo_trir_cap, T));
+    HG_TRY(ensure(c, c->d_redo_trix, c->redo_trix_cap, T));
     HG_TRY(ensure(c, c->d_redo_segs, c->redo_segs_cap, T * 3));
     HG_TRY(ensure(c, c->d_redo_fwd, c->redo_fwd_cap, T * 6));
     HG_TRY(ensure(c, c->d_redo_inv, c->redo_inv_cap, T * kInvStride));
@@ -548,7 +564,7 @@ int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int ma
     HIP_TRY(c, hipMemcpyAsync(c->d_redo_frame, st.h + sizeof(FrameDesc) * (size_t)f, sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_redo_dst, pts, sizeof(float) * 2 * c->n_pts, hipMemcpyHostToDevice, c->stream));
     PwFrames fr = frames_of(c);
-    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
+    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
     fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
     launch_tri_setup(mesh_of(c), fr, c->stream);
     launch_fwd_pw(c->d_fmap, c->d_redo_fwd, frame_img(mesh_of(c), f), c->W, c->H, c->min_src_x, c->min_src_y, max_src_x - c->min_src_x, max_src_y - c->min_src_y,
@@ -655,7 +671,8 @@ extern "C" int hg_sync(hg_ctx *c)
             if (c->pw_fast && c->row_cap < kRowSpanCapDense)      // denser mesh than assumed: larger lists next time
                 c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
             c->layout_age = 1 << 30;                             // ... and a fresh layout estimate for the next frame set
-            if (c->pw_self) c->pw_self_disabled = true;          // the self-span path flagged: more candidates / spans than its LDS blocks hold -> row lists for this mesh
+            if (c->pw_self && c->pw_tile) c->pw_tile_disabled = true;         // a tile beyond its limits: k_pw_patch<SELF> for this mesh
+            else if (c->pw_self) c->pw_self_disabled = true;          // the self-span path flagged: more candidates / spans than its LDS blocks hold -> row lists for this mesh
         }
     }
     if (!c->fwd_pending.empty()) {

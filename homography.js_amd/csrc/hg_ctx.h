@@ -46,6 +46,7 @@ struct hg_ctx {
     FrameDesc *d_pw_frames = nullptr;                         // = d_set
     float *d_dst = nullptr;                                   // = d_set + F * sizeof(FrameDesc)
     TriRange *d_trir = nullptr; size_t trir_cap = 0;
+    int2 *d_trix = nullptr; size_t trix_cap = 0;
     Seg *d_segs = nullptr; size_t segs_cap = 0;
     float *d_fwd = nullptr; size_t fwd_cap = 0;
     float *d_inv = nullptr; size_t inv_cap = 0;
@@ -102,6 +103,7 @@ struct hg_ctx {
     FrameDesc *d_redo_frame = nullptr; size_t redo_frame_cap = 0;
     float *d_redo_dst = nullptr; size_t redo_dst_cap = 0;
     TriRange *d_redo_trir = nullptr; size_t redo_trir_cap = 0;
+    int2 *d_redo_trix = nullptr; size_t redo_trix_cap = 0;
     Seg *d_redo_segs = nullptr; size_t redo_segs_cap = 0;
     float *d_redo_fwd = nullptr; size_t redo_fwd_cap = 0;
     float *d_redo_inv = nullptr; size_t redo_inv_cap = 0;
@@ -114,6 +116,9 @@ struct hg_ctx {
     bool pw_self = false;                                      // the current step uses the self-span path
     bool pw_self_disabled = false;                             // a run on it flagged a frame (more candidates / spans than its LDS blocks hold): row lists for this mesh
     bool pw_self_patch = false;                                // ... through k_pw_patch (dense / sheared meshes, one source per frame)
+    bool pw_tile = false;                                      // ... through k_pw_tile (sheared meshes: 16 x 512 tiles whose gathers follow the source rows)
+    bool pw_tile_disabled = false;                             // a tile exceeded its limits once: k_pw_patch for this mesh
+    int opt_tile = -1;                                         // option "tile": 1 whenever k_pw_patch<SELF> would run, 0 never, -1 by policy
     bool pw_bands = false;                                     // ... with candidate bands (meshes too large for every workgroup to scan)
     int4 *d_bands = nullptr; size_t bands_cap = 0;             // F x n_bands x band_cap entries (hg_kernels.h)
     int band_cap = 0, n_bands = 0;

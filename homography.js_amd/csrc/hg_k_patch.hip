@@ -86,14 +86,14 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
         if (fr.band_ent) {
             const int band = r0 >> fr.band_rows_log2;
             n_src = min(fr.band_cnt[(size_t)f * fr.band_stride + band], fr.band_cap);      // (an overfull band flagged the frame in k_tri_setup)
-            bent = fr.band_ent + ((size_t)f * fr.n_bands + band) * fr.band_cap;
+            bent = fr.band_ent + ((size_t)f * fr.n_bands + band) * fr.band_cap * 2;        // (two int4 per entry; the second holds the column reach k_pw_tile uses)
         }
         const TriRange *__restrict__ trir = fr.trir + (size_t)f * T;
         for (int i0 = 0; i0 < n_src; i0 += 256) {
             const int i = i0 + (int)threadIdx.x;
             int t = i; TriRange tr = TriRange{0, 0, 0, 0};
             if (i < n_src) {
-                if (bent) { const int4 e = bent[i]; t = e.x; tr.y_min = e.y; tr.y_end = e.z; tr.a = (int16_t)(e.w & 0xffff); tr.b = e.w >> 16; }
+                if (bent) { const int4 e = bent[2 * i]; t = e.x; tr.y_min = e.y; tr.y_end = e.z; tr.a = (int16_t)(e.w & 0xffff); tr.b = e.w >> 16; }
                 else tr = trir[i];
             }
             const int ylo0 = max(g_lo - tr.a, tr.y_min), n0 = min(g_hi - tr.b, tr.y_end - 1) - ylo0 + 1;

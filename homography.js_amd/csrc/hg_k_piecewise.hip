@@ -74,7 +74,9 @@ __device__ __forceinline__ bool tri_setup_one(const PwMesh &mesh, const PwFrames
         }
         if (irregular) atomicOr(&fr.status[f], FRAME_IRREGULAR);
         regular = !irregular;
+        if (regular) fr.trix[ft] = make_int2((int)floor(fmin(fmin(x0, x1), x2)) - 1, (int)ceil(fmax(fmax(x0, x1), x2)) + 1);
     }
+    if (!regular) fr.trix[ft] = make_int2(0, -1);
     fr.trir[ft] = tr;
     return regular;
 }
@@ -108,6 +110,8 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
         if (tr.a < -32768 || tr.a > 32767 || tr.b < -32768 || tr.b > 32767) { atomicOr(&fr.status[f], FRAME_IRREGULAR); file = false; }
     }
     const int4 ent = make_int4(t, tr.y_min, tr.y_end, (tr.a & 0xffff) | (int)((uint32_t)tr.b << 16));
+    const int2 tx = file ? fr.trix[(size_t)f * mesh.n_tris + t] : make_int2(0, -1);      // (written by this thread above)
+    const int4 ent2 = make_int4(tx.x, tx.y, 0, 0);
     // (an image-1 range that shares a band with the image-0 range files the triangle twice there: harmless, a duplicate candidate
     //  produces duplicate spans of the same id)
 #pragma unroll 1
@@ -121,7 +125,10 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
                     const int local = atomicAdd(&s_cnt[band], 1);
                     if (pass == 1) {
                         const int slot = s_base[band] + local;
-                        if (slot < fr.band_cap) fr.band_ent[((size_t)f * fr.n_bands + band) * fr.band_cap + slot] = ent;
+                        if (slot < fr.band_cap) {
+                            int4 *dst = fr.band_ent + (((size_t)f * fr.n_bands + band) * fr.band_cap + slot) * 2;
+                            dst[0] = ent; dst[1] = ent2;
+                        }
                     }
                 }
             }

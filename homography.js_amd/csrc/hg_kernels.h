@@ -53,6 +53,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     const FrameDesc *frames;
     const float *dst_pts;           // F x n_pts x 2
     TriRange *trir;                 // F x n_tris
+    int2 *trix;                     // F x n_tris: {floor(min x) - 1, ceil(max x) + 1} of the triangle's destiny vertices (column reach of its spans; k_pw_tile)
     Seg *segs;                      // F x n_tris x 3
     float *fwd;                     // F x n_tris x 6
     float *inv;                     // F x n_tris x kInvStride
@@ -77,7 +78,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     // Candidate bands of the self-span path for meshes too large to scan per workgroup (k_tri_setup files every triangle under the
     // bands of 1 << band_rows_log2 output rows it can reach; a row workgroup tests only its band's entries).  band_ent == nullptr:
     // workgroups scan trir[frame][0 .. n_tris).  Counters: the row-counter arrays (unused without row lists), index frame * band_stride + band.
-    int4 *band_ent;                 // F x n_bands x band_cap entries {triangle, y_min, y_end, a & 0xffff | b << 16}
+    int4 *band_ent;                 // F x n_bands x band_cap entries of TWO int4: {triangle, y_min, y_end, a & 0xffff | b << 16}, {xlo, xhi, 0, 0}
     int32_t *band_cnt;
     int32_t band_stride, n_bands, band_cap, band_rows_log2;
 };
@@ -123,6 +124,8 @@ constexpr int kPatchMaxW = 8192, kPatchMaxRowSpans = 215, kPatchMaxGroupTris = 2
 // global_records: the variant for up to 511 spans per row whose pixels read their matrix from the tap array instead of LDS
 constexpr int kPatchMaxRowSpansDense = 480;
 void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream);
+// Sheared meshes (self-span path only): tiles of 16 rows x 512 columns whose gathers follow the source rows (hg_k_tile.hip).
+void launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
 // the pixel loop :1042-1056 reading the map.

@@ -269,7 +269,8 @@ int hg_multi_warp_geometric_batch_images(hg_multi *multi, int kind, const float 
 int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, size_t *bytes);
 
 /* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
- * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general). */
+ * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general),
+ * 5 = k_pw_tile (8-row tiles whose gathers follow the source rows: one source per frame). */
 int hg_last_piecewise_kernel(hg_ctx *ctx);
 /* 1 if that run's row workgroups evaluated their own spans (k_tri_setup + k_pw_rows<SELF>: no row lists, no slot atomics, option
  * "self_spans"), 0 if they read the per-output-row span lists of k_tri_spans. */
@@ -323,6 +324,10 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "col_split" (default -1 = 1): 1, 2 or 4 k_pw_rows workgroups per row group, each taking a contiguous share of its windows;
  *   "lds_pad" (default -1 = 12-16 KB with one source per frame on 4-row groups, else 0): KB of unused dynamic LDS per k_pw_rows
  *           workgroup, 0..40: fewer, deeper-queued workgroups per CU where the kernel is HBM-bound;
+ *   "tile" (default -1 = whenever every frame reads its own source and k_pw_patch would evaluate its own spans; 1 = with a shared
+ *           source too; 0 never): k_pw_tile instead of k_pw_patch -- 8 x 2048-pixel tiles, gathers in 8-pixel runs along the source
+ *           rows; a tile beyond its limits (96 spans per row and tile, 128 triangle pieces) flags its frame, hg_sync
+ *           redoes it and the mesh goes back to k_pw_patch;
  *   "fwd_tiles": see hg_last_forward_kernel.
  * Unknown keys are refused (HG_ERR_INVALID). */
 int hg_set_option(hg_ctx *ctx, const char *key, int value);

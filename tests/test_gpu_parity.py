@@ -25,7 +25,8 @@ GOLD = G.load()
 LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds": 0, "xcc": 4, "self_spans": 0, "tri_group": 1, "compact": 1}, "rows1": {"min_row_groups": 1 << 30, "patch": 0, "xcc": 1, "xcc_rotate": 0, "compact": 0},
            "patch": {"min_row_groups": 0, "patch": 1, "phase": 2, "tri_group": 64}, "patch_global": {"min_row_groups": 0, "patch": 2, "hi_bounds": 0, "xcc": 2},
            "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0, "self_spans": 1},
-           "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16, "self_spans": 0, "xcc_rotate": 1, "tri_group": 0}}
+           "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16, "self_spans": 0, "xcc_rotate": 1, "tri_group": 0},
+           "tile": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 1, "xcc_rotate": 1}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))
@@ -827,6 +828,72 @@ def test_irregular_and_overflow_frames_fall_back_to_map_path(ctx):
     assert np.array_equal(ctx.warp_inverse_piecewise_via_map(), want2)
 
 
+def test_tile_kernel_policy_and_fallback():
+    """k_pw_tile (8-row x 2048-column tiles, gathers along the source rows): (a) the default exactly when every frame reads its own source,
+    never with a shared one unless forced, same bytes as k_pw_patch and the oracle either way, windows that wrap over the row end and
+    frames narrower than a tile included; (b) a row with more spans inside one tile than its LDS block holds (96) flags the frame: redone
+    through the map path, bit-exact, and the mesh goes back to k_pw_patch."""
+    c = HG.Context(0)
+    try:
+        W, H, nx, ny, F, NI = 2600, 520, 12, 6, 5, 2
+        imgs = [G.lcg_image(W, H, 700 + k) for k in range(NI)]
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        frames = [WL.sin_dst(sp, 30.0 + 9 * f, 8 + (f % 4)) for f in range(F)]     # steep shear: runs change rows inside a block
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        ms = WL.src_min(sp)
+        offs, total = HG.pack_offsets(geoms)
+        stride = W * H * 4
+        d_src, d_out = c.alloc(stride * NI), c.alloc(total)
+        try:
+            for k in range(NI):
+                c.to_device(d_src, imgs[k], k * stride)
+            c.set_option("min_row_groups", 0)
+            c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+            wants = {n: [O.warp_inverse_piecewise(sp, frames[f], tris, imgs[f % n], ms[0], ms[1], *geoms[f]) for f in range(F)] for n in (1, NI)}
+            for n_img, tile, kernel in ((NI, -1, 5), (NI, 0, 3), (1, -1, 3), (1, 1, 5)):
+                c.set_images_device(d_src, W, H, n_img, stride)
+                c.set_option("patch", 1); c.set_option("self_spans", 1); c.set_option("tile", tile)
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                assert c.last_piecewise_kernel() == kernel, (n_img, tile, c.last_piecewise_kernel())
+                for f in range(F):
+                    g = geoms[f]
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), wants[n_img][f]), (n_img, tile, f)
+            assert c.redone_frames() == 0
+        finally:
+            c.free(d_out)
+        # (b) 70 x 2 cells on 2000 columns: ~140 spans per row, all inside ONE tile (k_pw_patch holds 199 per row)
+        W2, H2, nx, ny, F = 2000, 160, 70, 2, 3
+        img = G.lcg_image(W2, H2, 811)
+        sp, tris = WL.grid_points(W2, H2, nx, ny), WL.grid_triangles(nx, ny)
+        frames = [WL.sin_dst(sp, 3.0 + f, 8 + f) for f in range(F)]
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        ms = WL.src_min(sp)
+        offs, total = HG.pack_offsets(geoms)
+        d_out = c.alloc(total)
+        try:
+            c.set_image(img)
+            c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+            c.set_option("tile", 1)
+            want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(F)]
+            kernels = []
+            for rep in range(2):
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                kernels.append(c.last_piecewise_kernel())
+                for f in range(F):
+                    g = geoms[f]
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), ("overflow", rep, f)
+            assert kernels == [5, 3] and c.redone_frames() == F, (kernels, c.redone_frames())
+        finally:
+            c.free(d_out)
+            c.free(d_src)
+    finally:
+        c.close()
+
+
 def test_self_span_path_policy_flags_and_falls_back():
     """The self-span path (k_tri_setup + k_pw_rows<SELF> / k_pw_patch<SELF>: the row workgroups evaluate the spans of their own rows, no
     row lists): (a) taken by default for a frame set that fills the chip, not for a single frame, forced / forbidden by the option, same
@@ -886,13 +953,14 @@ def test_self_span_path_policy_flags_and_falls_back():
             c.set_option("min_row_groups", 0)
             c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
             want = [O.warp_inverse_piecewise(sp, frames[f], tris, imgs[f % NI], ms[0], ms[1], *geoms[f]) for f in range(F)]
-            for opt in (1, 0):
+            for opt, tile, kernel in ((1, 0, 3), (0, -1, 3), (1, -1, 5)):   # (one source per frame: k_pw_tile by default where spans are self-evaluated)
                 c.set_option("self_spans", opt)
                 c.set_option("patch", 1)
+                c.set_option("tile", tile)
                 c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
                 c.warp_inverse_piecewise_frames_device(d_out)
                 c.sync()
-                assert c.last_piecewise_kernel() == 3 and c.last_piecewise_self() == opt, (opt, c.last_piecewise_kernel(), c.last_piecewise_self())
+                assert c.last_piecewise_kernel() == kernel and c.last_piecewise_self() == opt, (opt, tile, c.last_piecewise_kernel(), c.last_piecewise_self())
                 for f in range(F):
                     g = geoms[f]
                     assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), ("bands", opt, f)

@@ -21,7 +21,8 @@ def main():
         else: k, v = args[i].split("="); knobs[k] = [int(x) for x in v.split(",")]; i += 1
     dev = torch.device("cuda", 0)
     for config in configs:
-        cfg = wl.CONFIGS[config]; W, H = cfg["W"], cfg["H"]
+        cfg = dict(wl.CONFIGS[config]); W, H = cfg["W"], cfg["H"]
+        if "HG_A" in os.environ and "A" in cfg: cfg["A"] = float(os.environ["HG_A"])      # the sine's amplitude (shear experiments)
         F = Fopt or {"C5": 8, "C5flat": 8}.get(config, 64)
         img = torch.from_numpy(wl.lcg_image(W, H, 1)).to(dev)
         srcs = None
