@@ -392,7 +392,7 @@ def measure(args, config, F, env, primary=True):
     shared_copy = None
     if do_shared:
         elapsed, k_ms, k_launches = timed_region()
-        kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
+        kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused", 5: "k_pw_tile"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
         rf = roofline_block(k_ms, k_launches, "shared", elapsed)
         comp = compulsory_bytes_shared / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         rf["hbm_compulsory_frac"] = round(comp / HBM_PEAK_GBS, 4)
@@ -469,7 +469,7 @@ def measure(args, config, F, env, primary=True):
         ctx.set_images_device(srcs.data_ptr(), W, H, F, W * H * 4)
         elapsed_d, k_ms_d, k_launches_d = timed_region()
         kernel_shared = kernel_name                 # (the layout policy may pick another kernel when every frame streams its own source)
-        kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
+        kernel_name = ({3: "k_pw_patch", 4: "k_pw_fused", 5: "k_pw_tile"}.get(ctx.last_piecewise_kernel(), "k_pw_rows") if piecewise else "k_geo_fast<projective>")
         rd = roofline_block(k_ms_d, k_launches_d, "distinct", elapsed_d)
         kernel_name = kernel_shared or kernel_name
         rd["sources"] = f"{F} distinct {W}x{H} RGBA sources per step ({F * W * H * 4 / 1e6:.0f} MB >> 256 MiB Infinity Cache): algorithmic bytes are HBM bytes"

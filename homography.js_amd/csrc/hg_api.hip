@@ -170,6 +170,7 @@ extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kerne
 extern "C" int hg_last_forward_kernel(hg_ctx *c) { return c ? c->fwd_last_kernel : 0; }
 
 extern "C" int hg_last_piecewise_self(hg_ctx *c) { return c && c->pw_self ? 1 : 0; }
+extern "C" int hg_last_piecewise_flag(hg_ctx *c) { return c ? c->pw_last_flag : 0; }
 extern "C" long hg_redone_frames(hg_ctx *c) { return c ? c->pw_redone : 0; }
 extern "C" long hg_layout_walks(hg_ctx *c) { return c ? c->pw_layout_walks : 0; }
 

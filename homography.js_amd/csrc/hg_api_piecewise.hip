@@ -36,7 +36,7 @@ extern "C" int hg_piecewise_set_mesh(hg_ctx *c, const float *src, int n_pts, con
     c->have_mesh = true;
     c->mesh_gen++;
     c->fwd_pw_tiles_disabled = false; c->fwd_pw_cap = 64;     // (learned on the previous mesh)
-    c->pw_self_disabled = false; c->pw_tile_disabled = false;
+    c->pw_self_disabled = false; c->pw_tile_disabled = false; c->pw_patch_disabled = false;
     c->pw_frames.clear(); c->pw_setup_done = false;
     return HG_OK;
 }

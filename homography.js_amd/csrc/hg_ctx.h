@@ -73,7 +73,7 @@ struct hg_ctx {
     int opt_compact = -1;                                      // span-list entry format: 1 = 8-byte entries, 0 = 32-byte entries with the matrix, -1 by estimate
     double pw_shear = 0.0;                                     // mean |d(source row) / d(output x)| of the uploaded frames (layout heuristic)
     bool pw_patch_dense = false;                               // ... only in its global-record variant (up to 511 spans per row)
-    bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows
+    bool pw_patch_disabled = false;                            // a group exceeded k_pw_patch's limits once: stay with k_pw_rows for this mesh
     bool pw_used_patch = false;                                // the last fused run went through k_pw_patch
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
     int32_t pw_last_flag = 0;                                  // status word of the last frame a fused run flagged (bits 4..: which limit, see k_pw_patch<SELF>)

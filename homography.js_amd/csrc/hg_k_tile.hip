@@ -23,7 +23,8 @@ namespace hg {
 #define HG_TILE_COLS 2048
 #endif
 constexpr int kTileRows = 8, kTileCols = HG_TILE_COLS, kTileBlocks = kTileCols / 64, kTileCap = 96, kTileRecs = 128, kTileCands = 192,
-              kTileBinSlots = 8, kTilePitch = 72, kTilePB = HG_TILE_PB;
+              kTileBinSlots = 8, kTilePitch = 72, kTilePB = HG_TILE_PB,
+              kTileSpanPitch = kTileCap + 8;         // words between the rows' span blocks: 8 mod 64, so the eight rows a wave looks up at once start 8 banks apart (96: 4-way conflicts)
 
 template <bool HIB>
 __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int groups_per_xcd, int col_tiles,
@@ -40,10 +41,13 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
     // the OTHER counter set, every row of the frame's block: clean for the next step (ping-pong, see k_pw_rows; the band counters live there)
     if (ct == 0 && (int)threadIdx.x < kTileRows && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0 || t0 >= fd.obj_w) return;
+#if defined(HG_TILE_EXP) && HG_TILE_EXP == 6                     // timing experiment: the launch alone
+    if (fd.obj_w > 0) return;
+#endif
 
     __shared__ __align__(16) double s_rec[(kTileRecs + 1) * 6];               // {m0, m2, m4, m1, m3, m5} per candidate entry; last = NaN record
-    __shared__ uint32_t s_lohi[kTileRows * kTileCap];                          // span cells [lo, hi) of the row, relative to the tile's first column
-    __shared__ int s_key[kTileRows * kTileCap];                                // id << 14 | byte offset of the candidate's record
+    __shared__ uint32_t s_lohi[kTileRows * kTileSpanPitch];                          // span cells [lo, hi) of the row, relative to the tile's first column
+    __shared__ int s_key[kTileRows * kTileSpanPitch];                                // id << 14 | byte offset of the candidate's record
     __shared__ int s_bincnt[kTileBlocks * kTileRows];
     __shared__ __align__(4) uint8_t s_bin[kTileBlocks * kTileRows * kTileBinSlots];
     __shared__ int s_cand_tn[kTileCands], s_cand_y[kTileCands];
@@ -114,6 +118,9 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
     }
     __syncthreads();
     const int nc = s_ncand;
+#if defined(HG_TILE_EXP) && HG_TILE_EXP == 4                     // timing experiment: launch + LDS init + candidate scan alone
+    if (nc >= 0) return;
+#endif
     if (nc > kTileRecs) { if (threadIdx.x == 0) s_fail = 1 | (nc << 8); }
     // ---- (2) spans: 8 lanes per candidate entry, one source row each (predictXLimits :1172-1197 + the fill() indices :1124, the lean
     // form of span_cells: see k_pw_rows<SELF>); pieces cut at output-row boundaries, then to the tile's columns
@@ -165,16 +172,19 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
                 const int row = r - r0;
                 const int slot = atomicAdd(&s_rowcnt[row], 1);
                 if (slot >= kTileCap) continue;             // (counted: the check below fails the tile)
-                s_lohi[row * kTileCap + slot] = (uint32_t)lo | ((uint32_t)hi << 16);
-                s_key[row * kTileCap + slot] = (t << kKeyShift) | (c * 48);
+                s_lohi[row * kTileSpanPitch + slot] = (uint32_t)lo | ((uint32_t)hi << 16);
+                s_key[row * kTileSpanPitch + slot] = (t << kKeyShift) | (c * 48);
             }
         }
     }
     __syncthreads();
+#if defined(HG_TILE_EXP) && HG_TILE_EXP == 5                     // timing experiment: ... + the spans
+    if (nc >= 0) return;
+#endif
     // ---- (3) bins: span index -> every 64-pixel block of the tile it overlaps
     bool bad = s_fail != 0;
-    for (int e = threadIdx.x; e < kTileRows * kTileCap && !bad; e += 256) {
-        const int row = e / kTileCap, i = e - row * kTileCap;
+    for (int e = threadIdx.x; e < kTileRows * kTileSpanPitch && !bad; e += 256) {
+        const int row = e / kTileSpanPitch, i = e - row * kTileSpanPitch;
         const int cnt = s_rowcnt[row];
         if (cnt > kTileCap) { s_fail = 2 | (cnt << 8); continue; }
         if (i < cnt) {
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
             const int bidx = blk * kTileRows + row;
             const int nb = s_bincnt[bidx];
             const uint8_t *bin = s_bin + bidx * kTileBinSlots;
-            const int row_base = row * kTileCap;
+            const int row_base = row * kTileSpanPitch;
             if (!__any(nb > kTileBinSlots)) {
                 for (int p = 0; __any(p < nb); p++) {
                     int lo = 0, len = 0, key = 0;
@@ -260,7 +270,11 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
                 const bool inb = HIB ? hi_inb(hb, h[2 * k], h[2 * k + 1])
                                      : (bool)((int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi));   // :1047 (NaN fails)
                 const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
+#if defined(HG_TILE_EXP) && HG_TILE_EXP == 1                     // timing experiment (tools/variants.sh): no source traffic
+                px[4 * half + k] = __builtin_amdgcn_raw_buffer_load_b32(src, (inb && o == 0x7fffffffu) ? o : 0xffffffffu, 0, 0);
+#else
                 px[4 * half + k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
+#endif
             }
         }
     };
@@ -276,7 +290,11 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
 #pragma unroll
         for (int rw = 0; rw < kTileRows; rw++) {
             const uint32_t v = tile[rw * kTilePitch + lane];
+#if defined(HG_TILE_EXP) && HG_TILE_EXP == 2                     // timing experiment: no output traffic (the stores are issued and rejected)
+            __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && rw < nrows && v == 0x12345678u) ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
+#else
             __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && rw < nrows) ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
+#endif
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
         const int bidx = blk * kTileRows + (kTileRows / 2);
         const int nb = min(s_bincnt[bidx], kTileBinSlots);
         for (int p = 0; p < nb; p++) {
-            const int e = (kTileRows / 2) * kTileCap + s_bin[bidx * kTileBinSlots + p];
+            const int e = (kTileRows / 2) * kTileSpanPitch + s_bin[bidx * kTileBinSlots + p];
             const uint32_t lh = s_lohi[e];
             const int lo = (int)(lh & 0xffffu), len = (int)(lh >> 16) - lo;
             if ((unsigned)(cb + 32 - lo) < (unsigned)len) best = max(best, s_key[e]);
@@ -300,6 +318,9 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
         sl = fminf(fmaxf(sl, -1.f), 1.f);
         return (int)rintf(sl * (float)c);
     };
+#if defined(HG_TILE_EXP) && HG_TILE_EXP == 3                     // timing experiment: the prologue alone
+    if (s_fail == 0) return;
+#endif
     // this wave's blocks: wave, wave + 4, ...; kTilePB of them in flight before the first is transposed and stored
     for (int blk = wave; blk < nblk; blk += 4 * kTilePB) {
         uint32_t px[kTilePB][8];

@@ -286,6 +286,10 @@ int hg_last_forward_kernel(hg_ctx *ctx);
  * Bounds: DESIGN.md §4.7 / EXPERIMENTS.md (matrix magnitudes, projective denominator >= 1e-2 at the source corners, no source pixel more than
  * 30 columns outside the window, window at least 64 wide). */
 int hg_forward_tiles_admissible(int kind, const double *m, int W, int H, hg_geom geom);
+/* Status word of the last frame a fused piecewise run flagged (0 = none since hg_create; diagnostics): bit 0 = a triangle with
+ * non-finite / absurd vertices, bit 1 = a kernel's limits (more spans in a row than its lists or LDS blocks hold, more candidate triangles
+ * than a workgroup's list); with bit 1, bits 4.. say which limit of k_pw_rows<SELF> / k_pw_patch<SELF> / k_pw_tile and the count. */
+int hg_last_piecewise_flag(hg_ctx *ctx);
 /* Frames the fused kernels only flagged (row lists / kernel limits exceeded, irregular spans) and hg_sync redid through the
  * materialised map, since the ctx was created (tests / profiling: a steady-state workload should show 0). */
 long hg_redone_frames(hg_ctx *ctx);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off wide fuzz of the HIP path against the CPU oracle (run on the GPU box): tools/fuzz_gpu.py [trials] [seed]."""
+"""Wide fuzz of the HIP path against the CPU oracle (run on the GPU box): tools/fuzz_gpu.py [trials] [seed].
+FUZZ_TILE=1: wide frames, every trial also as a 3-frame batch (shared source and one source per frame) with k_pw_tile forced half of the time."""
 import os
 import sys
 
@@ -13,10 +14,13 @@ HG = hip.load()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = HG.Context(0)
+TILE = bool(os.environ.get("FUZZ_TILE"))
 bad = 0
+seen = {}                                                  # kernel id -> batch runs that went through it
 overflow = 0
 for t in range(trials):
     W, H = int(rng.integers(8, 700)), int(rng.integers(8, 400))
+    if TILE: W, H = int(rng.integers(300, 1500)), int(rng.integers(24, 260))
     img = G.lcg_image(W, H, 9000 + t)
     mode = t % 8
     # a random kernel-layout policy per trial (results must not depend on it): k_pw_rows phases, row groups, k_pw_patch variants,
@@ -28,6 +32,9 @@ for t in range(trials):
     ctx.set_option("fwd_tiles", int(rng.choice([-1, 0, 1, 1])))
     ctx.set_option("hi_bounds", int(rng.choice([1, 1, 0])))
     ctx.set_option("self_spans", int(rng.choice([-1, 1, 0])))
+    ctx.set_option("tile", int(rng.choice([-1, 1, 1, 0])))
+    if TILE:
+        ctx.set_option("self_spans", 1); ctx.set_option("patch", 1); ctx.set_option("min_row_groups", 0)
     ctx.set_option("xcc_rotate", int(rng.choice([-1, 0, 1])))
     ctx.set_option("tri_group", int(rng.choice([-1, 0, 16, 64])))
     ctx.set_option("compact", int(rng.choice([-1, -1, 0, 1])))
@@ -43,7 +50,7 @@ for t in range(trials):
         sp = sp * 1.3 - np.array([W, H]) * 0.15                                            # minSrc < 0 (general kernel)
     jit = rng.uniform(0, 0.45)
     dp = (sp + rng.uniform(-jit, jit, sp.shape) * [W / nx, H / ny]) * rng.uniform(0.3, 3.0, 2) + rng.uniform(-80, 120, 2)
-    if mode == 3:
+    if mode == 3 or (TILE and t % 2):
         dp[:, 1] += np.sin(dp[:, 0] * 0.37) * rng.uniform(1, 40)                            # steep shear
     if mode == 4:
         dp = np.round(dp * 2) / 2                                                           # .0 / .5 vertices (ties)
@@ -66,7 +73,7 @@ for t in range(trials):
         ok = ok and np.array_equal(ctx.get_tri_map(fused=True), wmap)
     except HG.HgError:
         overflow += 1          # more spans in a row than the fused kernel's LDS list: the warp itself went through the map path
-    if mode == 7:                                                                           # the same mesh as a 3-frame batch with different windows
+    if mode == 7 or TILE:                                                                   # the same mesh as a 3-frame batch with different windows
         frames = [dp32, (dp * rng.uniform(0.6, 1.4, 2) + rng.uniform(-30, 30, 2)).astype(np.float32).ravel(),
                   (dp + rng.uniform(-3, 3, dp.shape)).astype(np.float32).ravel()]
         geoms = []
@@ -80,6 +87,8 @@ for t in range(trials):
             ctx.warp_inverse_piecewise_frames_device(d_out)
             ctx.warp_inverse_piecewise_frames_device(d_out)                                 # queued twice: self-cleaning counters
             ctx.sync()
+            seen[ctx.last_piecewise_kernel()] = seen.get(ctx.last_piecewise_kernel(), 0) + 1
+            if os.environ.get("FUZZ_DEBUG"): print("batch", t, mode, "kernel", ctx.last_piecewise_kernel(), "self", ctx.last_piecewise_self(), "geoms", geoms, "tris", tris.size // 3, "redone", ctx.redone_frames(), "flag", hex(ctx.last_piecewise_flag()), flush=True)
             for f, g in enumerate(geoms):
                 gotf = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
                 ok = ok and np.array_equal(gotf, O.warp_inverse_piecewise(sp32, frames[f], tris, img, int(ms[0]), int(ms[1]), *g))
@@ -91,6 +100,7 @@ for t in range(trials):
             ctx.set_images_device(d_src, W, H, 3, W * H * 4)
             ctx.warp_inverse_piecewise_frames_device(d_out)
             ctx.sync()
+            seen[ctx.last_piecewise_kernel()] = seen.get(ctx.last_piecewise_kernel(), 0) + 1
             for f, g in enumerate(geoms):
                 gotf = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
                 ok = ok and np.array_equal(gotf, O.warp_inverse_piecewise(sp32, frames[f], tris, imgs[f], int(ms[0]), int(ms[1]), *g))
@@ -146,5 +156,5 @@ for t in range(trials):
     if not ok:
         bad += 1
         print("MISMATCH trial", t, "mode", mode, W, H, nx, ny, geom, flush=True)
-print(f"fuzz done: {trials} trials, {bad} mismatches, {overflow} frames through the map-path fallback")
+print(f"fuzz done: {trials} trials, {bad} mismatches, {overflow} frames through the map-path fallback, batch runs by kernel id {dict(sorted(seen.items()))}, redone frames {ctx.redone_frames()}")
 sys.exit(1 if bad else 0)

@@ -59,7 +59,7 @@ def parse(d):
     steps = []                                             # (tri_start, tri_end, warp_start, warp_end)
     i = 0
     while i + 1 < len(rows):
-        if ("k_tri_spans" in rows[i][0] or "k_tri_setup" in rows[i][0]) and ("k_pw_rows" in rows[i + 1][0] or "k_pw_patch" in rows[i + 1][0]):
+        if ("k_tri_spans" in rows[i][0] or "k_tri_setup" in rows[i][0]) and (any(k in rows[i + 1][0] for k in ("k_pw_rows", "k_pw_patch", "k_pw_tile"))):
             steps.append((rows[i][1], rows[i][2], rows[i + 1][1], rows[i + 1][2], rows[i + 1][0])); i += 2
         else: i += 1
     per = 20 + REPS                                        # warmup + synced steps per F
