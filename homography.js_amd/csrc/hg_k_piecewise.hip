@@ -477,6 +477,9 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     //  previous step's geometry, whose frame may have been a row taller)
     if ((int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
+#if defined(HG_ROWS_EXP) && HG_ROWS_EXP == 6                     // timing experiment: the launch alone
+    if (fd.obj_w > 0) return;
+#endif
 
     __shared__ __align__(16) double s_m[CAP * 6];
     __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (KS)
@@ -639,7 +642,8 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     edge(q0); edge(q1); edge(q2);
                 } else {
                     // one edge at a time: with all three in flight the prologue would need 14 registers more than the pixel loop does
-                    // (72 instead of 56-58: 7 waves per SIMD instead of 8)
+                    // (72 instead of 56-58: 7 waves per SIMD instead of 8).  The three dependent round trips this costs are NOT what the
+                    // prologue's time is made of (EXPERIMENTS.md R4.8: forming the edges from the vertices in one round trip changed nothing)
 #pragma unroll 1
                     for (int e = 0; e < 3; e++) edge(sg[e]);
                 }
@@ -790,6 +794,9 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
             if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
             return;
         }
+#if defined(HG_ROWS_EXP) && HG_ROWS_EXP == 3                     // timing experiment (tools/variants.sh): the prologue alone
+        if (nrows > 0) return;
+#endif
         const int row = packed ? wave : 0;
         const int cnt = __builtin_amdgcn_readfirstlane(cnts[0] * (row == 0) + cnts[1] * (row == 1) + cnts[2] * (row == 2) + cnts[3] * (row == 3));
         if (row < nrows) do_row(row, cnt, packed ? wave * 64 : 0, packed ? 63 : CAP - 1, w_lo + (packed ? 0 : wave), packed ? 1 : nwaves);

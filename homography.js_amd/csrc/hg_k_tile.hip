@@ -174,31 +174,25 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
                 if (slot >= kTileCap) continue;             // (counted: the check below fails the tile)
                 s_lohi[row * kTileSpanPitch + slot] = (uint32_t)lo | ((uint32_t)hi << 16);
                 s_key[row * kTileSpanPitch + slot] = (t << kKeyShift) | (c * 48);
+                // ... and into the bin of every 64-pixel block of the tile it overlaps, right here: a pass of its own over the span blocks
+                // (one more barrier, every workgroup's full latency) cost 12-35 us of the kernel, EXPERIMENTS.md R4.7
+                for (int b = lo >> 6; b <= (hi - 1) >> 6; b++) {
+                    const int pos = atomicAdd(&s_bincnt[b * kTileRows + row], 1);      // (a count beyond the slots marks the bin as overfull)
+                    if (pos < kTileBinSlots) s_bin[(b * kTileRows + row) * kTileBinSlots + pos] = (uint8_t)slot;
+                }
             }
         }
     }
     __syncthreads();
-#if defined(HG_TILE_EXP) && HG_TILE_EXP == 5                     // timing experiment: ... + the spans
+#if defined(HG_TILE_EXP) && HG_TILE_EXP == 5                     // timing experiment: ... + the spans and bins
     if (nc >= 0) return;
 #endif
-    // ---- (3) bins: span index -> every 64-pixel block of the tile it overlaps
-    bool bad = s_fail != 0;
-    for (int e = threadIdx.x; e < kTileRows * kTileSpanPitch && !bad; e += 256) {
-        const int row = e / kTileSpanPitch, i = e - row * kTileSpanPitch;
-        const int cnt = s_rowcnt[row];
-        if (cnt > kTileCap) { s_fail = 2 | (cnt << 8); continue; }
-        if (i < cnt) {
-            const uint32_t lh = s_lohi[e];
-            const int lo = (int)(lh & 0xffffu), hi = (int)(lh >> 16);
-            for (int b = lo >> 6; b <= (hi - 1) >> 6 && b < nblk; b++) {
-                const int pos = atomicAdd(&s_bincnt[b * kTileRows + row], 1);
-                if (pos < kTileBinSlots) s_bin[(b * kTileRows + row) * kTileBinSlots + pos] = (uint8_t)i;
-            }
-        }
-    }
-    __syncthreads();
-    if (s_fail) {                                           // the host redoes the frame through the materialised map
-        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW | (s_fail << 4));
+    // ---- (3) limits: every thread reads the eight row counts (no further barrier)
+    int fail = s_fail;
+#pragma unroll
+    for (int r = 0; r < kTileRows; r++) { const int cnt = s_rowcnt[r]; if (cnt > kTileCap && fail == 0) fail = 2 | (cnt << 8); }
+    if (fail) {                                             // the host redoes the frame through the materialised map
+        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW | (fail << 4));
         return;
     }
 
