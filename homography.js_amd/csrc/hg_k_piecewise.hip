@@ -741,6 +741,9 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     constexpr int STEP = PH == 1 ? 4 : 2;
 #pragma unroll
                     for (int kk = 0; kk < 4; kk += STEP) {
+                        // the ragged last window of a row: a pair of 64-pixel pieces wholly past the row end is not computed at all (its
+                        // stores would be dropped by the range check anyway; wave-uniform test) -- a 2170-pixel row has 2 dead pieces in 36
+                        if (STEP == 2 && kk == 2 && c0 + 128 >= W) { px[p][2] = px[p][3] = 0u; continue; }
                         double h[2 * STEP], rd[2 * STEP];
 #pragma unroll
                         for (int k = kk; k < kk + STEP; k++) {
