@@ -315,6 +315,7 @@ PwFrames frames_of(const hg_ctx *c)
     // stay in that XCD's L2 from frame to frame), rotating with the frame otherwise (even load; measured in hg_k_piecewise.hip)
     f.xcc_rotate = c->opt_xcc_rotate >= 0 ? (c->opt_xcc_rotate != 0) : (c->n_imgs > 1 || c->pw_fill > 1.08);
     f.xcc_log2 = c->xcc_log2; f.no_hi_bounds = c->opt_hi_bounds ? 0 : 1;
+    f.rows8 = c->pw_rows8 ? 1 : 0;
     f.sgpr_cap = c->opt_sgpr_cap >= 0 ? (c->opt_sgpr_cap != 0) : (c->n_imgs <= 1);
     f.lds_pad_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : (c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0);
     f.lds_pad_patch_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : 0;
@@ -402,6 +403,9 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         const bool self_patch = self_ok && want_patch && !global_records && (c->n_tris <= 256 || c->pw_tri_rows_max > 0);
         const bool self_rows = self_ok && !want_patch && !compact && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 && (c->pw_row_group == 1 || c->pw_cover <= 56);
         c->pw_self_patch = self_patch;
+        // 8-row workgroups (k_pw_rows8: one candidate scan and one launch slot per eight rows).  Same box, shared source, 4 -> 8 rows: C3 (200
+        // triangles) 0.588 -> 0.576 ms, C4 (110) 0.2263 -> 0.2260, a 16 x 16 grid (512) 0.628 -> 0.636: small meshes only.
+        c->pw_rows8 = self_rows && c->pw_row_group == kRowGroup && (c->opt_rows8 >= 0 ? c->opt_rows8 == 1 : c->n_tris <= 256);
         // k_pw_tile instead of k_pw_patch<SELF> where every frame streams its own source (option "tile" forces either).  Measured
         // same box, one source per frame, patch -> tile (EXPERIMENTS.md R4.7): C5 0.580 -> 0.502 ms, its mesh at 3/4, 1/2, 1/4, 1/8 of the
         // shear 0.551 -> 0.486, 0.488 -> 0.449, 0.456 -> 0.440, 0.444 -> 0.430; C3 at 4x / 2x its shear 1.082 -> 0.980, 0.889 -> 0.860, C3

@@ -115,6 +115,7 @@ struct hg_ctx {
     bool pw_small_set = false;                                 // fewer 4-row groups than "min_row_groups": one row per workgroup, short-latency prologues
     bool pw_self = false;                                      // the current step uses the self-span path
     bool pw_self_disabled = false;                             // a run on it flagged a frame (more candidates / spans than its LDS blocks hold): row lists for this mesh
+    bool pw_rows8 = false;                                     // ... with 8-row workgroups (k_pw_rows8)
     bool pw_self_patch = false;                                // ... through k_pw_patch (dense / sheared meshes, one source per frame)
     bool pw_tile = false;                                      // ... through k_pw_tile (sheared meshes: 16 x 512 tiles whose gathers follow the source rows)
     bool pw_tile_disabled = false;                             // a tile exceeded its limits once: k_pw_patch for this mesh
@@ -126,6 +127,7 @@ struct hg_ctx {
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
     int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate
     int opt_tri_group = -1;                                    // k_tri_spans_grouped: 16 / 64 triangles per workgroup, 0 never, -1 by mesh size
+    int opt_rows8 = -1;                                        // k_pw_rows<SELF>: 8 rows per workgroup (1), 4 (0), -1 by policy
     int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
     int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
     // layout estimates of the last frame set, reused for the next set of the same shape (the kernels check the real counts)

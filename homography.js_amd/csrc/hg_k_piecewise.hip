@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh m
 }
 
 
-template <int CAP, class X, bool MAP, int PH, bool COMPACT, bool HIB, int SELF>      // SELF: 0 row lists, 1 own spans, 2 the same with all three edges in flight (small frame sets)
+template <int CAP, class X, bool MAP, int PH, bool COMPACT, bool HIB, int SELF, int RG = kRowGroup>      // SELF: 0 row lists, 1 own spans, 2 the same with all three edges in flight (small frame sets); RG: rows per group in packed mode (8: k_pw_rows8, SELF only)
 __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *__restrict__ out,
                                              int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
                                              int32_t *__restrict__ status_next)
@@ -483,7 +483,8 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
 
     __shared__ __align__(16) double s_m[CAP * 6];
     __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (KS)
-    static_assert(CAP >= 64 * kRowGroup, "packed mode gives each of the 4 rows a 64-slot block");
+    static_assert(CAP >= 64 * RG, "packed mode gives each of the RG rows a 64-slot block");
+    static_assert(RG == kRowGroup || (RG == 8 && SELF == 1), "8-row groups exist for the self-span path only");
     constexpr int KS = CAP * 48 <= (1 << kKeyShift) ? kKeyShift : kKeyShift + 1, KMASK = (1 << KS) - 1;   // id << KS | record offset
     static_assert(CAP * 48 <= (1 << KS) && KS <= 15, "record offsets must fit below the 15-bit id");
 
@@ -502,19 +503,19 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // SELF (round 4, hg_kernels.h): no row lists exist; the workgroup evaluates the spans of its own rows in the prologue below
     // (4-row groups are always "packed", one-row groups use the whole LDS) and the counts come out of it.
     constexpr int kCandCap = SELF ? 256 : 1;
-    __shared__ int s_cnt[kRowGroup], s_ncand;
+    __shared__ int s_cnt[RG], s_ncand;
     __shared__ int s_cand_tn[kCandCap], s_cand_y[kCandCap];      // candidate: triangle | rows << 16, first source row
-    int cnts[kRowGroup], cmax = 0;
+    int cnts[RG], cmax = 0;
     if (!SELF) {
         const int32_t *cntp = rl.cnt + (size_t)f * rl.row_stride + r0;
 #pragma unroll
-        for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
+        for (int j = 0; j < RG; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
         if (cmax > rl.cap || cmax > CAP - 1) {
             if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
             return;
         }
     }
-    const bool packed = SELF ? rows_per_group == kRowGroup : (rows_per_group == kRowGroup && __builtin_amdgcn_readfirstlane(cmax) <= 63);
+    const bool packed = SELF ? rows_per_group == RG : (rows_per_group == RG && __builtin_amdgcn_readfirstlane(cmax) <= 63);
 
     // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
     // from the hardware range check == the JS `undefined` -> 0 of :1051.
@@ -571,7 +572,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     //      fill() indices :1124 exactly (span_cells, hg_math.h), cut at output-row boundaries, every piece that falls into a row
     //      of the group filed into that row's LDS block -- exactly what load_row copies from a list.  Arbitrary order, like there.
     auto self_prologue = [&]() -> bool {
-        if ((int)threadIdx.x < kRowGroup) s_cnt[threadIdx.x] = 0;
+        if ((int)threadIdx.x < RG) s_cnt[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_ncand = 0;
         if ((int)threadIdx.x < 3 * nrows) {                 // the NaN record of every row block ("no triangle")
             const int row = threadIdx.x / 3, part = threadIdx.x - 3 * row;
@@ -587,7 +588,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         // Candidate entries carry up to `chunk` source rows (4 for 4-row groups, 1 for one-row groups: one lane per row below); a
         // triangle that reaches more rows -- window borders, spans spilling over the row end (x-offset quirk) -- files a second entry
         // for the rest, whose lanes loop if that is still more than `chunk` (a - b > 1: triangles wider than the map; rare).
-        const int chunk_log2 = packed ? 2 : 0, chunk = 1 << chunk_log2;
+        const int chunk_log2 = packed ? (RG == 8 ? 3 : 2) : 0, chunk = 1 << chunk_log2;
         for (int t0 = 0; t0 < T; t0 += nthreads) {
             const int t = t0 + (int)threadIdx.x;
             const TriRange tr = t < T ? trir[t] : TriRange{0, 0, 0, 0};
@@ -682,7 +683,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         __syncthreads();
         bool ok = true;
 #pragma unroll
-        for (int j = 0; j < kRowGroup; j++) { cnts[j] = j < nrows ? s_cnt[j] : 0; ok = ok && cnts[j] <= capr; }
+        for (int j = 0; j < RG; j++) { cnts[j] = j < nrows ? s_cnt[j] : 0; ok = ok && cnts[j] <= capr; }
         return ok;
     };
 
@@ -801,7 +802,10 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         if (nrows > 0) return;
 #endif
         const int row = packed ? wave : 0;
-        const int cnt = __builtin_amdgcn_readfirstlane(cnts[0] * (row == 0) + cnts[1] * (row == 1) + cnts[2] * (row == 2) + cnts[3] * (row == 3));
+        int cnt_row = 0;
+#pragma unroll
+        for (int j = 0; j < RG; j++) cnt_row += cnts[j] * (row == j);
+        const int cnt = __builtin_amdgcn_readfirstlane(cnt_row);
         if (row < nrows) do_row(row, cnt, packed ? wave * 64 : 0, packed ? 63 : CAP - 1, w_lo + (packed ? 0 : wave), packed ? 1 : nwaves);
         return;
     }
@@ -822,6 +826,14 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
                                                  int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
 {
     pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, SELF>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
+}
+
+// 8-row groups of the self-span path (512 threads, wave j walks row r0 + j): one candidate scan and one launch slot per EIGHT rows -- the
+// prologue is issue time the pixel loop cannot hide (EXPERIMENTS.md R4.8), and its scan / launch share halves.  Same body, RG = 8.
+template <int PH, bool HIB>
+__global__ __launch_bounds__(512) void k_pw_rows8(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int groups_per_xcd, int32_t *__restrict__ status_next)
+{
+    pw_rows_body<kRowSpanCapDense, NoExperiment, false, PH, false, HIB, 1, 8>(mesh, fr, rl, out, nullptr, groups_per_xcd, 8, status_next);
 }
 
 // The same kernel held to 80 SGPRs.  A 256-thread workgroup puts one wave on each SIMD and a SIMD has 800 SGPRs, allocated in
@@ -892,7 +904,8 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
 {
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
-    const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
+    const bool rows8 = fr.self_spans == 1 && fr.rows8 && fr.row_group == kRowGroup && !map_out && fr.col_split <= 1;
+    const int rg = rows8 ? 8 : (fr.row_group == kRowGroup ? kRowGroup : 1);
     const int nx = 1 << fr.xcc_log2;                                            // XCCs of this device (partition mode), hg_create
     const int rpx = ((fr.max_obj_h + rg - 1) / rg + nx - 1) / nx;               // row groups per XCD band
     dim3 grid((unsigned)rpx * (unsigned)nx * (unsigned)fr.n_frames * (unsigned)std::max(fr.col_split, 1));
@@ -904,6 +917,11 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const size_t pad = (size_t)fr.lds_pad_kb * 1024;
 #define HG_ROWS(CAP, MAPF, PHV, CMP, HB, SF) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
 #define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true, 0); else HG_ROWS(CAP, false, 1, CMP, false, 0); } while (0)
+    if (rows8) {
+        if (hib) hipLaunchKernelGGL((k_pw_rows8<4, true>), grid, dim3(512), pad, stream, mesh, fr, rl, out, rpx, status_next);
+        else     hipLaunchKernelGGL((k_pw_rows8<1, false>), grid, dim3(512), pad, stream, mesh, fr, rl, out, rpx, status_next);
+        return;
+    }
     if (fr.self_spans) {                                     // spans evaluated by the row workgroups themselves (sparse meshes: CAP 256, no row lists, k_tri_setup in front)
         if (map_out) { HG_ROWS(kRowSpanCapFast, true, 1, false, false, 1); return; }
         if (!hib) { HG_ROWS(kRowSpanCapFast, false, 1, false, false, 1); return; }
