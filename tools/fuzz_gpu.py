@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Wide fuzz of the HIP path against the CPU oracle (run on the GPU box): tools/fuzz_gpu.py [trials] [seed].
-FUZZ_TILE=1: wide frames, every trial also as a 3-frame batch (shared source and one source per frame) with k_pw_tile forced half of the time."""
+FUZZ_TILE=1: wide frames, every trial also as a 3-frame batch (shared source and one source per frame) with k_pw_tile forced half of the time.
+FUZZ_ROWS=1: the same frames through the self-span row kernel (4- and 8-row workgroups at random)."""
 import os
 import sys
 
@@ -14,7 +15,8 @@ HG = hip.load()
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = HG.Context(0)
-TILE = bool(os.environ.get("FUZZ_TILE"))
+ROWS = bool(os.environ.get("FUZZ_ROWS"))
+TILE = bool(os.environ.get("FUZZ_TILE")) or ROWS
 bad = 0
 seen = {}                                                  # kernel id -> batch runs that went through it
 overflow = 0
@@ -33,8 +35,9 @@ for t in range(trials):
     ctx.set_option("hi_bounds", int(rng.choice([1, 1, 0])))
     ctx.set_option("self_spans", int(rng.choice([-1, 1, 0])))
     ctx.set_option("tile", int(rng.choice([-1, 1, 1, 0])))
+    ctx.set_option("rows8", int(rng.choice([-1, 1, 0])))
     if TILE:
-        ctx.set_option("self_spans", 1); ctx.set_option("patch", 1); ctx.set_option("min_row_groups", 0)
+        ctx.set_option("self_spans", 1); ctx.set_option("patch", 0 if ROWS else 1); ctx.set_option("min_row_groups", 0)
     ctx.set_option("xcc_rotate", int(rng.choice([-1, 0, 1])))
     ctx.set_option("tri_group", int(rng.choice([-1, 0, 16, 64])))
     ctx.set_option("compact", int(rng.choice([-1, -1, 0, 1])))
