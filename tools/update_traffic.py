@@ -25,11 +25,11 @@ for config in ("C3", "C4", "C5", "C2"):
         text = open(src).read()
         # dominant kernel = the warp kernel with the most dispatches in the fetch pass
         best = None
-        for m in re.finditer(r"^\s+(void hg::)?(k_pw_rows_s80|k_pw_rows|k_pw_patch|k_pw_tile|k_geo_fast)\S*.*?FETCH_SIZE\s+n=\s*(\d+) avg=(\S+)", text, re.M):
+        for m in re.finditer(r"^\s+(void hg::)?(k_pw_rows_s80|k_pw_rows8|k_pw_rows|k_pw_patch|k_pw_tile|k_geo_fast)\S*.*?FETCH_SIZE\s+n=\s*(\d+) avg=(\S+)", text, re.M):
             if best is None or int(m.group(3)) > best[1]: best = (m.group(2), int(m.group(3)), float(m.group(4)))
         kern, _, fetch = best
         wr = None
-        for m in re.finditer(r"^\s+(void hg::)?(k_pw_rows_s80|k_pw_rows|k_pw_patch|k_pw_tile|k_geo_fast)\S*.*?WRITE_SIZE\s+n=\s*(\d+) avg=(\S+)", text, re.M):
+        for m in re.finditer(r"^\s+(void hg::)?(k_pw_rows_s80|k_pw_rows8|k_pw_rows|k_pw_patch|k_pw_tile|k_geo_fast)\S*.*?WRITE_SIZE\s+n=\s*(\d+) avg=(\S+)", text, re.M):
             if m.group(2) == kern and (wr is None or int(m.group(3)) > wr[0]): wr = (int(m.group(3)), float(m.group(4)))
         prev = old.get((config, sources)) or anyround.get((config, sources), {})
         alg = prev.get("algorithmic_bytes_per_launch")
