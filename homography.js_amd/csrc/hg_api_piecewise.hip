@@ -403,14 +403,14 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         const bool self_patch = self_ok && want_patch && !global_records && (c->n_tris <= 256 || c->pw_tri_rows_max > 0);
         const bool self_rows = self_ok && !want_patch && !compact && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 && (c->pw_row_group == 1 || c->pw_cover <= 56);
         c->pw_self_patch = self_patch;
-        // 8-row workgroups (k_pw_rows8: one candidate scan and one launch slot per eight rows).  Same box, shared source, 4 -> 8 rows: C3 (200
-        // triangles) 0.588 -> 0.576 ms, C4 (110) 0.2263 -> 0.2260, a 16 x 16 grid (512) 0.628 -> 0.636: small meshes only.
-        c->pw_rows8 = self_rows && c->pw_row_group == kRowGroup && (c->opt_rows8 >= 0 ? c->opt_rows8 == 1 : c->n_tris <= 256);
-        // k_pw_tile instead of k_pw_patch<SELF> where every frame streams its own source (option "tile" forces either).  Measured
-        // same box, one source per frame, patch -> tile (EXPERIMENTS.md R4.7): C5 0.580 -> 0.502 ms, its mesh at 3/4, 1/2, 1/4, 1/8 of the
-        // shear 0.551 -> 0.486, 0.488 -> 0.449, 0.456 -> 0.440, 0.444 -> 0.430; C3 at 4x / 2x its shear 1.082 -> 0.980, 0.889 -> 0.860, C3
-        // itself 0.810 -> 0.814, C4 0.341 -> 0.336, 40x40 / 64x36 grids 0.895 -> 0.889, 0.991 -> 0.978.  With a shared source the source
-        // lines of a 4-row patch are L2 hits anyway and the taller tile only costs: C5 0.411 -> 0.413, 40x40 grid 0.741 -> 0.767.
+        // 8-row workgroups (k_pw_rows8: one candidate scan and one launch slot per eight rows).  Same box, order-controlled (EXPERIMENTS.md R4.10):
+        // shared source C3 0.574 -> 0.583 ms, C4 0.226 -> 0.227 -- a loss; one source per frame (where k_pw_tile does not take the set) C3
+        // 0.875 -> 0.839, C4 0.376 -> 0.339.  Hence only there, and only for small meshes.
+        c->pw_rows8 = self_rows && c->pw_row_group == kRowGroup && (c->opt_rows8 >= 0 ? c->opt_rows8 == 1 : (c->n_imgs > 1 && c->n_tris <= 256));
+        // k_pw_tile instead of k_pw_patch<SELF> where every frame streams its own source (option "tile" forces either).  Same box, one source
+        // per frame, alternating order, patch -> tile (EXPERIMENTS.md R4.7): C5 0.5915 -> 0.5093 ms, its mesh at 3/4, 1/2, 1/4 of the shear
+        // 0.5345 -> 0.4737, 0.486 -> 0.4528, 0.437 -> 0.429; C3 0.8155 -> 0.816, C4 0.332 -> 0.330, 40x40 / 64x36 grids 0.870 -> 0.868, 0.975 ->
+        // 0.950.  With a shared source it is a toss-up (C5 0.4009 -> 0.3975, 64x36 grid 0.848 -> 0.830, 40x40 grid 0.734 -> 0.747): k_pw_patch stays.
         c->pw_tile = self_patch && !c->pw_tile_disabled && mw >= 512 && (c->opt_tile >= 0 ? c->opt_tile == 1 : c->n_imgs > 1);
         c->pw_bands = self_patch && c->n_tris > 256;
         if (c->pw_bands && (std::max(max_h, 1) + 63) / 64 > 2048) { c->pw_bands = false; c->pw_self_patch = false; }      // (kBandMax; frames taller than 131 072 rows)

@@ -328,8 +328,9 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "col_split" (default -1 = 1): 1, 2 or 4 k_pw_rows workgroups per row group, each taking a contiguous share of its windows;
  *   "lds_pad" (default -1 = 12-16 KB with one source per frame on 4-row groups, else 0): KB of unused dynamic LDS per k_pw_rows
  *           workgroup, 0..40: fewer, deeper-queued workgroups per CU where the kernel is HBM-bound;
- *   "rows8" (default -1 = meshes of up to 256 triangles; 1 / 0 force / forbid): the self-span form of k_pw_rows with 8 rows per workgroup
- *           (512 threads) instead of 4: half as many candidate scans and launch slots per pixel;
+ *   "rows8" (default -1 = one source per frame and a mesh of up to 256 triangles; 1 / 0 force / forbid): the self-span form of k_pw_rows
+ *           with 8 rows per workgroup (512 threads) instead of 4: half as many candidate scans and launch slots per pixel (a loss with a
+ *           shared source, a gain where every frame streams its own and k_pw_tile does not apply);
  *   "tile" (default -1 = whenever every frame reads its own source and k_pw_patch would evaluate its own spans; 1 = with a shared
  *           source too; 0 never): k_pw_tile instead of k_pw_patch -- 8 x 2048-pixel tiles, gathers in 8-pixel runs along the source
  *           rows; a tile beyond its limits (96 spans per row and tile, 128 triangle pieces) flags its frame, hg_sync
