@@ -328,8 +328,8 @@ PwFrames frames_of(const hg_ctx *c)
         (void)groups;
     }
     // (self-span path: its instantiations fit 56 VGPRs / 78 SGPRs whatever the phase depth -- 8 workgroups per CU where the list-reading
-    //  4-window form admits 7 -- and 4 windows per phase then wins on every shared-source config measured, round 4 same box:
-    //  C3 step 0.603 -> 0.580 ms, 512-triangle grid 0.664 -> 0.640, 8 frames of C3 0.102 -> 0.091)
+    //  4-window form admits 7.  Same box, alternating order, 2 -> 4 windows per phase: C3 0.5697 -> 0.5685 ms, C4 0.2220 -> 0.2228, 512-triangle
+    //  grid 0.6323 -> 0.6267: a wash to a slight gain, so one depth for every self-span set; EXPERIMENTS.md R4.10)
     f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 || c->pw_self ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
     f.patch_blocks = c->opt_phase > 0 ? c->opt_phase : 8;    // (k_pw_patch: measured best in both source layouts, hg_k_patch.hip)
     return f;
