@@ -70,7 +70,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t rows1_threads;          // k_pw_rows with one row per workgroup: 256 threads, or 128 for small frame sets (more workgroups resident)
     int32_t col_split;              // k_pw_rows: workgroups per row group, each with a contiguous share of the windows (small frame sets)
     int32_t lds_pad_kb;             // option "lds_pad": KB of unused dynamic LDS per k_pw_rows workgroup (caps the workgroups resident per CU)
-    int32_t lds_pad_patch_kb;       // the same for k_pw_patch (explicit option only: it loses with fewer workgroups)
+    int32_t lds_pad_patch_kb;       // the same for k_pw_patch / k_pw_tile (explicit option only: they lose with fewer workgroups)
     int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only
     int32_t no_hi_bounds;           // option "hi_bounds" = 0: keep the fp64 bounds compares (parity suite runs both forms)
     int32_t rows8;                  // k_pw_rows<SELF> with 8 rows per workgroup (512 threads) instead of 4
