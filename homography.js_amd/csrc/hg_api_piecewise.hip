@@ -363,7 +363,11 @@ static bool patch_preferred(const hg_ctx *c, bool *global_records)
     // by estimate (dense, sheared rows), and -- measured round 3 -- whenever every frame streams its own source from HBM and the
     // set fits the kernel: its 16 x 4 gather patches and 8-byte lists beat k_pw_rows there even on sparse meshes (same box, one
     // source per frame: C4 0.371 -> 0.330 ms, C3 step 0.973 -> 0.947)
-    return c->pw_fast && mw <= kPatchMaxW && !c->pw_patch_disabled && (force >= 0 ? force >= 1 : (c->pw_patch || (c->n_imgs > 1 && c->pw_patch_fits)));
+    // ... and -- round 4 -- whenever the rows are too dense for k_pw_rows<SELF> (more than 56 spans) and the set fits: what k_pw_rows would gain on
+    // flat dense meshes (round 3, kernel only: 24x24 grid 0.38 -> 0.37 ms) is less than the span producer it needs and k_pw_patch<SELF> does
+    // not (same box, step ms, alternating order: 24x24 grid on 4K 0.760 -> 0.685, C5's mesh at 1/10, 1/8, 1/4 of its shear 0.383 -> 0.351, 0.390 -> 0.355, 0.405 -> 0.363)
+    return c->pw_fast && mw <= kPatchMaxW && !c->pw_patch_disabled &&
+           (force >= 0 ? force >= 1 : (c->pw_patch || (c->pw_patch_fits && (c->n_imgs > 1 || c->pw_cover > 56))));
 }
 
 // per-frame solves; status words are reset first.  Fast path: k_tri_spans (solves + per-row span lists);

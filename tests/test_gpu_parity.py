@@ -1245,15 +1245,16 @@ def test_queued_runs_settle_in_call_order():
 
 def test_dense_sheared_mesh_takes_the_patch_kernel():
     """A mesh with ~150 spans per row and shear ~1 (C5's regime at a size the oracle does in a blink): the host picks
-    k_pw_patch (4-row groups, 2-D gather patches, one matrix record per triangle of the group); a flat dense mesh and a
-    sparse mesh stay on k_pw_rows.  All bit-exact against the oracle, three frames with different windows per batch."""
+    k_pw_patch (4-row groups, 2-D gather patches, one matrix record per triangle of the group), for a flat dense mesh too; a dense
+    mesh too narrow for its bins and a sparse mesh stay on k_pw_rows.  All bit-exact against the oracle, three frames with different windows per batch."""
     c = HG.Context(0)
     c.set_option("min_row_groups", 0)            # (these frame sets are small: without this they would all run one row per workgroup)
     try:
-        # (dense sheared -> k_pw_patch; dense flat, few spans per window -> k_pw_rows one row per workgroup; sparse -> 4-row
-        #  groups; very dense, ~300 spans per row -> k_pw_patch in its global-record variant)
-        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 3), (3200, 150, 17, 3, 0.5, 2), (640, 150, 8, 3, 18.0, 1),
-                                               (3000, 100, 110, 2, 5.0, 3)]:
+        # (dense sheared -> k_pw_patch; dense flat -> k_pw_patch as well since round 4 (its self-span form needs no producer kernel);
+        #  dense rows too narrow for its bins -> k_pw_rows one row per workgroup; sparse -> 4-row groups; very dense, ~300 spans per
+        #  row -> k_pw_patch in its global-record variant)
+        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 3), (3200, 150, 17, 3, 0.5, 3), (640, 150, 60, 3, 0.5, 2),
+                                               (640, 150, 8, 3, 18.0, 1), (3000, 100, 110, 2, 5.0, 3)]:
             img = G.lcg_image(W, H, 31)
             sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
             frames = [WL.sin_dst(sp, A, 8 + f) for f in range(3)]
