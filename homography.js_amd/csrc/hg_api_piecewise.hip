@@ -405,7 +405,9 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         // chain): small frame sets keep the row lists unless the option forces it.
         const bool self_ok = !c->pw_self_disabled && small_geom && (c->opt_self >= 0 ? c->opt_self == 1 : !c->pw_small_set);
         const bool self_patch = self_ok && want_patch && !global_records && (c->n_tris <= 256 || c->pw_tri_rows_max > 0);
-        const bool self_rows = self_ok && !want_patch && !compact && c->row_cap <= kRowSpanCapFast && c->n_tris <= 1024 && (c->pw_row_group == 1 || c->pw_cover <= 56);
+        // (beyond 1024 triangles a row group scans its candidate band instead of the whole mesh, like k_pw_patch<SELF>)
+        bool self_rows = self_ok && !want_patch && !compact && c->row_cap <= kRowSpanCapFast && (c->n_tris <= 1024 || (c->n_tris <= 8192 && c->pw_tri_rows_max > 0)) &&
+                         (c->pw_row_group == 1 || c->pw_cover <= 56);
         c->pw_self_patch = self_patch;
         // 8-row workgroups (k_pw_rows8: one candidate scan and one launch slot per eight rows).  Same box, order-controlled (EXPERIMENTS.md R4.10):
         // shared source C3 0.574 -> 0.583 ms, C4 0.226 -> 0.227 -- a loss; one source per frame (where k_pw_tile does not take the set) C3
@@ -416,8 +418,11 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         // 0.5345 -> 0.4737, 0.486 -> 0.4528, 0.437 -> 0.429; C3 0.8155 -> 0.816, C4 0.332 -> 0.330, 40x40 / 64x36 grids 0.870 -> 0.868, 0.975 ->
         // 0.950.  With a shared source it is a toss-up (C5 0.4009 -> 0.3975, 64x36 grid 0.848 -> 0.830, 40x40 grid 0.734 -> 0.747): k_pw_patch stays.
         c->pw_tile = self_patch && !c->pw_tile_disabled && mw >= 512 && (c->opt_tile >= 0 ? c->opt_tile == 1 : c->n_imgs > 1);
-        c->pw_bands = self_patch && c->n_tris > 256;
-        if (c->pw_bands && (std::max(max_h, 1) + 63) / 64 > 2048) { c->pw_bands = false; c->pw_self_patch = false; }      // (kBandMax; frames taller than 131 072 rows)
+        c->pw_bands = (self_patch && c->n_tris > 256) || (self_rows && c->n_tris > 1024);
+        if (c->pw_bands && (std::max(max_h, 1) + 63) / 64 > 2048) {      // (kBandMax; frames taller than 131 072 rows)
+            c->pw_bands = false; c->pw_self_patch = false;
+            if (c->n_tris > 1024) { self_rows = false; c->pw_rows8 = false; }
+        }
         if (c->pw_bands) {
             // bands of 64 output rows; capacity from the tallest triangle of the frame set (host estimate; an overfull band flags its frame)
             c->n_bands = (std::max(max_h, 1) + 63) / 64;

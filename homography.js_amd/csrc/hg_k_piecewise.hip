@@ -589,9 +589,22 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         // triangle that reaches more rows -- window borders, spans spilling over the row end (x-offset quirk) -- files a second entry
         // for the rest, whose lanes loop if that is still more than `chunk` (a - b > 1: triangles wider than the map; rare).
         const int chunk_log2 = packed ? (RG == 8 ? 3 : 2) : 0, chunk = 1 << chunk_log2;
-        for (int t0 = 0; t0 < T; t0 += nthreads) {
-            const int t = t0 + (int)threadIdx.x;
-            const TriRange tr = t < T ? trir[t] : TriRange{0, 0, 0, 0};
+        // (meshes beyond 1024 triangles: not the whole mesh but the entries k_tri_setup filed under this group's 64-row band, as in k_pw_patch<SELF>)
+        int n_src = T;
+        const int4 *__restrict__ bent = nullptr;
+        if (fr.band_ent) {
+            const int bandi = r0 >> fr.band_rows_log2;      // (row groups never straddle a band)
+            n_src = min(fr.band_cnt[(size_t)f * fr.band_stride + bandi], fr.band_cap);
+            bent = fr.band_ent + ((size_t)f * fr.n_bands + bandi) * fr.band_cap * 2;
+        }
+        for (int t0 = 0; t0 < n_src; t0 += nthreads) {
+            const int i = t0 + (int)threadIdx.x;
+            int t = i;
+            TriRange tr = TriRange{0, 0, 0, 0};
+            if (i < n_src) {
+                if (bent) { const int4 e = bent[2 * i]; t = e.x; tr.y_min = e.y; tr.y_end = e.z; tr.a = (int16_t)(e.w & 0xffff); tr.b = e.w >> 16; }
+                else tr = trir[i];
+            }
             const int ylo0 = max(g_lo - tr.a, tr.y_min), n0 = min(g_hi - tr.b, tr.y_end - 1) - ylo0 + 1;
             const int ylo1 = max(g_lo - tr.a - fd.obj_h, tr.y_min), n1 = min(g_hi - tr.b - fd.obj_h, tr.y_end - 1) - ylo1 + 1;
             const unsigned long long m0 = __ballot(n0 > 0), m1 = __ballot(n1 > 0);

@@ -111,6 +111,9 @@ CONFIGS = {
     "G24": dict(kind="piecewise", W=3840, H=2160, nx=24, ny=24, A=16.0),
     "G40": dict(kind="piecewise", W=3840, H=2160, nx=40, ny=40, A=10.0),
     "G64": dict(kind="piecewise", W=3840, H=2160, nx=64, ny=36, A=6.0),
+    # sparse rows, many triangles (20 cells across, 60 down: 2 400 triangles, ~42 spans per row): beyond k_pw_rows<SELF>'s scan limit
+    "T20x60": dict(kind="piecewise", W=3840, H=2160, nx=20, ny=60, A=10.0),
+    "T12x60": dict(kind="piecewise", W=3840, H=2160, nx=12, ny=60, A=10.0),
 }
 
 

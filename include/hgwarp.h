@@ -305,7 +305,7 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "phase" (default -1 = 2 for a shared source -- 4 when the rows carry 3 or more spans per window --, 1 with one source per frame):
  *           windows per k_pw_rows gather/store phase, 1, 2 or 4;
  *   "geo_windows" (default 8): 256-pixel windows per wave of the affine / projective kernel, 1, 2, 4 or 8;
- *   "self_spans" (default -1 = by policy; 1 = whenever eligible: sparse meshes of up to 1024 triangles; 0 never): no span
+ *   "self_spans" (default -1 = by policy; 1 = whenever eligible: sparse meshes of up to 8192 triangles; 0 never): no span
  *           producer kernel and no per-output-row span lists -- k_tri_setup writes every triangle's edge equations, inverse matrix
  *           and row reach, and each row workgroup of the warp kernel picks the triangles that reach its rows and evaluates
  *           predictXLimits + the fill() indices for exactly those rows in its prologue.  Bit-identical;

@@ -970,6 +970,34 @@ def test_self_span_path_policy_flags_and_falls_back():
             c.set_image(imgs[0])
             c.free(d_out)
             c.free(d_src)
+        # (b2) k_pw_rows<SELF> with candidate bands: sparse rows (12 cells across), 1440 triangles -- beyond what a row group scans whole
+        W, H, nx, ny, F = 1536, 1024, 12, 60, 5
+        img = G.lcg_image(W, H, 411)
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        frames = [WL.sin_dst(sp, 5.0 + f, 8 + (f % 4)) for f in range(F)]
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        ms = WL.src_min(sp)
+        offs, total = HG.pack_offsets(geoms)
+        d_out = c.alloc(total)
+        try:
+            c.set_image(img)
+            c.set_option("min_row_groups", 0); c.set_option("patch", 0); c.set_option("tile", -1)
+            c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+            want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(F)]
+            for opt, rows8 in ((-1, 0), (-1, 1), (0, 0)):
+                c.set_option("self_spans", opt); c.set_option("rows8", rows8)
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.warp_inverse_piecewise_frames_device(d_out)          # (queued twice: the band counters clean themselves)
+                c.sync()
+                assert c.last_piecewise_kernel() == 1 and c.last_piecewise_self() == (1 if opt else 0), (opt, c.last_piecewise_kernel(), c.last_piecewise_self())
+                for f in range(F):
+                    g = geoms[f]
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), ("row bands", opt, rows8, f)
+            assert c.redone_frames() == 0
+        finally:
+            c.set_option("rows8", -1); c.set_option("patch", -1); c.set_option("self_spans", -1)
+            c.free(d_out)
         # (c) 320 x 1 cells, 7 small frames: the host skips its per-triangle walk for such sets and guesses ~63 spans per row, every row is
         #     crossed by ~640 -> the one-row self-span blocks (255) overflow -> frames flagged -> map path; then row lists for this mesh
         c.set_option("patch", 0); c.set_option("compact", 0); c.set_option("self_spans", 1); c.set_option("min_row_groups", 1 << 30)
