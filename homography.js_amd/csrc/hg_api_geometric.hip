@@ -57,8 +57,7 @@ extern "C" int hg_geometric_set_frames(hg_ctx *c, int kind, const double *m, con
     HG_TRY(geo_stage_slot(c, fd_bytes + m_bytes, &gs));
     std::memcpy(gs->h, fresh.data(), fd_bytes);
     std::memcpy(gs->h + fd_bytes, m, m_bytes);
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, gs->h, fd_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_mats, gs->h + fd_bytes, m_bytes, hipMemcpyHostToDevice, c->stream));
+    HG_TRY(upload_staged(c, c->d_geo_frames, gs->h, fd_bytes, c->d_mats, gs->h + fd_bytes, m_bytes));
     HIP_TRY(c, hipEventRecord(gs->done, c->stream)); gs->used = true;
     c->geo_frames.swap(fresh);
     c->geo_kind = kind; c->geo_from_points = false;
@@ -93,9 +92,8 @@ extern "C" int hg_geometric_set_frames_points(hg_ctx *c, int kind, const float *
     std::memcpy(gs->h, fresh.data(), fd_bytes);
     std::memcpy(gs->h + fd_bytes, from, p_bytes);
     std::memcpy(gs->h + fd_bytes + p_bytes, to, p_bytes);
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_frames, gs->h, fd_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_pts, gs->h + fd_bytes, p_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_geo_pts + (size_t)n * 8, gs->h + fd_bytes + p_bytes, p_bytes, hipMemcpyHostToDevice, c->stream));
+    HG_TRY(upload_staged(c, c->d_geo_frames, gs->h, fd_bytes, c->d_geo_pts, gs->h + fd_bytes, p_bytes,
+                         c->d_geo_pts + (size_t)n * 8, gs->h + fd_bytes + p_bytes, p_bytes));
     HIP_TRY(c, hipEventRecord(gs->done, c->stream)); gs->used = true;
     c->geo_frames.swap(fresh);
     c->geo_kind = kind; c->geo_from_points = true;

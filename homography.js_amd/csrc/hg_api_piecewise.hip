@@ -186,7 +186,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     st.n = n; st.n_pts = c->n_pts;
     static_assert(sizeof(FrameDesc) % 8 == 0, "the destiny points follow the frame records in the same block");
     c->d_pw_frames = reinterpret_cast<FrameDesc *>(c->d_set); c->d_dst = reinterpret_cast<float *>(c->d_set + fd_bytes);
-    HIP_TRY(c, hipMemcpyAsync(c->d_set, st.h, fd_bytes + pt_bytes, hipMemcpyHostToDevice, c->stream));    // (one DMA: the staged block has the device layout)
+    HG_TRY(upload_staged(c, c->d_set, st.h, fd_bytes + pt_bytes));      // (one copy: the staged block has the device layout)
     HIP_TRY(c, hipEventRecord(st.done, c->stream));
     st.used = true;
     c->pw_frames.swap(fresh);

@@ -127,6 +127,7 @@ struct hg_ctx {
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
     int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate
     int opt_tri_group = -1;                                    // k_tri_spans_grouped: 16 / 64 triangles per workgroup, 0 never, -1 by mesh size
+    int opt_upload_kernel = -1;                                // frame-set blocks up to 1 MB go up by k_upload (default) instead of hipMemcpyAsync (0)
     int opt_rows8 = -1;                                        // k_pw_rows<SELF>: 8 rows per workgroup (1), 4 (0), -1 by policy
     int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
     int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
@@ -199,6 +200,24 @@ inline int fail(hg_ctx *c, int code, const std::string &msg)
     } while (0)
 
 #define HG_TRY(expr) do { int s_ = (expr); if (s_ != HG_OK) return s_; } while (0)
+
+// A staged block (page-locked, device-visible) to the device, stream-ordered: up to 1 MB by k_upload -- a kernel that reads the host block --,
+// beyond that (or with option "upload_kernel" = 0) by the copy engine, whose start-up latency is what a 36-KB frame set paid for (R4.13).
+inline int upload_staged(hg_ctx *c, void *d0, const void *s0, size_t b0, void *d1 = nullptr, const void *s1 = nullptr, size_t b1 = 0,
+                         void *d2 = nullptr, const void *s2 = nullptr, size_t b2 = 0)
+{
+    if (b0 + b1 + b2 == 0) return HG_OK;
+    if (std::max(b0, std::max(b1, b2)) <= ((size_t)1 << 20) && ((b0 | b1 | b2) & 7) == 0 && c->opt_upload_kernel != 0) {
+        UploadSegs sg{{d0, d1, d2}, {s0, s1, s2}, {b0 / 8, b1 / 8, b2 / 8}};
+        launch_upload(sg, c->stream);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        if (b0) HIP_TRY(c, hipMemcpyAsync(d0, s0, b0, hipMemcpyHostToDevice, c->stream));
+        if (b1) HIP_TRY(c, hipMemcpyAsync(d1, s1, b1, hipMemcpyHostToDevice, c->stream));
+        if (b2) HIP_TRY(c, hipMemcpyAsync(d2, s2, b2, hipMemcpyHostToDevice, c->stream));
+    }
+    return HG_OK;
+}
 
 template <typename T>
 inline int ensure(hg_ctx *c, T *&p, size_t &cap, size_t need)

@@ -868,6 +868,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_pw
 namespace hg {
 #endif
 
+// A frame set's block (a few KB .. a few hundred KB) from its page-locked staging slot to the device by a KERNEL that reads host memory: the
+// copy engine's start-up latency made the stream-ordered hipMemcpyAsync of 36 KB cost 13 us of a 233-us step (EXPERIMENTS.md R4.13).
+__global__ __launch_bounds__(256) void k_upload(UploadSegs sg)
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint2 *__restrict__ dst = static_cast<uint2 *>(sg.dst[k]);
+        const uint2 *__restrict__ src = static_cast<const uint2 *>(sg.src[k]);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < sg.n8[k]; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    }
+}
+
+void launch_upload(const UploadSegs &sg, hipStream_t stream)     // up to three (dst, page-locked src, 8-byte words) segments in ONE launch
+{
+    const size_t n8 = std::max(sg.n8[0], std::max(sg.n8[1], sg.n8[2]));
+    if (n8 == 0) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((n8 + 255) / 256, 128);
+    hipLaunchKernelGGL(k_upload, dim3(blocks), dim3(256), 0, stream, sg);
+}
+
 void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream)
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;

@@ -107,6 +107,8 @@ struct RowLists {
 // k_tri_setup: per (frame, triangle): forward affine (:785-804, :1265-1306), its inverse (:1036-1038, :1345-1365),
 // edge equations (:1141-1151) and row range (:1113-1115).
 void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream);
+struct UploadSegs { void *dst[3]; const void *src[3]; size_t n8[3]; };     // (dst, page-locked device-visible src, count of 8-byte words)
+void launch_upload(const UploadSegs &sg, hipStream_t stream);              // small host -> device copies by ONE kernel launch
 
 // k_pw_fused: _inversePiecewiseAffineWarp :1029-1058 for all frames, one workgroup per output row, without a
 // materialised triangle map.  map_out (optional, int16 per output pixel) receives the per-pixel triangle id the

@@ -329,6 +329,9 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "col_split" (default -1 = 1): 1, 2 or 4 k_pw_rows workgroups per row group, each taking a contiguous share of its windows;
  *   "lds_pad" (default -1 = 12-16 KB with one source per frame on 4-row groups, else 0): KB of unused dynamic LDS per k_pw_rows
  *           workgroup, 0..40: fewer, deeper-queued workgroups per CU where the kernel is HBM-bound;
+ *   "upload_kernel" (default -1 = on): frame-set blocks of up to 1 MB go from their page-locked staging slot to the device by a small kernel
+ *           that reads host memory instead of a stream-ordered hipMemcpyAsync (whose copy-engine start-up cost 10-15 us per set); 0: always
+ *           the copy engine;
  *   "rows8" (default -1 = one source per frame and a mesh of up to 256 triangles; 1 / 0 force / forbid): the self-span form of k_pw_rows
  *           with 8 rows per workgroup (512 threads) instead of 4: half as many candidate scans and launch slots per pixel (a loss with a
  *           shared source, a gain where every frame streams its own and k_pw_tile does not apply);
