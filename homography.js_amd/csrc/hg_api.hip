@@ -65,6 +65,7 @@ extern "C" void hg_destroy(hg_ctx *c)
                      c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_fwd_status, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
     for (hg_ctx::Stage &st : c->stage) { if (st.h) (void)hipHostFree(st.h); if (st.done) (void)hipEventDestroy(st.done); }
     for (hg_ctx::GeoStage &gs : c->geo_stage) { if (gs.h) (void)hipHostFree(gs.h); if (gs.done) (void)hipEventDestroy(gs.done); }
     { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_trix, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status };

@@ -159,6 +159,12 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     HG_TRY(ensure(c, c->d_fwd, c->fwd_cap, F * T * 6));
     HG_TRY(ensure(c, c->d_inv, c->inv_cap, F * T * kInvStride));
     HG_TRY(ensure(c, c->d_status, c->status_cap, F));
+    if (!c->h_flag) {
+        void *q = nullptr;
+        hipError_t e = hipHostMalloc(&q, 64, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipHostMalloc (flag word): ") + hipGetErrorString(e));
+        c->h_flag = static_cast<int32_t *>(q); *c->h_flag = 0;
+    }
     if (F * kStatusRing > c->h_status_cap) {
         HG_TRY(hg_sync(c));
         if (c->h_status) HIP_TRY(c, hipHostFree(c->h_status));
@@ -288,6 +294,7 @@ static RowLists rows_of(const hg_ctx *c);
 PwFrames frames_of(const hg_ctx *c)
 {
     PwFrames f;
+    f.host_flag = c->opt_upload_kernel != 0 ? c->h_flag : nullptr;
     f.frames = c->d_pw_frames; f.dst_pts = c->d_dst; f.trir = c->d_trir; f.trix = c->d_trix; f.segs = c->d_segs; f.fwd = c->d_fwd; f.inv = c->d_inv;
     f.status = c->status_ptr ? c->status_ptr : c->d_status; f.n_frames = (int)c->pw_frames.size();
     int mh = 0;
@@ -544,7 +551,7 @@ static int redo_frame_staged(hg_ctx *c, int stage, int f, uint8_t *d_out)
     PwMesh mesh = mesh_of(c);
     mesh.img = frame_img(mesh, f); mesh.n_imgs = 1;          // this frame's own source
     PwFrames fr = frames_of(c);
-    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
+    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.host_flag = nullptr; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
     fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
     launch_tri_setup(mesh, fr, c->stream);
     launch_map_build(mesh, fr, 0, fd, c->d_map32, c->stream);
@@ -577,7 +584,7 @@ int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int ma
     HIP_TRY(c, hipMemcpyAsync(c->d_redo_frame, st.h + sizeof(FrameDesc) * (size_t)f, sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_redo_dst, pts, sizeof(float) * 2 * c->n_pts, hipMemcpyHostToDevice, c->stream));
     PwFrames fr = frames_of(c);
-    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
+    fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.host_flag = nullptr; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
     fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
     launch_tri_setup(mesh_of(c), fr, c->stream);
     launch_fwd_pw(c->d_fmap, c->d_redo_fwd, frame_img(mesh_of(c), f), c->W, c->H, c->min_src_x, c->min_src_y, max_src_x - c->min_src_x, max_src_y - c->min_src_y,
@@ -660,21 +667,10 @@ static int replay_queued(hg_ctx *c, const std::vector<P> &pending, NF n_frames, 
 extern "C" int hg_sync(hg_ctx *c)
 {
     HG_TRY(bind(c));
-    // The status ring of the queued fused runs comes down by a kernel queued BEHIND them (it writes the page-locked h_status), so that one
-    // stream synchronisation settles runs and flags together: a blocking hipMemcpy after the synchronisation cost a second round trip
-    // (a synced single 4K frame: 47.6 -> 36.2 us on the host, EXPERIMENTS.md R4.13)
-    bool status_down = false;
-    if (!c->pw_pending_out.empty() && c->status_base && c->opt_upload_kernel != 0) {
-        const int st0 = c->pw_pending_out.front().stage;
-        const size_t F = (st0 >= 0 && c->stage[st0].h) ? (size_t)c->stage[st0].n : c->pw_frames.size();
-        const size_t bytes = sizeof(int32_t) * F * kStatusRing;
-        if (bytes > 0 && bytes <= ((size_t)1 << 20) && F * kStatusRing <= c->h_status_cap) {
-            UploadSegs sg{{c->h_status, nullptr, nullptr}, {c->status_base, nullptr, nullptr}, {bytes / 8, 0, 0}};
-            launch_upload(sg, c->stream);
-            HIP_TRY(c, hipGetLastError());
-            status_down = true;
-        }
-    }
+    // Fast-path runs set the page-locked word h_flag whenever a kernel flags a frame (flag_frame, hg_dev.h): if it is still 0 after the
+    // synchronisation nobody flagged anything and the status ring is not read at all; otherwise it comes down with a blocking copy (rare).
+    // (A blocking hipMemcpy after EVERY synchronisation made a synced single 4K frame 47.6 us on the host; a download kernel queued
+    //  behind the runs 36.2; this, 34.0: EXPERIMENTS.md R4.13.)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (!c->pw_pending_out.empty()) {
         // frames a fused run flagged (irregular, or a row list overflowed) are redone through the materialised map, into the
@@ -685,8 +681,12 @@ extern "C" int hg_sync(hg_ctx *c)
         // (all queued runs share one layout of the status ring: a set with another frame count settles them before it runs)
         const int st0 = pending.front().stage;
         const size_t F = (st0 >= 0 && c->stage[st0].h) ? (size_t)c->stage[st0].n : c->pw_frames.size();
-        if (c->status_base && !status_down) HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < pending.size(); i++)
+        const bool none_flagged = c->status_base && c->h_flag && c->opt_upload_kernel != 0 && *c->h_flag == 0;
+        if (c->status_base && !none_flagged) {
+            HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
+            if (c->h_flag) *c->h_flag = 0;                   // (the GPU is idle here)
+        }
+        if (!none_flagged) for (size_t i = 0; i < pending.size(); i++)
             for (size_t f = 0; f < F; f++)
                 if (c->h_status[(size_t)pending[i].slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; c->pw_last_flag = c->h_status[(size_t)pending[i].slot * F + f]; }
         if (redo)

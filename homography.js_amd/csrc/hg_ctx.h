@@ -53,6 +53,7 @@ struct hg_ctx {
     int32_t *d_status = nullptr; size_t status_cap = 0;
     int32_t *status_ptr = nullptr;                             // where this frame set's status words live (d_status, or the tail of d_rowcnt)
     int32_t *h_status = nullptr; size_t h_status_cap = 0;      // pinned
+    int32_t *h_flag = nullptr;                                 // pinned, device-visible: set to 1 by any fused kernel that flags a frame (PwFrames::host_flag)
     bool pw_setup_done = false;                                // the per-triangle solves ran for the uploaded frames
     // fast path: per-output-row span lists
     int32_t *d_rowcnt = nullptr; size_t rowcnt_cap = 0;

@@ -8,6 +8,14 @@
 
 namespace hg {
 
+// A kernel flags frame f (status word in device memory, read by hg_sync only when the host-visible flag says there is something to read)
+__device__ __forceinline__ void flag_frame(const PwFrames &fr, int f, int32_t bits)
+{
+    atomicOr(&fr.status[f], bits);
+    if (fr.host_flag) __hip_atomic_store(fr.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 // ------------------------------------------------------------------------------------------------ experiment hooks
 // The warp kernels call these hooks at the few places the timing ablations of EXPERIMENTS.md alter.  The product translation
 // units only ever instantiate NoExperiment, whose hooks are identities; the ablation policies (which write WRONG pixels by

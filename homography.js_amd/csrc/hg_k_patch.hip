@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     __syncthreads();
     if (s_fail) {                                           // the host redoes the frame through the materialised map
         // (SELF: bits 4.. say which limit -- 1 | candidates << 8, or 2 | longest row << 8 -- for whoever reads the status word in a debugger)
-        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW | (SELF ? (s_fail << 4) : 0));
+        if (threadIdx.x == 0) flag_frame(fr, f, FRAME_LDS_OVERFLOW | (SELF ? (s_fail << 4) : 0));
         return;
     }
 

@@ -72,7 +72,7 @@ __device__ __forceinline__ bool tri_setup_one(const PwMesh &mesh, const PwFrames
                 tr.b = (int32_t)floordiv64(lo, fd.obj_w);
             }
         }
-        if (irregular) atomicOr(&fr.status[f], FRAME_IRREGULAR);
+        if (irregular) flag_frame(fr, f, FRAME_IRREGULAR);
         regular = !irregular;
         if (regular) fr.trix[ft] = make_int2((int)floor(fmin(fmin(x0, x1), x2)) - 1, (int)ceil(fmax(fmax(x0, x1), x2)) + 1);
     }
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
         lo0 = lo0 < 0 ? 0 : lo0; hi0 = hi0 > H - 1 ? H - 1 : hi0;
         lo1 = lo1 < 0 ? 0 : lo1; hi1 = hi1 > H - 1 ? H - 1 : hi1;
         if (lo1 <= hi1 && lo0 <= hi0 && lo1 <= hi0 + 1) { hi0 = hi1 > hi0 ? hi1 : hi0; lo0 = lo1 < lo0 ? lo1 : lo0; hi1 = lo1 - 1; }      // overlapping: one range
-        if (tr.a < -32768 || tr.a > 32767 || tr.b < -32768 || tr.b > 32767) { atomicOr(&fr.status[f], FRAME_IRREGULAR); file = false; }
+        if (tr.a < -32768 || tr.a > 32767 || tr.b < -32768 || tr.b > 32767) { flag_frame(fr, f, FRAME_IRREGULAR); file = false; }
     }
     const int4 ent = make_int4(t, tr.y_min, tr.y_end, (tr.a & 0xffff) | (int)((uint32_t)tr.b << 16));
     const int2 tx = file ? fr.trix[(size_t)f * mesh.n_tris + t] : make_int2(0, -1);      // (written by this thread above)
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
                 if (n > 0) {
                     const int base = atomicAdd(&fr.band_cnt[(size_t)f * fr.band_stride + i], n);
                     s_base[i] = base;
-                    if (base + n > fr.band_cap) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+                    if (base + n > fr.band_cap) flag_frame(fr, f, FRAME_LDS_OVERFLOW);
                 }
                 s_cnt[i] = 0;
             }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
     __syncthreads();
     const int cnt = s_cnt;
     if (cnt > kRowSpanCap) {                         // frame is redone through the materialised-map path by the host
-        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+        if (threadIdx.x == 0) flag_frame(fr, f, FRAME_LDS_OVERFLOW);
         return;
     }
 
@@ -511,7 +511,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
 #pragma unroll
         for (int j = 0; j < RG; j++) { cnts[j] = j < nrows ? cntp[j] : 0; cmax = max(cmax, cnts[j]); }
         if (cmax > rl.cap || cmax > CAP - 1) {
-            if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+            if (threadIdx.x == 0) flag_frame(fr, f, FRAME_LDS_OVERFLOW);
             return;
         }
     }
@@ -808,7 +808,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // 8 waves/SIMD the other waves already cover a window's memory latency, and reads + writes together run at ~5.2 TB/s.
     if (SELF) {
         if (!self_prologue()) {                             // more candidates / spans than the LDS holds: the host redoes the frame through the map
-            if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW);
+            if (threadIdx.x == 0) flag_frame(fr, f, FRAME_LDS_OVERFLOW);
             return;
         }
 #if defined(HG_ROWS_EXP) && HG_ROWS_EXP == 3                     // timing experiment (tools/variants.sh): the prologue alone

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
 #pragma unroll
     for (int r = 0; r < kTileRows; r++) { const int cnt = s_rowcnt[r]; if (cnt > kTileCap && fail == 0) fail = 2 | (cnt << 8); }
     if (fail) {                                             // the host redoes the frame through the materialised map
-        if (threadIdx.x == 0) atomicOr(&fr.status[f], FRAME_LDS_OVERFLOW | (fail << 4));
+        if (threadIdx.x == 0) flag_frame(fr, f, FRAME_LDS_OVERFLOW | (fail << 4));
         return;
     }
 

@@ -58,6 +58,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     float *fwd;                     // F x n_tris x 6
     float *inv;                     // F x n_tris x kInvStride
     int32_t *status;                // F
+    int32_t *host_flag;             // page-locked, device-visible word set to 1 whenever a kernel flags a frame (nullptr: none): lets hg_sync skip reading the status ring
     int32_t n_frames;
     int32_t max_obj_h;              // max over frames (grid size)
     int32_t row_group;              // output rows per k_pw_rows workgroup: kRowGroup (sparse rows) or 1 (dense meshes)
