@@ -163,7 +163,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
         void *q = nullptr;
         hipError_t e = hipHostMalloc(&q, 64, hipHostMallocDefault);
         if (e != hipSuccess) return fail(c, HG_ERR_NOMEM, std::string("hipHostMalloc (flag word): ") + hipGetErrorString(e));
-        c->h_flag = static_cast<int32_t *>(q); *c->h_flag = 0;
+        c->h_flag = static_cast<int32_t *>(q); c->h_flag[0] = 0; c->h_flag[1] = 0;      // [0] inverse fused kernels, [1] forward tile kernels
     }
     if (F * kStatusRing > c->h_status_cap) {
         HG_TRY(hg_sync(c));
@@ -710,9 +710,14 @@ extern "C" int hg_sync(hg_ctx *c)
         std::vector<hg_ctx::FwdPending> pending;
         pending.swap(c->fwd_pending);
         std::vector<int32_t> st(c->fwd_status_cap);
-        HIP_TRY(c, hipMemcpy(st.data(), c->d_fwd_status, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost));
+        // (as above: the status words are read only when a forward tile kernel set its host-visible flag word)
+        const bool none_flagged = c->h_flag && c->opt_upload_kernel != 0 && c->h_flag[1] == 0;
+        if (!none_flagged) {
+            HIP_TRY(c, hipMemcpy(st.data(), c->d_fwd_status, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost));
+            if (c->h_flag) c->h_flag[1] = 0;
+        }
         bool overflow = false, unbounded = false, any = false;
-        for (const hg_ctx::FwdPending &fp : pending) {
+        if (!none_flagged) for (const hg_ctx::FwdPending &fp : pending) {
             const int32_t *sf = st.data() + (size_t)fp.slot * c->fwd_status_stride;
             for (int f = 0; f < fp.n; f++) {
                 if (sf[f] == 0) continue;

@@ -6,6 +6,14 @@
 
 namespace hg {
 
+// (forward tile kernels: flag frame f for the scatter + gather redo, and tell hg_sync through the host-visible word that there is something to read)
+__device__ __forceinline__ void fwd_flag(const FwdPwTiles &p, int f, int32_t bits)
+{
+    atomicOr(&p.status[f], bits);
+    if (p.host_flag) __hip_atomic_store(p.host_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 // ------------------------------------------------------------------------------------------------ forward (scatter) paths
 // _geometricWarp :911-932 and _piecewiseAffineWarp :948-972 write each SOURCE pixel to its transformed position; where
 // several land on one output pixel the sequential loops keep the last writer in raster order.  On the GPU:
@@ -331,10 +339,10 @@ __global__ __launch_bounds__(256) void k_fwd_pw_bins(FwdPwTiles p)
         fx -= (double)fd.x_off; fy -= (double)fd.y_off;
         umin = fmin(umin, fx); umax = fmax(umax, fx); vmin = fmin(vmin, fy); vmax = fmax(vmax, fy);
     }
-    if (bad) { if (lane == 0) atomicOr(&p.status[f], FWD_FALLBACK); return; }
+    if (bad) { if (lane == 0) fwd_flag(p, f, FWD_FALLBACK); return; }
     const int64_t ua = (int64_t)floor(umin) - 2, ub = (int64_t)ceil(umax) + 2, va = (int64_t)floor(vmin) - 2, vb = (int64_t)ceil(vmax) + 2;
     const int64_t kmin = floordiv64(ua, fd.obj_w), kmax = floordiv64(ub, fd.obj_w);
-    if (kmin < -2 || kmax > 2) { if (lane == 0) atomicOr(&p.status[f], FWD_FALLBACK); return; }
+    if (kmin < -2 || kmax > 2) { if (lane == 0) fwd_flag(p, f, FWD_FALLBACK); return; }
     for (int64_t k = kmin; k <= kmax; k++) {
         const int64_t c0 = (ua > k * fd.obj_w ? ua : k * fd.obj_w) - k * fd.obj_w;
         const int64_t c1 = (ub < (k + 1) * fd.obj_w - 1 ? ub : (k + 1) * fd.obj_w - 1) - k * fd.obj_w;
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(256) void k_fwd_pw_bins(FwdPwTiles p)
             const size_t idx = ((size_t)f * p.tsy + ty) * p.tsx + tx;
             const int slot = atomicAdd(&p.tile_cnt[idx], 1);
             if (slot < p.cap) p.tile_ent[idx * p.cap + slot] = t | (((int)k + 2) << 16);
-            else atomicOr(&p.status[f], FWD_OVERFLOW);
+            else fwd_flag(p, f, FWD_OVERFLOW);
         }
     }
 }

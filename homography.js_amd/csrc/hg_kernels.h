@@ -173,6 +173,7 @@ struct FwdPwTiles {
     const int32_t *rowext;      // per (matrix index t, row of its bbox): {min mx, max mx} of its cells in that map row, at rowoff[t] + (my - bbox.cy0)
     const uint32_t *rowoff;
     int32_t *tile_cnt, *tile_ent, *status;
+    int32_t *host_flag;         // page-locked, device-visible word set to 1 by any kernel that flags a frame (nullptr: none); see PwFrames::host_flag
     int32_t T, min_src_x, min_src_y, map_w, map_h, tsx, tsy, cap;
 };
 void launch_fmap_bbox(const int32_t *fmap, int map_w, int map_h, int32_t *bbox, int T, hipStream_t stream);
