@@ -237,7 +237,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     {   // few rows in total (a single 4K frame has 560 four-row groups for 256 CUs): one row per workgroup fills the chip better
         int64_t groups = 0;
         for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + kRowGroup - 1) / kRowGroup;
-        c->pw_small_set = groups < c->opt_min_row_groups;
+        c->pw_small_set = groups < c->opt_min_row_groups; c->pw_groups = groups;
         if (c->pw_small_set) c->pw_row_group = 1;
     }
     // dense rows that still fit the patch kernel's LDS budget, sheared enough for 2-D gather patches to pay.  Measured
@@ -410,7 +410,11 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         // producer gone), C4 0.258 -> 0.236-0.242, 8 frames of C3 0.104 -> 0.093; a single 4K frame 22.8 -> 23.1 us per queued step (one
         // row per workgroup: every one of 2239 workgroups scans all triangles, and k_tri_setup's 4 us are one workgroup's dependent
         // chain): small frame sets keep the row lists unless the option forces it.
-        const bool self_ok = !c->pw_self_disabled && small_geom && (c->opt_self >= 0 ? c->opt_self == 1 : !c->pw_small_set);
+        // The small / large boundary (option "min_row_groups", 1152 four-row groups), queued steps, alternating order: C3 2 frames (1120 groups)
+        // lists 0.0375 vs self 0.0389, 3 frames (1680) 0.0495 vs 0.0474; C4 2 frames (624) 0.0275 vs 0.0283, 4 frames (1248) 0.0374 vs 0.0332.
+        // (k_pw_patch takes the self-span form from half the threshold: a single 8K frame of C5, 1120 groups, 0.0914 -> 0.084 ms per queued step)
+        const bool self_ok = !c->pw_self_disabled && small_geom &&
+                             (c->opt_self >= 0 ? c->opt_self == 1 : (!c->pw_small_set || (want_patch && c->pw_groups * 2 >= c->opt_min_row_groups)));
         const bool self_patch = self_ok && want_patch && !global_records && (c->n_tris <= 256 || c->pw_tri_rows_max > 0);
         // (beyond 1024 triangles a row group scans its candidate band instead of the whole mesh, like k_pw_patch<SELF>)
         bool self_rows = self_ok && !want_patch && !compact && c->row_cap <= kRowSpanCapFast && (c->n_tris <= 1024 || (c->n_tris <= 8192 && c->pw_tri_rows_max > 0)) &&

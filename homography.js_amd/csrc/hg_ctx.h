@@ -79,7 +79,7 @@ struct hg_ctx {
     int pw_last_kernel = 0;                                    // hg_last_piecewise_kernel()
     int32_t pw_last_flag = 0;                                  // status word of the last frame a fused run flagged (bits 4..: which limit, see k_pw_patch<SELF>)
     long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
-    int opt_min_row_groups = 1536, opt_patch = -1, opt_phase = -1, opt_geo_nw = 8;   // hg_set_option()
+    int opt_min_row_groups = 1152, opt_patch = -1, opt_phase = -1, opt_geo_nw = 8;   // hg_set_option()
     int xcc_log2 = 3;                                          // log2(XCCs of the device): hipDeviceAttributeNumberOfXccs at hg_create, option "xcc"
     int opt_lds_pad = -1;                                       // KB of dynamic LDS padding per k_pw_rows workgroup (occupancy experiments)
     int opt_sgpr_cap = -1;                                     // -1 auto (shared source), 0 never, 1 always: k_pw_rows_s80
@@ -113,6 +113,7 @@ struct hg_ctx {
     size_t rows_F = 0; int rows_stride = 0, rows_cap = 0;
     // self-span path (k_tri_setup -> k_pw_rows<SELF>, hg_kernels.h): the row workgroups evaluate their own spans, no row lists
     int pw_tri_rows_max = 0;                                   // tallest triangle of the uploaded frames, in rows (host estimate)
+    int64_t pw_groups = 0;                                     // 4-row groups of the frame set (layout estimate)
     bool pw_small_set = false;                                 // fewer 4-row groups than "min_row_groups": one row per workgroup, short-latency prologues
     bool pw_self = false;                                      // the current step uses the self-span path
     bool pw_self_disabled = false;                             // a run on it flagged a frame (more candidates / spans than its LDS blocks hold): row lists for this mesh

@@ -298,7 +298,8 @@ long hg_redone_frames(hg_ctx *ctx);
 long hg_layout_walks(hg_ctx *ctx);
 /* Layout knobs of the piecewise fast path; they never change results (tests run the parity suite under each setting), only
  * which kernel layout the next hg_piecewise_set_frames picks:
- *   "min_row_groups" (default 1536): frame sets with fewer 4-row groups run one row per workgroup;
+ *   "min_row_groups" (default 1152): frame sets with fewer 4-row groups run one row per workgroup on row lists (k_pw_patch sets keep
+ *           the self-span form down to half of it);
  *   "patch" (default -1 = by estimate: rows of more than 56 spans in a frame set that fits the kernel, and every set that fits it when
  *           each frame reads its own source): 0 never use k_pw_patch, 1 use it whenever the frame width allows, 2 the same in its
  *           global-record variant;
