@@ -68,7 +68,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     for (hg_ctx::Stage &st : c->stage) { if (st.h) (void)hipHostFree(st.h); if (st.done) (void)hipEventDestroy(st.done); }
     for (hg_ctx::GeoStage &gs : c->geo_stage) { if (gs.h) (void)hipHostFree(gs.h); if (gs.done) (void)hipEventDestroy(gs.done); }
-    { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_trix, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status };
+    { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_trix, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status, c->d_st_pts, c->d_st_tris, c->d_st_mats };
       for (void *q : rp) if (q) (void)hipFree(q); }
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

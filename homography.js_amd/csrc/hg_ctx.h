@@ -1,6 +1,6 @@
 // hg_ctx.h -- the context behind the C ABI of include/hgwarp.h and the helpers its translation units share
 // (hg_api.hip: library / context / buffers / host-side solves / source image; hg_api_geometric.hip; hg_api_piecewise.hip;
-// hg_api_forward.hip).  Internal: nothing here is exported.
+// hg_api_forward.hip; hg_api_state.hip).  Internal: nothing here is exported.
 #pragma once
 #include "../../include/hgwarp.h"
 #include "hg_kernels.h"
@@ -109,6 +109,10 @@ struct hg_ctx {
     float *d_redo_fwd = nullptr; size_t redo_fwd_cap = 0;
     float *d_redo_inv = nullptr; size_t redo_inv_cap = 0;
     int32_t *d_redo_status = nullptr; size_t redo_status_cap = 0;
+    // reference-state warps (hg_api_state.hip): the map's own point set and triangles, the cached matrices handed over by the caller
+    float *d_st_pts = nullptr; size_t st_pts_cap = 0;
+    uint32_t *d_st_tris = nullptr; size_t st_tris_cap = 0;
+    float *d_st_mats = nullptr; size_t st_mats_cap = 0;
     // layout of the row counters / status ring as of their last memset (a frame set with the same layout reuses them as they are)
     size_t rows_F = 0; int rows_stride = 0, rows_cap = 0;
     // self-span path (k_tri_setup -> k_pw_rows<SELF>, hg_kernels.h): the row workgroups evaluate their own spans, no row lists

@@ -39,6 +39,18 @@ __global__ void k_map_to_i16(const int32_t *__restrict__ m32, int16_t *__restric
     for (; i < n; i += stride) m16[i] = (int16_t)m32[i];
 }
 
+// Largest Int16Array VALUE among the first n cells (-1 when none is set): the reference-state warps compare it with the number of
+// matrices they were given before any pixel indexes one (hg_warp_*_piecewise_state).
+__global__ void k_map_max_i16(const int32_t *__restrict__ m32, size_t n, int32_t *__restrict__ out)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int best = -1;
+    for (; i < n; i += stride) { const int v = (int)(int16_t)m32[i]; best = v > best ? v : best; }
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(best, o); best = w > best ? w : best; }
+    if ((threadIdx.x & 63) == 0 && best >= 0) atomicMax(out, best);
+}
+
 // Pixel loop :1042-1056 reading the materialised map.  Block = 64 x 4 threads = 4 rows x 256 pixels.
 __global__ __launch_bounds__(256) void k_pw_from_map(PwMesh mesh, const float *__restrict__ invm, FrameDesc fd,
                                                      const int32_t *__restrict__ map32, uint8_t *__restrict__ out)
@@ -88,6 +100,14 @@ void launch_pw_from_map(const PwMesh &mesh, const PwFrames &fr, int f, const Fra
     dim3 grid((fd.obj_w + 255) / 256, (fd.obj_h + 3) / 4);
     hipLaunchKernelGGL(k_pw_from_map, grid, dim3(64, 4), 0, stream, mesh,
                        (const float *)(fr.inv + (size_t)f * mesh.n_tris * kInvStride), fd, map32, out);
+}
+
+void launch_map_max_i16(const int32_t *map32, size_t n, int32_t *out, hipStream_t stream)
+{
+    (void)hipMemsetAsync(out, 0xff, sizeof(int32_t), stream);      // -1
+    if (n == 0) return;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_map_max_i16, dim3(blocks), dim3(256), 0, stream, map32, n, out);
 }
 
 void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream_t stream)

@@ -137,6 +137,7 @@ void launch_map_build(const PwMesh &mesh, const PwFrames &fr, int f, const Frame
 void launch_pw_from_map(const PwMesh &mesh, const PwFrames &fr, int f, const FrameDesc &fd, const int32_t *map32,
                         uint8_t *out, hipStream_t stream);
 void launch_map_to_i16(const int32_t *map32, int16_t *map16, size_t n, hipStream_t stream);
+void launch_map_max_i16(const int32_t *map32, size_t n, int32_t *out, hipStream_t stream);      // *out = largest (int16) value of the first n cells, -1 if none
 void launch_fill_i32(int32_t *p, size_t n, int32_t v, hipStream_t stream);      // grid-stride fill (map / winner-buffer initialisation)
 
 // k_geo: _inverseGeometricWarp pixel loop :997-1011 for all frames.  mats = F x 8 doubles (inverse matrices).

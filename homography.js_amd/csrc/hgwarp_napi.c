@@ -643,6 +643,70 @@ static napi_value fn_warp_forward_piecewise(napi_env env, napi_callback_info inf
     return r;
 }
 
+/* ---------------------------------------------------------------- reference-state forms (stale matrices / stale map) */
+/* solveAffineTriangles(src, dst, triangles) -> Float32Array(6 T): affineMatrixFromTriangles per triangle (:785-804), on the host */
+static napi_value fn_solve_affine_triangles(napi_env env, napi_callback_info info)
+{
+    napi_value a[3];
+    if (!get_args(env, info, 3, a)) return NULL;
+    size_t ns, nd, nt;
+    float *s = (float *)get_typed(env, a[0], napi_float32_array, &ns, "src"); if (!s) return NULL;
+    float *d = (float *)get_typed(env, a[1], napi_float32_array, &nd, "dst"); if (!d) return NULL;
+    uint32_t *t = (uint32_t *)get_typed(env, a[2], napi_uint32_array, &nt, "triangles"); if (!t) return NULL;
+    const size_t np = (ns < nd ? ns : nd) / 2, T = nt / 3;
+    void *out; napi_value r = make_typed(env, napi_float32_array, 6 * T, 4, &out); if (!r) return NULL;
+    HG_CALL(NULL, "hg_solve_affine_triangles", hg_solve_affine_triangles(s, d, (int)np, t, (int)T, (float *)out));
+    return r;
+}
+
+/* a map id without a matrix: the reference's loop throws a TypeError at that pixel (`matrix[0]` of undefined, :1383) */
+static napi_value throw_state(napi_env env, hg_ctx *ctx, const char *what, int code)
+{
+    if (code == HG_ERR_RANGE) { napi_throw_type_error(env, NULL, "Cannot read property '0' of undefined"); return NULL; }
+    return throw_hg(env, ctx, what, code);
+}
+
+/* warpInversePiecewiseState(ctx, fwdMats, dstPoints, triangles, minSrcX, minSrcY, xOff, yOff, objW, objH) */
+static napi_value fn_warp_inverse_piecewise_state(napi_env env, napi_callback_info info)
+{
+    napi_value a[10];
+    if (!get_args(env, info, 10, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    size_t nm, np, nt; int msx, msy; hg_geom g;
+    float *m = (float *)get_typed(env, a[1], napi_float32_array, &nm, "matrices"); if (!m) return NULL;
+    float *p = (float *)get_typed(env, a[2], napi_float32_array, &np, "dstPoints"); if (!p) return NULL;
+    uint32_t *t = (uint32_t *)get_typed(env, a[3], napi_uint32_array, &nt, "triangles"); if (!t) return NULL;
+    if (!get_i32(env, a[4], &msx) || !get_i32(env, a[5], &msy)) return NULL;
+    if (!get_geom(env, a + 6, &g)) return NULL;
+    const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
+    void *out; napi_value r = make_pixels(env, px * 4, NULL, 0, &out); if (!r) return NULL;
+    hg_tri_map_def def = { p, (int)(np / 2), t, (int)(nt / 3), g.obj_w, g.obj_h, g.y_off };
+    if (px) { int rc = hg_warp_inverse_piecewise_state(h->ctx, m, (int)(nm / 6), &def, msx, msy, g, (uint8_t *)out);
+              if (rc != HG_OK) return throw_state(env, h->ctx, "hg_warp_inverse_piecewise_state", rc); }
+    return r;
+}
+
+/* warpForwardPiecewiseState(ctx, fwdMats, mapPoints, mapTriangles, mapWidth, mapHeight, mapYOff, minSrcX, minSrcY, maxSrcX, maxSrcY, xOff, yOff, objW, objH) */
+static napi_value fn_warp_forward_piecewise_state(napi_env env, napi_callback_info info)
+{
+    napi_value a[15];
+    if (!get_args(env, info, 15, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    size_t nm, np, nt; int mw, mh, myo, msx, msy, mxx, mxy; hg_geom g;
+    float *m = (float *)get_typed(env, a[1], napi_float32_array, &nm, "matrices"); if (!m) return NULL;
+    float *p = (float *)get_typed(env, a[2], napi_float32_array, &np, "mapPoints"); if (!p) return NULL;
+    uint32_t *t = (uint32_t *)get_typed(env, a[3], napi_uint32_array, &nt, "mapTriangles"); if (!t) return NULL;
+    if (!get_i32(env, a[4], &mw) || !get_i32(env, a[5], &mh) || !get_i32(env, a[6], &myo)) return NULL;
+    if (!get_i32(env, a[7], &msx) || !get_i32(env, a[8], &msy) || !get_i32(env, a[9], &mxx) || !get_i32(env, a[10], &mxy)) return NULL;
+    if (!get_geom(env, a + 11, &g)) return NULL;
+    const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
+    void *out; napi_value r = make_pixels(env, px * 4, NULL, 0, &out); if (!r) return NULL;
+    hg_tri_map_def def = { p, (int)(np / 2), t, (int)(nt / 3), mw, mh, myo };
+    if (px) { int rc = hg_warp_forward_piecewise_state(h->ctx, m, (int)(nm / 6), &def, msx, msy, mxx, mxy, g, (uint8_t *)out);
+              if (rc != HG_OK) return throw_state(env, h->ctx, "hg_warp_forward_piecewise_state", rc); }
+    return r;
+}
+
 /* parity taps */
 static napi_value fn_get_tri_map(napi_env env, napi_callback_info info)
 {
@@ -1059,6 +1123,8 @@ static napi_value init(napi_env env, napi_value exports)
         { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch }, { "warpInverseGeometricBatch", fn_warp_inverse_geometric_batch },
         { "warpForwardGeometric", fn_warp_forward_geometric }, { "warpForwardPiecewise", fn_warp_forward_piecewise },
         { "warpForwardPiecewiseBatch", fn_warp_forward_piecewise_batch }, { "warpForwardGeometricBatch", fn_warp_forward_geometric_batch },
+        { "solveAffineTriangles", fn_solve_affine_triangles }, { "warpInversePiecewiseState", fn_warp_inverse_piecewise_state },
+        { "warpForwardPiecewiseState", fn_warp_forward_piecewise_state },
         { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },
         { "multiCreate", fn_multi_create }, { "multiDestroy", fn_multi_destroy }, { "multiSetImage", fn_multi_set_image },
         { "multiSetMesh", fn_multi_set_mesh }, { "multiWarpBatch", fn_multi_warp_batch }, { "multiWarpGeometricBatch", fn_multi_warp_geometric_batch },

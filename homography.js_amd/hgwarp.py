@@ -36,12 +36,19 @@ EXPORTS = [
     "hg_get_tri_map", "hg_get_tri_map_fused", "hg_get_matrices", "hg_warp_inverse_piecewise_via_map",
     "hg_warp_forward_geometric", "hg_warp_forward_piecewise", "hg_warp_forward_geometric_device", "hg_warp_forward_geometric_batch_device",
     "hg_warp_forward_piecewise_device", "hg_warp_forward_piecewise_batch_device",
+    "hg_solve_affine_triangles", "hg_warp_inverse_piecewise_state", "hg_warp_forward_piecewise_state",
     "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_piecewise_self", "hg_last_piecewise_flag", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_layout_walks", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range",
 ]
 
 
 class Geom(C.Structure):
     _fields_ = [("x_off", C.c_int32), ("y_off", C.c_int32), ("obj_w", C.c_int32), ("obj_h", C.c_int32)]
+
+
+class TriMapDef(C.Structure):
+    """hg_tri_map_def: what the reference's shared map field was rasterised from (include/hgwarp.h, reference-state forms)."""
+    _fields_ = [("points", C.POINTER(C.c_float)), ("n_points", C.c_int), ("triangles", C.POINTER(C.c_uint32)), ("n_triangles", C.c_int),
+                ("width", C.c_int32), ("height", C.c_int32), ("y_off", C.c_int32)]
 
 
 class HgError(RuntimeError):
@@ -111,6 +118,9 @@ def lib():
         "hg_warp_forward_geometric_batch_device": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
         "hg_warp_forward_piecewise_device": (i, [vp, f32p, i, i, Geom, vp]),
         "hg_warp_forward_piecewise_batch_device": (i, [vp, f32p, i, i, C.POINTER(Geom), C.POINTER(sz), i, vp]),
+        "hg_solve_affine_triangles": (i, [f32p, f32p, i, C.POINTER(C.c_uint32), i, f32p]),
+        "hg_warp_inverse_piecewise_state": (i, [vp, f32p, i, C.POINTER(TriMapDef), i, i, Geom, u8p]),
+        "hg_warp_forward_piecewise_state": (i, [vp, f32p, i, C.POINTER(TriMapDef), i, i, i, i, Geom, u8p]),
     }
     older = "HGWARP_LIB" in os.environ       # A/B tooling (tools/ab*.sh) loads an OLDER build beside the current one: it may lack newer symbols
     for name, (res, args) in sig.items():
@@ -150,6 +160,22 @@ def solve_affine(src, dst):
     out = np.empty(6, np.float32)
     _check(lib().hg_solve_affine(s, d, out.ctypes.data_as(C.POINTER(C.c_float))))
     return out
+
+
+def solve_affine_triangles(src_pts, dst_pts, tris):
+    """affineMatrixFromTriangles per triangle of a mesh (:785-804): (T, 6) float32, on the host."""
+    (s, sp), (d, dp) = _f32(src_pts), _f32(dst_pts)
+    t = np.ascontiguousarray(tris, np.uint32)
+    out = np.empty((t.size // 3, 6), np.float32)
+    _check(lib().hg_solve_affine_triangles(sp, dp, min(s.size, d.size) // 2, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size // 3,
+                                           out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def _map_def(points, tris, width, height, y_off):
+    p, pp = _f32(points)
+    t = np.ascontiguousarray(tris, np.uint32)
+    return TriMapDef(pp, p.size // 2, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size // 3, int(width), int(height), int(y_off)), (p, t)
 
 
 def invert_affine(m):
@@ -371,6 +397,24 @@ class Context:
         g = Geom(*[int(v) for v in geom])
         out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
         self._c(lib().hg_warp_forward_piecewise(self._h, dp, int(max_src_x), int(max_src_y), g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    # reference-state forms: the cached matrices as they stood + the definition of the map the shared field held
+    def warp_inverse_piecewise_state(self, fwd_mats, dst_pts, tris, min_src_x, min_src_y, geom):
+        m, mp = _f32(fwd_mats)
+        g = Geom(*[int(v) for v in geom])
+        d, keep = _map_def(dst_pts, tris, g.obj_w, g.obj_h, g.y_off)
+        out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
+        self._c(lib().hg_warp_inverse_piecewise_state(self._h, mp, m.size // 6, C.byref(d), int(min_src_x), int(min_src_y), g, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def warp_forward_piecewise_state(self, fwd_mats, map_pts, map_tris, map_w, map_h, map_y_off, min_src_x, min_src_y, max_src_x, max_src_y, geom):
+        m, mp = _f32(fwd_mats)
+        g = Geom(*[int(v) for v in geom])
+        d, keep = _map_def(map_pts, map_tris, map_w, map_h, map_y_off)
+        out = np.zeros((max(g.obj_h, 0), max(g.obj_w, 0), 4), np.uint8)
+        self._c(lib().hg_warp_forward_piecewise_state(self._h, mp, m.size // 6, C.byref(d), int(min_src_x), int(min_src_y), int(max_src_x), int(max_src_y), g,
+                                                      out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
     def warp_forward_geometric_batch_device(self, kind, mats, geoms, offsets, d_out):

@@ -15,9 +15,12 @@
 //
 // Differences, all Node-only consequences of having no DOM:
 //   * HTMLImageElement inputs / asHTMLPromise / transformHTMLElement throw (the reference needs a browser for them too);
-//   * a forward piecewise warp that follows an inverse one: the reference then indexes the stale INVERSE triangle map left in
-//     the shared `_trianglesCorrespondencesMatrix` field (:819-820 vs :847-848) with forward indices and returns garbage;
-//     here the forward map is simply rebuilt (what the author evidently meant);
+//   * (the reference's stale-state behaviour IS reproduced -- SURVEY.md Appendix A-Q12: one field holds the forward and the inverse
+//     triangle map (:819-820 vs :847-848), so a forward piecewise warp that follows an inverse one indexes the stale INVERSE map
+//     (:957); the per-triangle matrices survive setSourcePoints / setTriangles until the next setDestinyPoints (:252-255, :519,
+//     :766).  The class mirrors both caches as value snapshots (`_map`, `_pm`) and hands the GPU exactly what the reference's loops
+//     would read.  `new Homography(t, w, h, {repairStaleMap: true})` opts out: forward warps then always read the forward map of the
+//     current mesh and every warp the matrices of the current point sets -- what the author evidently meant);
 //   * frames of 1 MiB and more live in pooled page-locked memory handed out as external ArrayBuffers (no behavioural
 //     difference; `Homography.release(imageData)` optionally returns a frame to the pool at once);
 //   * Delaunator is not bundled: `Homography.triangulate` (default: ./delaunay.mjs, a restatement of delaunator 5's
@@ -76,6 +79,20 @@ function unscalePoints(p, sx, sy) { for (let i = 0; i < p.length; i++) p[i] = (i
 // degenerate matrix, > 2^31 - 1 under Node 12): same error here, before anything reaches the native side.
 function checkedLength(n) { if (n > 2147483647) throw new RangeError(`Invalid typed array length: ${n}`); return n; }
 const asF32 = (p) => (p instanceof Float32Array ? p : Float32Array.from(p));     // what the native side needs (values are already f32 when typed Float32Array)
+// value equality of two point lists as the reference's Float32Array scratch triangles see them (:792-799); NaN equals NaN
+function samePoints(a, b) {
+    if (a.length !== b.length) return false;
+    for (let i = 0; i < a.length; i++) { const x = Math.fround(a[i]), y = Math.fround(b[i]); if (x !== y && (x === x || y === y)) return false; }
+    return true;
+}
+function sameTriangles(a, b) {
+    if (a === b) return true;
+    if (a === null || b === null || a.length !== b.length) return false;
+    for (let i = 0; i < a.length; i++) if (a[i] !== b[i]) return false;
+    return true;
+}
+// `new Int16Array(n)` of the map builders (:820, :848): a negative length throws, NaN makes an empty array
+function checkedMapLength(n) { if (n < 0 || n > 2147483647) throw new RangeError(`Invalid typed array length: ${n}`); return n; }
 
 class Homography {
     constructor(transform = 'auto', width = null, height = null, options = {}) {
@@ -90,12 +107,21 @@ class Homography {
         this._image = null;
         this._maxSrcX = null; this._maxSrcY = null; this._minSrcX = null; this._minSrcY = null;
         this._srcPointsAreNormalized = true; this._dstPointsAreNormalized = true;
-        // The reference caches an Int16Array here; its null-ness steers re-triangulation (:252, :756).  We keep only that
-        // fact (and which map it would hold); the map itself lives on the GPU and is rebuilt per warp, as in :1033.
-        this._mapState = null;                                  // null | 'forward' | 'inverse'
+        // The two caches of the reference's piecewise path, mirrored as VALUE SNAPSHOTS of what they were computed from (the arrays
+        // themselves live on the GPU and are rebuilt there):
+        //   _map  <-> _trianglesCorrespondencesMatrix (:115): null | {kind: 'forward' | 'inverse', pts, tris, width, height, yOff} = the
+        //             point set, triangles and geometry fillTriangle rasterised (:817-832 source points over the source bbox, :845-861
+        //             destiny points over the output window).  Its null-ness steers re-triangulation (:252, :756); a forward warp reads
+        //             WHATEVER it holds (:957);
+        //   _pm   <-> _piecewiseMatrices (:119): null | {src, dst, tris} = the point sets and triangles the per-triangle matrices
+        //             were solved from (:785-804); both warps use those matrices as they stand (:961, :1036-1038).
+        this._map = null;
+        this._pm = null;
         this._triangles = null;
         this._transformMatrix = null;
-        this._piecewiseReady = false;                           // reference: _piecewiseMatrices !== null
+        // Opt-out of the stale-state quirks (header): forward warps always read the forward map of the current mesh, every warp the
+        // matrices of the current point sets.
+        this.repairStaleMap = options.repairStaleMap === true;
         this._lastPath = null;
         this._native = addon();                                 // throws if the addon is missing: there is no JS fallback
         this._device = options.device === undefined ? 0 : options.device;
@@ -112,6 +138,9 @@ class Homography {
         this._ctxHandle = null;                                 // GPU context, created at the first warp
         this._multiHandle = null; this._multiKey = null; this._multiImage = null;   // hg_multi over a device list (warpBatch({devices}))
     }
+
+    /** Which map the shared field would hold: null | 'forward' | 'inverse'. */
+    get _mapState() { return this._map === null ? null : this._map.kind; }
 
     /** GPU context of this instance (one hg_ctx per Homography).  Throws a string without a usable gfx950 device. */
     get _ctx() {
@@ -151,9 +180,9 @@ class Homography {
         if (this._dstPoints !== null && this.transform !== 'piecewiseaffine') {
             this._transformMatrix = this._solve(this._srcPoints, this._dstPoints);
         }
-        if (this.transform === 'piecewiseaffine' && this._mapState === null) {
+        if (this.transform === 'piecewiseaffine' && this._map === null) {
             this._triangles = null;                             // :254 (_initialTriangles is never set by the reference)
-            this._piecewiseReady = false;
+            this._pm = null;                                    // :255 (ONLY here: with a map in place the old matrices survive new source points)
             if (!this._srcPointsAreNormalized || (this._width > 0 && this._height > 0)) this._refreshPiecewise();
             else if (this._triangles === null) this._triangles = Homography.triangulate(this._srcPoints);
         }
@@ -185,7 +214,7 @@ class Homography {
             this._alignRanges();
             this._transformMatrix = this._solve(this._srcPoints, this._dstPoints);
         } else {
-            this._piecewiseReady = false;
+            this._pm = null;                                    // :361
         }
         if (this._image !== null || (this.transform === 'piecewiseaffine' && this._width > 0 && this._height > 0)) this._deriveOutputWindow();
         if (this.transform === 'piecewiseaffine' && this._width > 0 && this._height > 0) {
@@ -242,20 +271,34 @@ class Homography {
     warpBatch(dstPointSets, options = {}) {
         if (this.transform === 'affine' || this.transform === 'projective') return this._warpBatchGeometric(dstPointSets, options);
         if (this.transform !== 'piecewiseaffine') throw ("hgwarp: warpBatch() needs a transform (set the source points first)");
-        if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
         const F = dstPointSets.length, n = this._srcPoints.length;
         const all = new Float32Array(F * n), geoms = new Int32Array(F * 4), forward = new Array(F).fill(false), blank = new Array(F).fill(false);
+        const stale = [];                                       // forward frames that read something else than the forward map of the current mesh (:957)
         for (let f = 0; f < F; f++) {
             this.setDestinyPoints(dstPointSets[f], options.pointsAreNormalized === undefined ? null : options.pointsAreNormalized);   // :337-380, as the loop does
+            if (this._image === null && !options.images) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");   // the loop's first warp() (:411-413)
             all.set(asF32(this._dstPoints), f * n);
             const [xo, yo, ow, oh] = this._window();
-            if (!(ow * oh >= 1)) { blank[f] = true; continue; }                                         // :440: a 1 x 1 blank frame
+            forward[f] = !(options.inverse === true || ow > this._width || oh > this._height || ow * 1.2 < this._width || oh * 1.2 < this._height);   // :421-422
+            blank[f] = !(ow * oh >= 1);                                                                 // :440: a 1 x 1 blank frame
+            // the shared map field, carried from frame to frame as the loop would: an inverse frame leaves its own map there (:847-857),
+            // a forward frame reads what it finds
+            if (!forward[f]) {
+                checkedMapLength(ow * oh);
+                this._map = { kind: 'inverse', pts: all.subarray(f * n, (f + 1) * n), tris: this._triangles, width: ow, height: oh, yOff: yo };
+            } else if (this.repairStaleMap) {
+                if (!this._mapIsCurrentForward()) this._snapshotForwardMap();
+            } else if (!(this._mapIsCurrentForward() && this._matricesAreCurrent())) {
+                if (this._map === null) throw new TypeError("Cannot read property '0' of null");
+                if (!blank[f]) stale.push({ f, map: this._map, mats: this._snapshotMatrices() });
+                blank[f] = blank[f] || null;                                                            // (null: neither blank nor batched)
+            }
+            if (blank[f] === true) continue;
             checkedLength(ow * oh * 4);
             geoms.set([xo, yo, ow, oh], f * 4);
-            forward[f] = !(options.inverse === true || ow > this._width || oh > this._height || ow * 1.2 < this._width || oh * 1.2 < this._height);   // :421-422
         }
         const frames = new Array(F).fill(null);
-        const pick = (want) => { const ids = []; for (let f = 0; f < F; f++) if (!blank[f] && forward[f] === want) ids.push(f); return ids; };
+        const pick = (want) => { const ids = []; for (let f = 0; f < F; f++) if (blank[f] === false && forward[f] === want) ids.push(f); return ids; };
         const subset = (ids) => {                                                                       // points / windows / sources of a subset of the frames
             if (ids.length === F) return { pts: all, g: geoms, images: options.images };
             const pts = new Float32Array(ids.length * n), g = new Int32Array(ids.length * 4);
@@ -294,7 +337,6 @@ class Homography {
             inv.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
         if (fwd.length) {                                                                               // _piecewiseAffineWarp :948-972 for the frames warp() sends there
-            if (!this._native.warpForwardPiecewiseBatch) throw ("hgwarp: the forward (source-to-destiny) piecewise batch is not built into this addon; call warpBatch(sets, {inverse: true})");
             const { pts, g, images } = subset(fwd);
             room(g);
             this._uploadSources(images);
@@ -302,11 +344,14 @@ class Homography {
             const datas = this._native.warpForwardPiecewiseBatch(this._ctx, pts, this._maxSrcX, this._maxSrcY, g);
             fwd.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
-        for (let f = 0; f < F; f++) if (blank[f]) frames[f] = makeImageData(new Uint8ClampedArray(4), 1, 1);
-        if (F > 0 && !blank[F - 1]) {                                                                   // what the last warp() of the loop leaves behind
-            this._lastPath = forward[F - 1] ? '_piecewiseAffineWarp' : '_inversePiecewiseAffineWarp';
-            this._mapState = forward[F - 1] ? 'forward' : 'inverse';
+        for (const { f, map, mats } of stale) {                                                         // forward frames over a stale map: one by one, as they stand
+            const [xo, yo, ow, oh] = geoms.subarray(4 * f, 4 * f + 4);
+            makeRoomFor(this._native, ow * oh * 4, 1);
+            if (options.images) this._uploadSources([options.images[f % options.images.length]]); else this._uploadImage();
+            frames[f] = makeImageData(this._forwardOverHeldMap(mats, map, xo, yo, ow, oh), ow, oh);
         }
+        for (let f = 0; f < F; f++) if (blank[f] === true) frames[f] = makeImageData(new Uint8ClampedArray(4), 1, 1);
+        if (F > 0) this._lastPath = forward[F - 1] ? '_piecewiseAffineWarp' : '_inversePiecewiseAffineWarp';   // what the last warp() of the loop leaves behind
         return frames;
     }
 
@@ -318,12 +363,12 @@ class Homography {
      * Affine frames of the source's size go through the forward loop _geometricWarp (:427) with their forward matrices, as one batch.
      */
     _warpBatchGeometric(dstPointSets, options = {}) {
-        if (this._image === null) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");
         const F = dstPointSets.length, per = this.transform === 'affine' ? 6 : 8;
         const from = new Float32Array(F * per), to = new Float32Array(F * per), geoms = new Int32Array(F * 4), mats = new Float64Array(F * 8);
         const blank = new Array(F).fill(false), forward = new Array(F).fill(false);
         for (let f = 0; f < F; f++) {
             this.setDestinyPoints(dstPointSets[f], options.pointsAreNormalized === undefined ? null : options.pointsAreNormalized);
+            if (this._image === null && !options.images) throw ("warp() must receive an image if it was not setted before through `setImage(img)` or  `setSourcePoints(points, img)`");   // the loop's first warp() (:411-413)
             const [xo, yo, ow, oh] = this._window();
             forward[f] = this.transform === 'affine' && options.inverse !== true && ow === this._width && oh === this._height;      // :426-427, :431
             if (forward[f]) mats.set(Array.from(this._transformMatrix), f * 8);                          // _geometricWarp uses _transformMatrix as it stands (:915)
@@ -366,7 +411,6 @@ class Homography {
             inv.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
         if (fwd.length) {                                                                               // _geometricWarp :911-932
-            if (!this._native.warpForwardGeometricBatch) throw ("hgwarp: the forward (source-to-destiny) affine batch is not built into this addon; call warpBatch(sets, {inverse: true})");
             const g = sub(geoms, fwd, 4), m = sub(mats, fwd, 8);
             room(g);
             this._uploadSources(subImages(fwd));
@@ -424,7 +468,11 @@ class Homography {
 
     // ------------------------------------------------------------------------------------------------ private
     _solve(from, to) {                                                                                   // :1237-1250
-        const a = asF32(from), b = asF32(to);
+        // a point set shorter than the transform needs (an 'auto' instance between a 4-point setSourcePoints and the matching
+        // setDestinyPoints): the reference reads `undefined` past the end, i.e. NaN in its arithmetic
+        const need = this.transform === 'affine' ? 6 : 8;
+        const padded = (p) => { p = asF32(p); if (p.length >= need) return p; const q = new Float32Array(need).fill(NaN); q.set(p); return q; };
+        const a = padded(from), b = padded(to);
         if (this.transform === 'affine') return this._native.solveAffine(a, b);                          // Float32Array(6)
         if (this.transform === 'projective') return Array.from(this._native.solveProjective(a, b));      // plain Array(8) of doubles, as numeric.js returns
         throw (`${this.transform} transform does not exist`);
@@ -435,7 +483,7 @@ class Homography {
         this._width = width; this._height = height;
         if (lastW === width && lastH === height) return;
         this._width = Math.round(width); this._height = Math.round(height);
-        this._mapState = null;
+        this._map = null;                                                                                // :647
         if (this.transform === 'projective') {
             if (this._srcPoints !== null && this._srcPointsAreNormalized) { scalePoints(this._srcPoints, this._width, this._height); this._srcPointsAreNormalized = false; }
             if (this._dstPoints !== null && this._dstPointsAreNormalized) { scalePoints(this._dstPoints, this._width, this._height); this._dstPointsAreNormalized = false; }
@@ -481,15 +529,16 @@ class Homography {
             if (this._width > 0 && this._height > 0) { scalePoints(this._srcPoints, this._width, this._height); this._srcPointsAreNormalized = false; }
             else throw ("Trying to set the Piecewise Affine Transform parameters without knowing the source points ranges");
         }
-        if (!this._srcPointsAreNormalized && (this._triangles === null || this._mapState === null)) {
+        if (!this._srcPointsAreNormalized && (this._triangles === null || this._map === null)) {
             const mm = this._native.minmaxXY(asF32(this._srcPoints));                                    // :758
             [this._minSrcX, this._minSrcY, this._maxSrcX, this._maxSrcY] = mm;
-            this._mapState = 'forward';                                                                  // :759 (built on the GPU when a forward warp needs it)
+            this._snapshotForwardMap();                                                                  // :759
         }
-        if (this._dstPoints !== null && !this._piecewiseReady && this._triangles !== null) {
+        if (this._dstPoints !== null && this._pm === null && this._triangles !== null) {
             if (this._dstPointsAreNormalized) { scalePoints(this._dstPoints, this._width, this._height); this._dstPointsAreNormalized = false; }
             if (this._srcPointsAreNormalized !== this._dstPointsAreNormalized) this._alignRanges();     // :787-789
-            this._piecewiseReady = true;                                                                 // :769 (the per-triangle solves run on the GPU with the warp)
+            // :769: matrices of THESE point sets (the per-triangle solves run on the GPU with the warp)
+            this._pm = { src: Float32Array.from(this._srcPoints), dst: Float32Array.from(this._dstPoints), tris: this._triangles };
         }
     }
 
@@ -562,22 +611,53 @@ class Homography {
                                                  this._reusable(ow * oh * 4));
     }
 
+    /** Do the cached per-triangle matrices (:769) belong to the current point sets and triangles?  (Always, unless source points or
+     *  triangles were replaced after the last setDestinyPoints: :252-255, :519.) */
+    _matricesAreCurrent() {
+        const pm = this._pm;
+        return pm !== null && sameTriangles(pm.tris, this._triangles) && samePoints(pm.src, this._srcPoints) && samePoints(pm.dst, this._dstPoints);
+    }
+
+    /** Does the shared map field hold the forward map of the current mesh (:817-832 over the current source bbox)? */
+    _mapIsCurrentForward() {
+        const m = this._map;
+        return m !== null && m.kind === 'forward' && m.width === this._maxSrcX - this._minSrcX && m.height === this._maxSrcY - this._minSrcY &&
+               m.yOff === this._minSrcY && sameTriangles(m.tris, this._triangles) && samePoints(m.pts, this._srcPoints);
+    }
+
+    /** Forward matrices of the snapshot the reference's `_piecewiseMatrices` came from, 6 floats per triangle (host-side solves). */
+    _snapshotMatrices() {
+        const pm = this._pm;
+        if (pm === null) throw new TypeError("Cannot read property 'length' of null");                  // this._piecewiseMatrices.length (:1036) / [inTriangle] (:961)
+        const tris = pm.tris instanceof Uint32Array ? pm.tris : Uint32Array.from(pm.tris);
+        return this._native.solveAffineTriangles(pm.src, pm.dst, tris);
+    }
+
     _inversePiecewise() {                                                                                // :1029-1058
         this._lastPath = '_inversePiecewiseAffineWarp';
         const [xo, yo, ow, oh] = this._window();
-        this._mapState = 'inverse';                                                                      // :848 (the reference reuses the same field)
+        checkedMapLength(ow * oh);                                                                       // :848
+        // :847-857: the shared field now holds the INVERSE map of these destiny points over this window
+        this._map = { kind: 'inverse', pts: Float32Array.from(this._dstPoints), tris: this._triangles, width: ow, height: oh, yOff: yo };
+        const current = this.repairStaleMap || this._matricesAreCurrent();
+        const mats = current ? null : this._snapshotMatrices();
         if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
         checkedLength(ow * oh * 4);
         this._uploadImage();
+        if (!this.reuseOutput) makeRoomFor(this._native, ow * oh * 4, 1);
+        if (!current) {
+            // matrices of an OLDER point set / triangle list over the map of the current one (setSourcePoints or setTriangles without a
+            // setDestinyPoints since): the reference's loop as it stands, through the materialised map
+            const tris = this._triangles instanceof Uint32Array ? this._triangles : Uint32Array.from(this._triangles);
+            return this._native.warpInversePiecewiseState(this._ctx, mats, asF32(this._dstPoints), tris, this._minSrcX, this._minSrcY, xo, yo, ow, oh);
+        }
         this._uploadMesh();
         this._native.piecewisePrepare(this._ctx, asF32(this._dstPoints), xo, yo, ow, oh);
-        if (!this.reuseOutput) makeRoomFor(this._native, ow * oh * 4, 1);
         return this._native.warpInversePiecewise(this._ctx, this._reusable(ow * oh * 4));
     }
 
     _forwardGeometric() {                                                                                // :911-932
         this._lastPath = '_geometricWarp';
-        if (!this._native.warpForwardGeometric) throw ("hgwarp: the forward (source-to-destiny) affine path is not built into this addon; call warp(image, false, true)");
         this._uploadImage();
         const [xo, yo, ow, oh] = this._window();
         if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
@@ -588,15 +668,40 @@ class Homography {
 
     _forwardPiecewise() {                                                                                // :948-972
         this._lastPath = '_piecewiseAffineWarp';
-        if (!this._native.warpForwardPiecewise) throw ("hgwarp: the forward (source-to-destiny) piecewise path is not built into this addon; call warp(image, false, true)");
-        this._mapState = 'forward';                                                                      // (rebuilt on the GPU; see "Differences" in the header)
-        this._uploadImage();
-        this._uploadMesh();
         const [xo, yo, ow, oh] = this._window();
+        const usual = this.repairStaleMap || (this._mapIsCurrentForward() && this._matricesAreCurrent());
+        const map = this._map, mats = usual ? null : this._snapshotMatrices();
+        if (!usual && map === null) throw new TypeError("Cannot read property '0' of null");              // :957 on a null map
+        if (this.repairStaleMap && !this._mapIsCurrentForward()) this._snapshotForwardMap();
+        this._uploadImage();
         if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
         checkedLength(ow * oh * 4);
         makeRoomFor(this._native, ow * oh * 4, 1);
+        if (!usual) {
+            // :957 reads whatever the shared field holds -- after an inverse warp the stale INVERSE map of that warp's destiny points,
+            // laid out objectiveWidth cells per row but indexed (maxSrcX - minSrcX) per row, cells past its end `undefined` -- and :961
+            // the matrices as last solved: both handed over as they stand
+            return this._forwardOverHeldMap(mats, map, xo, yo, ow, oh);
+        }
+        this._uploadMesh();
         return this._native.warpForwardPiecewise(this._ctx, asF32(this._dstPoints), this._maxSrcX, this._maxSrcY, xo, yo, ow, oh);
+    }
+
+    /** _piecewiseAffineWarp :948-972 over the map snapshot `map` (whatever the shared field held) with the matrices `mats` as last solved. */
+    _forwardOverHeldMap(mats, map, xo, yo, ow, oh) {
+        const tris = map.tris instanceof Uint32Array ? map.tris : Uint32Array.from(map.tris);
+        // (`new Int16Array(w * h)` of a window that did not exist yet -- null, NaN -- is an empty array: every read is `undefined`)
+        const held = map.width * map.height >= 1 ? [map.width, map.height, map.yOff] : [0, 0, 0];
+        return this._native.warpForwardPiecewiseState(this._ctx, mats, map.pts, tris, held[0], held[1], held[2],
+                                                      this._minSrcX, this._minSrcY, this._maxSrcX, this._maxSrcY, xo, yo, ow, oh);
+    }
+
+    /** :759 / :817-832: the shared field becomes the forward map of the CURRENT source points over the current source bbox (built on
+     *  the GPU when a forward warp needs it). */
+    _snapshotForwardMap() {
+        const mw = this._maxSrcX - this._minSrcX, mh = this._maxSrcY - this._minSrcY;
+        checkedMapLength(mw * mh);
+        this._map = { kind: 'forward', pts: Float32Array.from(this._srcPoints), tris: this._triangles, width: mw, height: mh, yOff: this._minSrcY };
     }
 }
 

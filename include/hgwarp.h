@@ -41,7 +41,9 @@ enum {
     HG_ERR_HIP = 2,             /* a HIP runtime call failed (text in hg_last_error) */
     HG_ERR_NO_DEVICE = 3,       /* no usable GPU / device id out of range */
     HG_ERR_STATE = 4,           /* call order: image / mesh / prepared frame missing */
-    HG_ERR_NOMEM = 5
+    HG_ERR_NOMEM = 5,
+    HG_ERR_RANGE = 6            /* a reference-state warp whose map names a triangle without a matrix: the reference's loop throws a
+                                   TypeError there (`matrix[0]` of undefined, :1383) */
 };
 
 enum { HG_AFFINE = 0, HG_PROJECTIVE = 1 };
@@ -217,6 +219,36 @@ int hg_warp_forward_piecewise(hg_ctx *ctx, const float *dst_points, int max_src_
 int hg_warp_forward_piecewise_device(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, hg_geom geom, void *d_out);
 int hg_warp_forward_piecewise_batch_device(hg_ctx *ctx, const float *dst_points, int max_src_x, int max_src_y, const hg_geom *geoms,
                                            const size_t *out_offsets, int n_frames, void *d_out);
+
+/* ------------------------------------------------------------------------------------------------ reference-state forms
+ * The reference caches two things across calls and its loops read them AS THEY STAND:
+ *   - `_piecewiseMatrices` (:769): solved at setDestinyPoints, NOT invalidated by setTriangles (:519) nor -- once a map exists -- by
+ *     setSourcePoints (:252-255);
+ *   - `_trianglesCorrespondencesMatrix`: ONE field for the forward map (:819-820, source points over the source bounding box) and the
+ *     inverse map (:847-848, destiny points over the output window).  After an inverse warp, _piecewiseAffineWarp :957 indexes the
+ *     stale inverse map with forward indices ((y - minSrcY) * (maxSrcX - minSrcX) + (x - minSrcX)); cells past its end read
+ *     `undefined` and are skipped.
+ * A binding that mirrors those caches (js/Homography.mjs does, as value snapshots) uses the entry points above whenever both are
+ * current -- the only state a fresh instance can be in -- and these two otherwise.  They take the cached state explicitly: the
+ * FORWARD matrices as they were last solved (6 floats per triangle, hg_solve_affine_triangles of the snapshot) and the definition
+ * of the map the field holds (the point set + triangles fillTriangle rasterised, matrix_width, height = length / width, yOffset).
+ * Exact for any input (materialised map: atomicMax rasteriser + the pixel loop reading it), synchronous, host output of
+ * 4 * obj_w * obj_h bytes.  HG_ERR_RANGE when a cell the loop reads holds an id >= n_mats (JS: TypeError at that pixel). */
+typedef struct hg_tri_map_def {
+    const float *points; int n_points;              /* interleaved x,y of the point set the map was rasterised from */
+    const uint32_t *triangles; int n_triangles;
+    int32_t width, height, y_off;                   /* fillTriangle's matrix_width, Int16Array length / width, yOffset (:1111) */
+} hg_tri_map_def;
+/* affineMatrixFromTriangles for every triangle of a mesh (:785-804; host, no GPU): out = 6 floats per triangle; a vertex id beyond
+ * n_points reads `undefined` -> NaN like the reference's Float32Array scratch. */
+int hg_solve_affine_triangles(const float *src_points, const float *dst_points, int n_points, const uint32_t *triangles, int n_triangles, float *out);
+/* _inversePiecewiseAffineWarp :1029-1058 with stale matrices: the map is always the one of the current destiny points over the
+ * current window (:1033), so map->width / height / y_off must equal geom's obj_w / obj_h / y_off. */
+int hg_warp_inverse_piecewise_state(hg_ctx *ctx, const float *fwd_mats, int n_mats, const hg_tri_map_def *map, int min_src_x, int min_src_y,
+                                    hg_geom geom, uint8_t *out_host);
+/* _piecewiseAffineWarp :948-972 over whatever map the shared field holds. */
+int hg_warp_forward_piecewise_state(hg_ctx *ctx, const float *fwd_mats, int n_mats, const hg_tri_map_def *map, int min_src_x, int min_src_y,
+                                    int max_src_x, int max_src_y, hg_geom geom, uint8_t *out_host);
 
 /* ------------------------------------------------------------------------------------------------ several GPUs, one host thread
  * The caller loop `for (f) { setDestinyPoints(dst_f); warp(); }` (test/benchmark.js:107-110) spread over the devices of one

@@ -17,65 +17,10 @@ import { fileURLToPath } from 'url';
 
 const HERE = path.dirname(fileURLToPath(import.meta.url));
 
-function affineFromTriangles(s, d) {                                   // :1265-1306
-    const sE = s[4], sF = s[5], sA = s[0] - sE, sB = s[1] - sF, sC = s[2] - sE, sD = s[3] - sF;
-    const dE = d[4], dF = d[5], dA = d[0] - dE, dB = d[1] - dF, dC = d[2] - dE, dD = d[3] - dF;
-    const den = sA * sD - sB * sC;
-    const iA = sD / den, iB = sB / -den, iC = sC / -den, iD = sA / den;
-    const iE = (sD * sE - sC * sF) / -den, iF = (sB * sE - sA * sF) / den;
-    return new Float32Array([(dA * iA) + (dC * iB), (dB * iA) + (dD * iB), (dA * iC) + (dC * iD), (dB * iC) + (dD * iD),
-                             (dA * iE) + (dC * iF) + dE, (dB * iE) + (dD * iF) + dF]);
-}
-function inverseAffine(m) {                                            // :1345-1365
-    const out = new Float32Array(6), den = m[0] * m[3] - m[1] * m[2];
-    out[0] = m[3] / den; out[1] = m[1] / -den; out[2] = m[2] / -den; out[3] = m[0] / den;
-    out[4] = (m[3] * m[4] - m[2] * m[5]) / -den; out[5] = (m[1] * m[4] - m[0] * m[5]) / den;
-    return out;
-}
-function fillTriangle(t, idx, width, yOff, map) {                      // :1111-1197
-    const minY = ~~Math.min(t[1], t[3], t[5]), maxY = Math.ceil(Math.max(t[1], t[3], t[5]));
-    const seg = (xa, ya, xb, yb) => ({ m: xb !== xa ? (yb - ya) / (xb - xa) : Infinity, b: xb !== xa ? ya - xa * ((yb - ya) / (xb - xa)) : xa,
-                                       minY: Math.min(yb, ya), maxY: Math.max(yb, ya) });
-    const segs = [seg(t[0], t[1], t[2], t[3]), seg(t[0], t[1], t[4], t[5]), seg(t[2], t[3], t[4], t[5])];
-    for (let y = minY; y < maxY; y++) {
-        let mn = Infinity, mx = -Infinity;
-        for (let i = 0; i < 3; i++) {
-            const e = segs[i];
-            if (y >= e.minY && y <= e.maxY) {
-                let x;
-                if (e.m === Infinity) x = e.b; else if (e.m === 0) continue; else x = (y - e.b) / e.m;
-                if (x < mn) mn = x;
-                if (x > mx) mx = x;
-            }
-        }
-        map.fill(idx, (y - yOff) * width + Math.round(mn), (y - yOff) * width + Math.round(mx));
-    }
-}
-const applyAffine = (m, x, y) => [(m[0] * x) + (m[2] * y) + m[4], (m[1] * x) + (m[3] * y) + m[5]];     // :1382-1385
-export function warpInversePiecewise(sp, dp, tris, image, W, H, minSrcX, minSrcY, xOff, yOff, objW, objH) {
-    const T = tris.length / 3, inv = [], aS = new Float32Array(6), aD = new Float32Array(6);
-    const map = new Int16Array(objW * objH).fill(-1);                  // :845-861
-    for (let i = 0; i < T; i++) {
-        for (let k = 0; k < 3; k++) { const v = tris[3 * i + k] << 1; aS[2 * k] = sp[v]; aS[2 * k + 1] = sp[v + 1]; aD[2 * k] = dp[v]; aD[2 * k + 1] = dp[v + 1]; }
-        inv.push(inverseAffine(affineFromTriangles(aS, aD)));          // :785-804, :1036-1038
-        fillTriangle(aD, i, objW, yOff, map);
-    }
-    const srcRow = W << 2, dstRow = objW << 2, out = new Uint8ClampedArray(dstRow * objH);
-    for (let y = yOff; y < objH + yOff; y++) {                         // :1042-1056
-        for (let x = xOff; x < objW + xOff; x++) {
-            const t = map[(y - yOff) * objW + (x - xOff)];
-            if (t >= 0) {
-                let [sx, sy] = applyAffine(inv[t], x, y);              // :1046 (a fresh 2-element array per pixel, as the reference does)
-                if (sx >= minSrcX && sx < W + minSrcX && sy >= minSrcY && sy < H + minSrcY) {
-                    sx = Math.round(sx); sy = Math.round(sy);
-                    const si = (sy * srcRow) + (sx << 2), di = ((y - yOff) * dstRow) + ((x - xOff) << 2);
-                    out[di] = image[si]; out[di + 1] = image[si + 1]; out[di + 2] = image[si + 2]; out[di + 3] = image[si + 3];
-                }
-            }
-        }
-    }
-    return { out, map };
-}
+import core from './hg_oracle_core.cjs';
+
+const { warpInversePiecewise } = core;                                 // the loops themselves: oracle/hg_oracle_core.cjs
+export { warpInversePiecewise };
 
 // ---------------------------------------------------------------- workloads (same generators as homography.js_amd/workloads.py)
 function lcgImage(w, h, seed) {
@@ -113,15 +58,34 @@ if (mode === 'bench') {
     const BL = fs.readFileSync(path.join(HERE, '..', 'tests', 'golden', 'golden_blobs.bin'));
     const view = (ref, C) => { const b = BL.slice(ref.off, ref.off + ref.len); return new C(b.buffer.slice(b.byteOffset, b.byteOffset + b.length)); };
     const f32 = (x) => new Float32Array((Array.isArray(x) ? Uint32Array.from(x) : view(x, Uint32Array)).buffer);
+    const f64 = (xs) => { const d = new Float64Array(xs.length), u = new Uint32Array(d.buffer); xs.forEach((h, i) => { u[2 * i + 1] = parseInt(h.slice(0, 8), 16); u[2 * i] = parseInt(h.slice(8), 16); }); return d; };
     const sha = (t) => crypto.createHash('sha256').update(Buffer.from(t.buffer, t.byteOffset, t.byteLength)).digest('hex');
     const failures = [];
     let n = 0;
     for (const c of G.cases) {
         if (/_(4k|8k|1080p)/.test(c.name) || /int16_wrap/.test(c.name)) continue;
+        if (/^(seq_|readme_|css_|errors_)/.test(c.name)) continue;   // call-sequence cases: replayed through the class over these loops (tests/js/replay_golden.mjs --dry)
         c.warps.forEach((w, k) => {
-            if (w.path !== '_inversePiecewiseAffineWarp') return;
             const spec = Object.values(c.images)[0], img = lcgImage(spec.w, spec.h, spec.seed);
+            if (w.transform !== 'piecewiseaffine') {                   // the two geometric loops, matrices as the reference resolved them
+                const kind = w.transform === 'affine' ? 0 : 1, inverse = w.path === '_inverseGeometricWarp';
+                const mat = (mm) => (mm.f32 ? f32(mm.f32) : f64(mm.f64));
+                const out = inverse ? core.inverseGeometricLoop(kind, mat(w.invMatrix), img, w.W, w.H, w.xOff, w.yOff, w.objW, w.objH)
+                                    : core.forwardGeometricLoop(kind, mat(w.matrix), img, w.W, w.H, w.xOff, w.yOff, w.objW, w.objH);
+                n++;
+                if (sha(out) !== w.out.sha) failures.push(`${c.name}#${k}: RGBA (${w.path})`);
+                return;
+            }
             const tris = c.triangles.u32blob ? view(c.triangles.u32blob, Uint32Array) : Uint32Array.from(c.triangles);
+            if (w.path === '_piecewiseAffineWarp') {                   // forward loop over the forward map of the source points
+                const sp = f32(w.srcPoints), mw = w.maxSrcX - w.minSrcX, mh = w.maxSrcY - w.minSrcY;
+                const map = core.buildTriangleMap(sp, tris, mw, mh, w.minSrcY);
+                const out = core.forwardPiecewiseLoop(core.piecewiseMatrices(sp, f32(w.dstPoints), tris), map, img, w.W, w.minSrcX, w.minSrcY, w.maxSrcX, w.maxSrcY, w.xOff, w.yOff, w.objW, w.objH);
+                n++;
+                if (sha(out) !== w.out.sha) failures.push(`${c.name}#${k}: RGBA (forward piecewise)`);
+                if (sha(map) !== w.map.sha) failures.push(`${c.name}#${k}: forward map`);
+                return;
+            }
             const r = warpInversePiecewise(f32(w.srcPoints), f32(w.dstPoints), tris, img, w.W, w.H, w.minSrcX, w.minSrcY, w.xOff, w.yOff, w.objW, w.objH);
             n++;
             if (sha(r.out) !== w.out.sha) failures.push(`${c.name}#${k}: RGBA`);

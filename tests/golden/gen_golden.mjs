@@ -14,32 +14,14 @@
 // low-level state + outputs.  The C oracle / C-ABI tests consume the resolved state; the drop-in JS class
 // tests replay the script.
 import fs from 'fs';
-import os from 'os';
 import path from 'path';
 import crypto from 'crypto';
-import { fileURLToPath, pathToFileURL } from 'url';
+import { fileURLToPath } from 'url';
+import { loadReference } from './ref_loader.mjs';
+import { rng as seqRng, makeScript } from '../js/seq_scripts.mjs';
 
 const HERE = path.dirname(fileURLToPath(import.meta.url));
-const REF = process.env.HG_REFERENCE || '/root/reference';
 const FULL = process.env.HG_GOLDEN_FULL !== '0';       // HG_GOLDEN_FULL=0 skips the 4K/8K cases (quick run)
-
-// ---------------------------------------------------------------- shims + import of the reference
-const tmp = fs.mkdtempSync(path.join(os.tmpdir(), 'hgref-'));
-fs.writeFileSync(path.join(tmp, 'package.json'), '{"type":"module"}');
-let src = fs.readFileSync(path.join(REF, 'Homography.js'), 'utf8');
-const importLine = /^\s*import Delaunator from 'https:[^']*';\s*$/m;
-if (!importLine.test(src)) throw new Error('reference import line not found');
-src = src.replace(importLine, "import Delaunator from './delaunator_stub.js';");
-// expose the module-private pure functions for per-function vectors (temp copy only)
-src += '\nexport {fillTriangle, affineMatrixFromTriangles, inverseAffineMatrix, projectiveMatrixFromSquares, ' +
-       'calculateTransformMatrix, calculateTransformLimits, minmaxXYofArray, applyAffineTransformToPoint, ' +
-       'applyProjectiveTransformToPoint};\n';
-fs.writeFileSync(path.join(tmp, 'Homography.js'), src);
-fs.writeFileSync(path.join(tmp, 'delaunator_stub.js'),
-    'export default class { constructor(points){ this.triangles = globalThis.__TRI__(points); } }\n');
-globalThis.document = { createElement: () => ({ style: {}, width: 0, height: 0,
-    getContext: () => ({ clearRect() {}, drawImage() {}, getImageData() { throw new Error('no DOM'); }, putImageData() {} }) }) };
-globalThis.ImageData = class { constructor(data, w, h) { this.data = data; this.width = w; this.height = h; } };
 
 // ---------------------------------------------------------------- helpers
 const blobs = [];
@@ -83,7 +65,8 @@ function gridTriangles(nx, ny) {
 const RAW_LIMIT = 200 * 1024;          // outputs up to this many bytes are stored raw, larger ones as sha256 only
 
 (async () => {
-const M = await import(pathToFileURL(path.join(tmp, 'Homography.js')).href);
+const REFERENCE = await loadReference();               // the reference itself, through the three shims of SURVEY.md Appendix B
+const M = REFERENCE.M;
 const { Homography } = M;
 
 // ---------------------------------------------------------------- run one API script on the reference
@@ -92,62 +75,101 @@ function runCase(c) {
     for (const [k, v] of Object.entries(c.images || {})) images[k] = v.solid ? solidImage(v.w, v.h) : lcgImage(v.w, v.h, v.seed);
     globalThis.__TRI__ = () => Uint32Array.from(c.triangles || []);
     let H = null;
-    const warps = [];
+    const warps = [], css = [], throws = {}, opWarps = {};      // opWarps[opIndex] = [first warp record, count] of a warp / warpBatch op
     let chosen = null;
+    // What the reference's two piecewise caches were computed FROM (SURVEY.md Appendix A-Q12), tracked by wrapping the methods that
+    // fill them: mapDef <-> _trianglesCorrespondencesMatrix (:817-832 forward / :845-861 inverse), pmDef <-> _piecewiseMatrices (:785-804).
+    let mapDef = null, pmDef = null, entryMap = null, entryPm = null;
+    const f32c = (p) => Float32Array.from(p), u32c = (t) => Uint32Array.from(t);
+    const samePts = (a, b) => a.length === b.length && a.every((v, i) => v === b[i] || (v !== v && b[i] !== b[i]));
+    const sameTris = (a, b) => a.length === b.length && a.every((v, i) => v === b[i]);
     const img = (k) => (k === null || k === undefined) ? null : images[k];
-    const pts = (p) => (p && p.f32) ? Float32Array.from(p.f32) : p;       // {f32:[...]} => typed array input (aliased+mutated by the reference)
-    for (const op of c.script) {
+    const pts = (p) => (p && p.f32) ? Float32Array.from(p.f32) : (p && p.undef) ? undefined : p;       // {f32:[...]} => typed array input (aliased+mutated by the reference); {undef} => undefined
+    const errRepr = (e) => (typeof e === 'string' ? 'S:' + e : (e && e.constructor ? e.constructor.name : String(e)));
+    function oneWarp(a0, a1) {
+        chosen = null;
+        const t0 = process.hrtime.bigint();
+        const out = H.warp(img(a0), false, !!a1);
+        const ms = Number(process.hrtime.bigint() - t0) / 1e6;
+        const rec = { path: chosen, ref_ms: +ms.toFixed(3), transform: H.transform,
+            W: H._width, H: H._height, objW: H._objectiveWidth, objH: H._objectiveHeight,
+            xOff: H._xOutputOffset, yOff: H._yOutputOffset,
+            srcNorm: H._srcPointsAreNormalized, dstNorm: H._dstPointsAreNormalized,
+            srcPoints: maybeBlob(new Uint32Array(Float32Array.from(H._srcPoints).buffer), 'f32bits'), dstPoints: maybeBlob(new Uint32Array(Float32Array.from(H._dstPoints).buffer), 'f32bits'),
+            out: { w: out.width, h: out.height, sha: sha(out.data) } };
+        if (out.data.length <= RAW_LIMIT || c.raw) rec.out.blob = blob(out.data);
+        if (H.transform === 'piecewiseaffine') {
+            rec.minSrcX = H._minSrcX; rec.minSrcY = H._minSrcY; rec.maxSrcX = H._maxSrcX; rec.maxSrcY = H._maxSrcY;
+            const fwd = new Float32Array(H._piecewiseMatrices.length * 6), inv = new Float32Array(fwd.length);
+            H._piecewiseMatrices.forEach((m, i) => { fwd.set(m, i * 6); inv.set(M.inverseAffineMatrix(m), i * 6); });
+            rec.fwdSha = sha(fwd); rec.invSha = sha(inv);
+            // stale state: the loop read matrices / a map that do NOT belong to the current point sets (Q12).  Recorded explicitly:
+            // the matrices as they stood (fwd blob) and, for the forward loop, the definition of the map the shared field held.
+            const cur = { src: f32c(H._srcPoints), dst: f32c(H._dstPoints), tris: u32c(H._triangles) };
+            const pmCurrent = entryPm !== null && samePts(entryPm.src, cur.src) && samePts(entryPm.dst, cur.dst) && sameTris(entryPm.tris, cur.tris);
+            const forwardLoop = chosen === '_piecewiseAffineWarp';
+            const mapUsual = !forwardLoop || (entryMap !== null && entryMap.kind === 'forward' && samePts(entryMap.pts, cur.src) && sameTris(entryMap.tris, cur.tris) &&
+                                              entryMap.width === H._maxSrcX - H._minSrcX && entryMap.height === H._maxSrcY - H._minSrcY && entryMap.yOff === H._minSrcY);
+            if (!pmCurrent || !mapUsual) {
+                rec.stale = { matrices: !pmCurrent, map: !mapUsual, nMats: H._piecewiseMatrices.length };
+                if (forwardLoop) rec.stale.mapDef = { kind: entryMap.kind, width: entryMap.width, height: entryMap.height, yOff: entryMap.yOff,
+                                                      pts: maybeBlob(new Uint32Array(entryMap.pts.buffer), 'f32bits'), tris: maybeBlob(entryMap.tris, 'u32') };
+            }
+            if (!sameTris(cur.tris, Uint32Array.from(c.triangles || []))) rec.trisNow = maybeBlob(cur.tris, 'u32');   // (setTriangles replaced the case's list)
+            if ((fwd.byteLength <= RAW_LIMIT && !c.shaOnly) || rec.stale) { rec.fwd = blob(fwd); rec.inv = blob(inv); }
+            const map = H._trianglesCorrespondencesMatrix;       // int16; forward or inverse map depending on the path taken (and on what came before)
+            rec.map = { len: map.length, sha: sha(map) };
+            if (map.byteLength <= RAW_LIMIT || c.raw) rec.map.blob = blob(map);
+        } else {
+            rec.matrix = (H.transform === 'affine') ? { f32: f32bits(H._transformMatrix) } : { f64: f64hex(H._transformMatrix) };
+            const invM = M.calculateTransformMatrix(H.transform, H._dstPoints, H._srcPoints);
+            rec.invMatrix = (H.transform === 'affine') ? { f32: f32bits(invM) } : { f64: f64hex(invM) };
+        }
+        // N_hit: pixels that copied a source pixel = alpha 255 when the same call runs on an all-255 image
+        if (c.nhit !== false && !rec.stale) {
+            const key = a0 !== null && a0 !== undefined ? a0 : c.lastImage;
+            const spec = c.images[key];
+            const keep = H._image;
+            H._image = solidImage(spec.w, spec.h).data;
+            const o2 = H[chosen](H._image);
+            let n = 0; for (let i = 3; i < o2.length; i += 4) if (o2[i] === 255) n++;
+            rec.nhit = n;
+            H._image = keep;
+        }
+        return rec;
+    }
+    for (let opIndex = 0; opIndex < c.script.length; opIndex++) {
+        const op = c.script[opIndex];
         const [name, ...a] = op;
+        const firstWarp = warps.length;
+        try {
         if (name === 'new') {
             H = new Homography(...a);
             for (const w of ['_geometricWarp', '_piecewiseAffineWarp', '_inverseGeometricWarp', '_inversePiecewiseAffineWarp']) {
                 const orig = H[w].bind(H);
-                H[w] = (im) => { chosen = w; return orig(im); };
+                H[w] = (im) => { chosen = w; entryMap = mapDef; entryPm = pmDef; return orig(im); };
             }
+            const after = (m, fn) => { const orig = H[m].bind(H); H[m] = (...x) => { const r = orig(...x); fn(); return r; }; };
+            after('_buildTrianglesCorrespondencesMatrix', () => { mapDef = { kind: 'forward', pts: f32c(H._srcPoints), tris: u32c(H._triangles), width: H._maxSrcX - H._minSrcX, height: H._maxSrcY - H._minSrcY, yOff: H._minSrcY }; });
+            after('_buildInverseTrianglesCorrespondencesMatrix', () => { mapDef = { kind: 'inverse', pts: f32c(H._dstPoints), tris: u32c(H._triangles), width: H._objectiveWidth, height: H._objectiveHeight, yOff: H._yOutputOffset }; });
+            after('_calculatePiecewiseAffineTransformMatrices', () => { pmDef = { src: f32c(H._srcPoints), dst: f32c(H._dstPoints), tris: u32c(H._triangles) }; });
         } else if (name === 'setSourcePoints') H.setSourcePoints(pts(a[0]), img(a[1]), a[2] === undefined ? null : a[2], a[3] === undefined ? null : a[3], a[4] === undefined ? null : a[4]);
         else if (name === 'setDestinyPoints') H.setDestinyPoints(pts(a[0]), a[1] === undefined ? null : a[1]);
         else if (name === 'setReferencePoints') H.setReferencePoints(pts(a[0]), pts(a[1]), img(a[2]), a[3] === undefined ? null : a[3], a[4] === undefined ? null : a[4], a[5] === undefined ? null : a[5], a[6] === undefined ? null : a[6]);
         else if (name === 'setImage') H.setImage(img(a[0]), a[1] === undefined ? null : a[1], a[2] === undefined ? null : a[2]);
         else if (name === 'setTriangles') H.setTriangles(Uint32Array.from(a[0]));
-        else if (name === 'warp') {
-            chosen = null;
-            const t0 = process.hrtime.bigint();
-            const out = H.warp(img(a[0]), false, !!a[1]);
-            const ms = Number(process.hrtime.bigint() - t0) / 1e6;
-            const rec = { path: chosen, ref_ms: +ms.toFixed(3), transform: H.transform,
-                W: H._width, H: H._height, objW: H._objectiveWidth, objH: H._objectiveHeight,
-                xOff: H._xOutputOffset, yOff: H._yOutputOffset,
-                srcNorm: H._srcPointsAreNormalized, dstNorm: H._dstPointsAreNormalized,
-                srcPoints: maybeBlob(new Uint32Array(Float32Array.from(H._srcPoints).buffer), 'f32bits'), dstPoints: maybeBlob(new Uint32Array(Float32Array.from(H._dstPoints).buffer), 'f32bits'),
-                out: { w: out.width, h: out.height, sha: sha(out.data) } };
-            if (out.data.length <= RAW_LIMIT || c.raw) rec.out.blob = blob(out.data);
-            if (H.transform === 'piecewiseaffine') {
-                rec.minSrcX = H._minSrcX; rec.minSrcY = H._minSrcY; rec.maxSrcX = H._maxSrcX; rec.maxSrcY = H._maxSrcY;
-                const fwd = new Float32Array(H._piecewiseMatrices.length * 6), inv = new Float32Array(fwd.length);
-                H._piecewiseMatrices.forEach((m, i) => { fwd.set(m, i * 6); inv.set(M.inverseAffineMatrix(m), i * 6); });
-                rec.fwdSha = sha(fwd); rec.invSha = sha(inv);
-                if (fwd.byteLength <= RAW_LIMIT && !c.shaOnly) { rec.fwd = blob(fwd); rec.inv = blob(inv); }
-                const map = H._trianglesCorrespondencesMatrix;       // int16; forward or inverse map depending on the path taken
-                rec.map = { len: map.length, sha: sha(map) };
-                if (map.byteLength <= RAW_LIMIT || c.raw) rec.map.blob = blob(map);
-            } else {
-                rec.matrix = (H.transform === 'affine') ? { f32: f32bits(H._transformMatrix) } : { f64: f64hex(H._transformMatrix) };
-                const invM = M.calculateTransformMatrix(H.transform, H._dstPoints, H._srcPoints);
-                rec.invMatrix = (H.transform === 'affine') ? { f32: f32bits(invM) } : { f64: f64hex(invM) };
-            }
-            // N_hit: pixels that copied a source pixel = alpha 255 when the same call runs on an all-255 image
-            if (c.nhit !== false) {
-                const key = a[0] !== null && a[0] !== undefined ? a[0] : c.lastImage;
-                const spec = c.images[key];
-                const keep = H._image;
-                H._image = solidImage(spec.w, spec.h).data;
-                const o2 = H[chosen](H._image);
-                let n = 0; for (let i = 3; i < o2.length; i += 4) if (o2[i] === 255) n++;
-                rec.nhit = n;
-                H._image = keep;
-            }
-            warps.push(rec);
+        else if (name === 'css') css.push(H.getTransformationMatrixAsCSS(a[0] === undefined ? null : pts(a[0]), a[1] === undefined ? null : pts(a[1]), a[2] === undefined ? null : a[2], a[3] === undefined ? null : a[3]));
+        else if (name === 'warp') warps.push(oneWarp(a[0], a[1]));
+        else if (name === 'warpBatch') {                          // the caller loop the class's warpBatch() stands for (test/benchmark.js:107-110)
+            for (const d of a[0]) { H.setDestinyPoints(pts(d)); warps.push({ ...oneWarp(null, a[1]), batch: opIndex }); }
         } else throw new Error('bad op ' + name);
+        } catch (e) {
+            if (e instanceof Error && /^bad op/.test(e.message)) throw e;
+            throws[opIndex] = errRepr(e);                         // bare strings are part of the API (throw("...")); Error classes by name
+            if (name === 'warp') warps.push({ throws: throws[opIndex] });
+            if (typeof e !== 'string') { opWarps[opIndex] = [firstWarp, warps.length - firstWarp]; break; }     // an Error out of the middle of a method: stop the script there
+        }
+        if (name === 'warp' || name === 'warpBatch') opWarps[opIndex] = [firstWarp, warps.length - firstWarp];
         if (['setSourcePoints', 'setReferencePoints', 'setImage'].includes(name)) {
             const k = name === 'setSourcePoints' ? a[1] : name === 'setImage' ? a[0] : a[2];
             if (k !== null && k !== undefined) c.lastImage = k;
@@ -156,9 +178,14 @@ function runCase(c) {
     }
     const { lastImage, ...rest } = c;
     // compact: big point lists in the script become {f64blob:{off,len}, n} (flat x,y doubles); big triangle lists a u32 blob
-    rest.script = c.script.map((op) => op.map((a) => (Array.isArray(a) && a.length > BIG / 2 && Array.isArray(a[0])) ? { f64blob: blob(Float64Array.from(a.flat())), n: a.length } : a));
+    const compactPts = (a) => ((Array.isArray(a) && a.length > BIG / 2 && Array.isArray(a[0]) && typeof a[0][0] === 'number') ? { f64blob: blob(Float64Array.from(a.flat())), n: a.length } : a);
+    rest.script = c.script.map((op) => (op[0] === 'warpBatch' ? [op[0], op[1].map(compactPts), ...op.slice(2)] : op.map(compactPts)));
     if (rest.triangles && rest.triangles.length > BIG) rest.triangles = { u32blob: blob(Uint32Array.from(rest.triangles)), n: rest.triangles.length };
-    return { ...rest, warps };
+    const extra = {};
+    if (css.length) extra.css = css;
+    if (Object.keys(throws).length) extra.throws = throws;
+    if (c.script.some((o) => o[0] === 'warpBatch') || Object.keys(throws).length) extra.opWarps = opWarps;
+    return { ...rest, warps, ...extra };
 }
 
 const cases = [];
@@ -343,6 +370,136 @@ if (FULL) {
     }
 }
 
+// ================================================================= 7. call SEQUENCES over the reference's cached state (SURVEY.md Appendix A-Q12).  Appended after 5c.
+// The shared map field (:819-820 / :847-848) makes a forward piecewise warp that follows an inverse one read the stale INVERSE map (:957);
+// the per-triangle matrices (:769) survive setSourcePoints (once a map exists, :252-255) and setTriangles (:519) until the next
+// setDestinyPoints.  Every warp below records what its loop actually read (`stale`: the matrices as they stood, the map's definition).
+{
+    const W = 96, Hh = 64, nx = 4, ny = 3;
+    const g = cfgSinGrid(W, Hh, nx, ny, 2, 5);
+    const scaled = (sx, sy, ox = 0, oy = 0, k = 5) => cfgSinGrid(W, Hh, nx, ny, 2, k).dst.map(([x, y]) => [x * sx + ox, y * sy + oy]);
+    const I1 = { a: { w: W, h: Hh, seed: 31 }, b: { w: W, h: Hh, seed: 32 } };
+    const head = [['new', 'piecewiseaffine'], ['setSourcePoints', g.src, 'a', W, Hh, false]];
+    // inverse (output larger) -> forward (output within [1/1.2, 1] of the source): the forward loop reads the inverse map of the FIRST warp
+    add({ name: 'seq_inverse_then_forward', images: I1, triangles: g.tri, script: [...head,
+          ['setDestinyPoints', scaled(1.3, 1.25, 4, 3), false], ['warp'], ['setDestinyPoints', scaled(0.92, 0.9, 1, 2), false], ['warp'],
+          ['setDestinyPoints', scaled(0.97, 0.88, 0, 0, 7), false], ['warp'], ['warp', 'b']] });
+    // forward (fresh map) -> inverse -> forward (stale) -> inverse again -> forward (stale, the second inverse warp's map)
+    add({ name: 'seq_forward_inverse_forward', images: I1, triangles: g.tri, script: [...head,
+          ['setDestinyPoints', scaled(0.95, 0.93, 2, 1), false], ['warp'], ['setDestinyPoints', scaled(1.4, 1.1, -3, 5), false], ['warp'],
+          ['setDestinyPoints', scaled(0.95, 0.93, 2, 1), false], ['warp'], ['setDestinyPoints', scaled(0.6, 0.7, 8, 2), false], ['warp'],
+          ['setDestinyPoints', scaled(0.9, 0.99, 0, 0), false], ['warp']] });
+    // the video loop (test/benchmark.js:107-110): the output bbox breathes across both thresholds of :421 in both directions
+    {
+        const script = [...head];
+        [0.7, 0.8, 0.86, 0.95, 1.0, 1.08, 1.3, 1.05, 1.0, 0.9, 0.84, 0.8, 0.95].forEach((sc, i) => script.push(['setDestinyPoints', scaled(sc, sc * (i % 2 ? 0.97 : 1), i, 2 * i, 5 + (i % 3)), false], ['warp']));
+        add({ name: 'seq_threshold_loop', images: I1, triangles: g.tri, script });
+    }
+    // the same kind of loop as ONE warpBatch op (what the class's warpBatch() has to equal, frame by frame)
+    add({ name: 'seq_batch_mixed', images: I1, triangles: g.tri, script: [...head,
+          ['warpBatch', [1.25, 0.9, 0.95, 0.7, 1.0, 0.88, 1.1, 0.93].map((sc, i) => scaled(sc, sc, i, i, 5 + (i % 2))), false],
+          ['warpBatch', [0.9, 0.95, 1.0].map((sc, i) => scaled(sc, sc * 0.98, 2, 1, 6 + i)), false],
+          ['warpBatch', [0.9, 1.2, 0.95].map((sc, i) => scaled(sc, sc, 0, 0, 6 + i)), true]] });
+    // stale MATRICES: new source points with a map in place keep the old matrices (:252-255) -- inverse loop, then forward loop
+    const src2 = g.src.map(([x, y]) => [x * 0.9 + 3, y * 0.85 + 4]);
+    add({ name: 'seq_stale_matrices_source', images: I1, triangles: g.tri, script: [...head,
+          ['setDestinyPoints', scaled(1.2, 1.2), false], ['warp'], ['setSourcePoints', src2], ['warp'], ['warp', null, true],
+          ['setDestinyPoints', scaled(0.95, 0.95), false], ['warp'], ['setSourcePoints', g.src], ['warp']] });
+    // stale matrices through setTriangles (:519): reversed order, fewer triangles; then MORE triangles than matrices: the loop throws
+    const T = g.tri.length / 3, rev = [];
+    for (let i = T - 1; i >= 0; i--) rev.push(g.tri[3 * i], g.tri[3 * i + 1], g.tri[3 * i + 2]);
+    add({ name: 'seq_stale_matrices_triangles', images: I1, triangles: g.tri, script: [...head,
+          ['setDestinyPoints', scaled(1.2, 1.15), false], ['warp'], ['setTriangles', rev], ['warp'], ['setDestinyPoints', scaled(1.1, 1.3), false], ['warp'],
+          ['setTriangles', g.tri.slice(0, 3 * (T - 5))], ['warp'], ['setDestinyPoints', scaled(0.93, 0.9), false], ['warp'], ['warp', null, true]] });
+    add({ name: 'seq_more_triangles_than_matrices', images: I1, triangles: g.tri.slice(0, 3 * (T - 4)), nhit: false, script: [['new', 'piecewiseaffine'],
+          ['setSourcePoints', g.src, 'a', W, Hh, false], ['setDestinyPoints', scaled(1.2, 1.2), false], ['warp'], ['setTriangles', g.tri], ['warp']] });
+    // a new source size drops the map (:647): the next forward warp reads a FRESH forward map again
+    add({ name: 'seq_resize_resets_map', images: { ...I1, c: { w: 80, h: 72, seed: 33 } }, triangles: g.tri, script: [...head,
+          ['setDestinyPoints', scaled(1.3, 1.3), false], ['warp'], ['setDestinyPoints', scaled(0.9, 0.9), false], ['warp'],
+          ['setImage', 'c'], ['setDestinyPoints', scaled(0.8, 1.0), false], ['warp'], ['warp', 'a']] });
+    // seeded random sequences (tests/js/seq_scripts.mjs: the generator of the live differential fuzz), piecewise with the grid's own triangles
+    for (let k = 0; k < 32; k++) {
+        const { images, script, grid } = makeScript(seqRng(4200 + k), { transform: 'piecewiseaffine', triangles: (src, gr) => gridTriangles(gr.nx, gr.ny) });
+        add({ name: `seq_fuzz_${k}`, images, triangles: gridTriangles(grid.nx, grid.ny), nhit: false, script });
+    }
+    if (FULL) {                                                 // full size: C3's mesh, inverse frame then a forward frame over its stale map
+        const big = (sx, sy, k) => cfgSinGrid(3840, 2160, 10, 10, 40, k).dst.map(([x, y]) => [x * sx, y * sy]);
+        const c = cfgSinGrid(3840, 2160, 10, 10, 40, 8);
+        add({ name: 'seq_inverse_then_forward_4k', images: { a: { w: 3840, h: 2160, seed: 1 } }, triangles: c.tri, shaOnly: true, script: [['new', 'piecewiseaffine'],
+              ['setSourcePoints', c.src, 'a', 3840, 2160, false], ['setDestinyPoints', big(1, 1, 8), false], ['warp'], ['setDestinyPoints', big(0.95, 0.9, 9), false], ['warp']] });
+    }
+}
+
+// ================================================================= 8. the README benchmark grid (README.md:270-328 <- test/benchmark.js:50-113, :125-190): 2 / 400-ish / ~23 000
+// triangles x 200^2 / 400^2 / 800^2 outputs of a 400 x 400 source, points and call order as the benchmark's (typed-array destiny sets, first
+// frame + loop frames).  Row-major grid triangles are injected in place of Delaunator.  Covers the inverse row-list regime 8192 < T <= 32767
+// and the FORWARD dispatch of the 400^2 -> 400^2 rows (:421).
+{
+    const w = 400, h = 400;
+    const nFaces = (name, pointsInX, pointsInY, outW, outH) => {
+        const src = [], amplitude = 20, frame = (i) => { const d = [];
+            for (let y = amplitude; y <= h - amplitude; y += h / pointsInY) for (let x = 0; x <= w; x += w / pointsInX) d.push([x * (outW / w), (y + Math.sin((x * ((i % 1) + 8)) / Math.PI) * amplitude) * (outH / h)]);
+            return d; };
+        let rows = 0, cols = 0;
+        for (let y = amplitude; y <= h - amplitude; y += h / pointsInY) { rows++; cols = 0; for (let x = 0; x <= w; x += w / pointsInX) { cols++; src.push([x, y]); } }
+        const dst0 = src.map(([x, y]) => [x * (outW / w), (y + Math.sin((x * 8) / Math.PI) * amplitude) * (outH / h)]);
+        add({ name, images: { a: { w, h, seed: 41 } }, triangles: gridTriangles(cols - 1, rows - 1), shaOnly: true, nhit: false, script: [['new', 'piecewiseaffine'],
+              ['setSourcePoints', src, 'a', w, h, false], ['setDestinyPoints', dst0, false], ['warp'],
+              ['setDestinyPoints', { f32: frame(0).flat() }, false], ['warp'], ['setDestinyPoints', { f32: frame(1).flat() }, false], ['warp']] });
+    };
+    const twoFaces = (name, outW, outH) => {
+        const sq = [[0, 0], [0, h], [w, 0], [w, h]], d0 = [[outW / 4, outH / 4], [0, outH / 2], [outW, 0], [outW * 5 / 8, outH * 6 / 8]];
+        const mv = [[0, 0], [0, -(outH * 1 / 4) / 25], [0, 0], [(outW * 3 / 8) / 25, 0]];
+        const frame = (i) => d0.map(([x, y], p) => [x + mv[p][0] * (i % 25), y + mv[p][1] * (i % 25)]).flat();
+        add({ name, images: { a: { w, h, seed: 41 } }, triangles: T4, shaOnly: true, nhit: false, script: [['new', 'piecewiseaffine'],
+              ['setSourcePoints', sq, 'a', w, h, false], ['setDestinyPoints', d0, false], ['warp'],
+              ['setDestinyPoints', { f32: frame(0) }, false], ['warp'], ['setDestinyPoints', { f32: frame(7) }, false], ['warp'], ['setDestinyPoints', { f32: frame(24) }, false], ['warp']] });
+    };
+    for (const [tag, ow, oh] of [['400', w, h], ['200', w / 2, h / 2], ['800', w * 2, h * 2]]) {
+        twoFaces(`readme_2tri_to_${tag}`, ow, oh);
+        nFaces(`readme_20x10_to_${tag}`, 20, 10, ow, oh);
+        nFaces(`readme_160x80_to_${tag}`, 160, 80, ow, oh);
+    }
+}
+
+// ================================================================= 9. getTransformationMatrixAsCSS :548-587 and the API's bare-string errors, from the reference
+{
+    const I9 = { a: { w: 120, h: 90, seed: 51 } };
+    const a3 = [[0, 0], [0, 90], [120, 0]], a3d = [[10, 5], [-20, 130], [150.5, -7.25]], n3 = [[0, 0], [0, 1], [1, 0]], n3d = [[0.1, 0.05], [0.3, 0.95], [0.8, 0.2]];
+    const p4 = [[0, 0], [0, 90], [120, 0], [120, 90]], p4d = [[12, 3], [5, 101.5], [131, -4], [140, 120]], n4 = [[0, 0], [0, 1], [1, 0], [1, 1]], n4d = [[0.1, 0], [0.1, 1], [1, 0.25], [1, 0.75]];
+    // affine: pixel inputs, normalised inputs, points passed to the call, width / height passed to the call, typed arrays
+    add({ name: 'css_affine', images: I9, nhit: false, script: [['new', 'affine'], ['setSourcePoints', a3], ['setDestinyPoints', a3d], ['css'],
+          ['css', n3, n3d], ['css', null, a3], ['css', a3, a3d, 120, 90], ['css', n3, n3d, 120, 90], ['css', { f32: a3.flat() }, { f32: a3d.flat() }],
+          ['setSourcePoints', a3, 'a'], ['setDestinyPoints', a3d], ['css'], ['css', n3, null]] });
+    add({ name: 'css_projective', images: I9, nhit: false, script: [['new', 'projective'], ['setSourcePoints', p4], ['setDestinyPoints', p4d], ['css'],
+          ['css', n4, n4d], ['css', n4, n4d, 120, 90], ['css', p4, p4d, 120, 90], ['css', null, p4], ['css', { f32: n4.flat() }, { f32: n4d.flat() }, 400, 400],
+          ['setReferencePoints', n4, n4d, 'a'], ['css'], ['css', null, p4d]] });
+    add({ name: 'css_auto', images: I9, nhit: false, script: [['new'], ['css', a3, a3d], ['css', p4, p4d], ['css', n4, n4d, 64, 48], ['css', n3, n3d]] });
+    // every bare string the API throws on this path (:175, :342, :413, :556-558, :584, :720, :750, :889, :1247, :1451-1474)
+    const g = cfgSinGrid(120, 90, 2, 2, 2, 5), ng = g.src.map(([x, y]) => [x / 120, y / 90]);
+    add({ name: 'errors_bare_strings', images: I9, triangles: g.tri, nhit: false, script: [
+          ['new', 'piecewiseaffine'], ['warp'],                                                        // :413
+          ['setSourcePoints', g.src], ['setDestinyPoints', g.dst.slice(0, 5)],                         // :342
+          ['css'],                                                                                     // :557
+          ['setDestinyPoints', g.dst], ['css'],                                                        // :558 (piecewise: no matrix)
+          ['new', 'affine'], ['css'],                                                                  // :556
+          ['setSourcePoints', a3.slice(0, 2)],                                                         // :1463
+          ['setSourcePoints', p4],                                                                     // :1463
+          ['new', 'projective'], ['setSourcePoints', a3],                                              // :1469
+          ['new', 'piecewiseaffine'], ['setSourcePoints', a3.slice(0, 2)],                             // :1457
+          ['new', 'auto'], ['setSourcePoints', a3.slice(0, 2)],                                        // :1451
+          ['new', 'perspective'], ['setSourcePoints', a3],                                             // :1474
+          ['new', 'affine'], ['setSourcePoints', n3], ['setDestinyPoints', a3d],                       // :889 (ranges cannot be aligned without a size)
+          ['new', 'piecewiseaffine'], ['setSourcePoints', ng], ['setDestinyPoints', ng], ['setImage', 'a'], ['warp'],
+          ['new', 'piecewiseaffine'], ['setDestinyPoints', g.dst], ['setTriangles', g.tri], ['setImage', 'a'],
+          ['new', 'piecewiseaffine'], ['setSourcePoints', ng], ['setTriangles', g.tri],
+          ['new', 'piecewiseaffine', 120, 90], ['setDestinyPoints', ng], ['setSourcePoints', ng], ['warp', 'a'],
+          ['new'], ['setReferencePoints', { undef: true }, a3],                                              // :175
+          ['new', 'projective'], ['setReferencePoints', n4, p4d], ['css'], ['setImage', 'a'], ['warp'],
+          ['new', 'affine'], ['setReferencePoints', a3, n3d], ['setImage', 'a'], ['css'], ['warp'],
+    ] });
+}
+
 // ================================================================= 6. per-function vectors
 const func = { affine: [], inv_affine: [], projective: [], round: [], fill: [], limits: [], minmax: [] };
 {
@@ -396,8 +553,9 @@ const func = { affine: [], inv_affine: [], projective: [], round: [], fill: [], 
 const meta = { generator: 'tests/golden/gen_golden.mjs', reference: 'Eric-Canas/Homography.js v1.8.0 (package.json)', node: process.version,
                note: 'inputs are synthetic (LCG RGBA); triangles are injected in place of delaunator@5.0.0 (source absent => triangulation parity unpinned)',
                image_lcg: 's = s*1664525 + 1013904223 mod 2^32; byte = s >>> 24; seed per image' };
-fs.writeFileSync(path.join(HERE, 'golden.json'), JSON.stringify({ meta, cases, func }));
-fs.writeFileSync(path.join(HERE, 'golden_blobs.bin'), Buffer.concat(blobs));
+const OUT = process.env.HG_GOLDEN_OUT || HERE;             // (HG_GOLDEN_OUT: a scratch directory for trial runs)
+fs.writeFileSync(path.join(OUT, 'golden.json'), JSON.stringify({ meta, cases, func }));
+fs.writeFileSync(path.join(OUT, 'golden_blobs.bin'), Buffer.concat(blobs));
 console.error(`wrote ${cases.length} cases, ${blobOff} blob bytes`);
-fs.rmdirSync(tmp, { recursive: true });
+REFERENCE.cleanup();
 })().catch((e) => { console.error(e); process.exit(1); });

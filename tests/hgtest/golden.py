@@ -102,10 +102,12 @@ def case_triangles(case):
 
 
 def warp_image_key(case, warp_index):
-    """Which image the k-th warp() of the script operated on (same rule as the generator)."""
+    """Which image the k-th warp record of the case operated on (same rule as the generator; a warpBatch op stands for one warp() per
+    destiny set, a throwing warp() still occupies a record)."""
     last = None
     k = -1
-    for op in case["script"]:
+    ow = case.get("opWarps")
+    for i, op in enumerate(case["script"]):
         name, a = op[0], op[1:]
         key = None
         if name == "setSourcePoints" and len(a) > 1:
@@ -118,11 +120,34 @@ def warp_image_key(case, warp_index):
             key = a[0]
         if key is not None:
             last = key
-        if name == "warp":
-            k += 1
-            if k == warp_index:
+        if name in ("warp", "warpBatch"):
+            first, n = ow[str(i)] if ow and str(i) in ow else (k + 1, 1 if name == "warp" else len(a[0]))
+            if first <= warp_index < first + n:
                 return last
+            k = first + n - 1
     raise IndexError(warp_index)
+
+
+def is_pixel_warp(w):
+    """A warp record with pixels to compare: not one whose warp() threw in the reference, nor a blank 1 x 1 frame (:440: no output
+    window yet, e.g. right after setSourcePoints reset it).  Those are checked by the JS replay only."""
+    return "throws" not in w and isinstance(w.get("objW"), (int, float)) and isinstance(w.get("objH"), (int, float)) and w["objW"] * w["objH"] >= 1
+
+
+def _ints(x, dtype):
+    return blob(x, dtype) if isinstance(x, dict) else np.array(x, dtype=dtype)
+
+
+def warp_triangles(case, w):
+    """The triangle list in force at that warp (setTriangles may have replaced the case's own)."""
+    return _ints(w["trisNow"], np.uint32) if "trisNow" in w else case_triangles(case)
+
+
+def stale_map_def(w):
+    """(points f32, triangles u32, width, height, y_off) of the map the shared field held when a forward loop over stale state ran."""
+    d = w["stale"]["mapDef"]
+    # (an inverse map built before any output window existed has width = height = null: `new Int16Array(null * null)` is empty)
+    return f32_from_bits(d["pts"]), _ints(d["tris"], np.uint32), int(d["width"] or 0), int(d["height"] or 0), int(d["yOff"] or 0)
 
 
 def cases(filter_fn=None):

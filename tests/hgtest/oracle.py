@@ -132,6 +132,17 @@ def warp_inverse_piecewise(src_pts, dst_pts, tris, image, min_src_x, min_src_y, 
     return (out, map_, fwd, inv) if taps else out
 
 
+def warp_inverse_piecewise_loop(map16, inv, image, min_src_x, min_src_y, xoff, yoff, objw, objh):
+    """The pixel loop :1042-1056 alone, over a given Int16 map and the INVERSE matrices it indexes ((T, 6) float32)."""
+    image = np.ascontiguousarray(image, np.uint8)
+    H, W = image.shape[:2]
+    inv = np.ascontiguousarray(inv, np.float32)
+    out = np.zeros((max(objh, 0), max(objw, 0), 4), np.uint8)
+    lib().hgo_warp_inverse_piecewise_loop(np.ascontiguousarray(map16, np.int16), inv, inv.size // 6, image, W, H, min_src_x, min_src_y,
+                                          xoff, yoff, objw, objh, out)
+    return out
+
+
 def warp_forward_geometric(kind, m, image, xoff, yoff, objw, objh):
     image = np.ascontiguousarray(image, np.uint8)
     H, W = image.shape[:2]

@@ -58,7 +58,7 @@ def test_xcc_count_comes_from_the_device():
 
 
 def _inverse_warps():
-    return [pytest.param(c["name"], k, id=f"{c['name']}#{k}") for c in GOLD["cases"] for k, w in enumerate(c["warps"])]
+    return [pytest.param(c["name"], k, id=f"{c['name']}#{k}") for c in GOLD["cases"] for k, w in enumerate(c["warps"]) if G.is_pixel_warp(w)]
 
 
 def _nan_eq(a, b):
@@ -72,15 +72,24 @@ def hip_run_warp(ctx, case, k, taps=False):
     ctx.set_image(img)
     geom = (w["xOff"], w["yOff"], w["objW"], w["objH"])
     sp, dp = G.f32_from_bits(w["srcPoints"]), G.f32_from_bits(w["dstPoints"])
+    if w.get("stale"):
+        # the reference's loop read stale caches: the reference-state entry points get the matrices as the
+        # reference held them and, for the forward loop, the definition of the map its shared field held
+        fwd = G.blob(w["fwd"], np.float32).reshape(-1, 6)
+        if w["path"] == "_inversePiecewiseAffineWarp":
+            out = ctx.warp_inverse_piecewise_state(fwd, dp, G.warp_triangles(case, w), w["minSrcX"], w["minSrcY"], geom)
+            return (out, None, None, (None, None), out) if taps else out
+        pts, mtris, mw, mh, myoff = G.stale_map_def(w)
+        return ctx.warp_forward_piecewise_state(fwd, pts, mtris, mw, mh, myoff, w["minSrcX"], w["minSrcY"], w["maxSrcX"], w["maxSrcY"], geom)
     if w["path"] == "_piecewiseAffineWarp":         # forward scatter (what warp() picks when the output is not larger)
-        ctx.piecewise_set_mesh(sp, G.case_triangles(case), w["minSrcX"], w["minSrcY"])
+        ctx.piecewise_set_mesh(sp, G.warp_triangles(case, w), w["minSrcX"], w["minSrcY"])
         return ctx.warp_forward_piecewise(dp, w["maxSrcX"], w["maxSrcY"], geom)
     if w["path"] == "_geometricWarp":
         kind = 0 if w["transform"] == "affine" else 1
         m = G.f32_from_bits(w["matrix"]["f32"]).astype(np.float64) if kind == 0 else G.f64_from_hex(w["matrix"]["f64"])
         return ctx.warp_forward_geometric(kind, m, geom)
     if w["transform"] == "piecewiseaffine":
-        tris = G.case_triangles(case)
+        tris = G.warp_triangles(case, w)
         ctx.piecewise_set_mesh(sp, tris, w["minSrcX"], w["minSrcY"])
         ctx.piecewise_prepare(dp, geom)
         out = ctx.warp_inverse_piecewise()
@@ -105,7 +114,7 @@ def test_hip_matches_reference_golden(ctx, name, k):
         want = G.blob(w["out"]["blob"], np.uint8).reshape(out.shape)
         assert np.array_equal(out, want), f"{np.count_nonzero(np.any(out != want, axis=2))} pixels differ"
     assert G.sha256(out) == w["out"]["sha"]
-    if pw:
+    if pw and not w.get("stale"):
         _, map_k, map_f, (fwd, inv), out_map = res
         assert np.array_equal(out_map, out)                       # materialised-map path == fused path
         assert G.sha256(map_k) == w["map"]["sha"]                 # rasteriser kernel == reference Int16Array, bit-exact

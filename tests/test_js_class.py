@@ -33,9 +33,21 @@ def _node(script, *args, timeout=900, env=None):
 
 @needs_js
 def test_state_machine_replay_matches_reference():
-    rc, res = _node("replay_golden.mjs", "--dry")
+    """Every golden script -- incl. the call sequences over the reference's stale caches, warpBatch against
+    the reference's loop, the CSS strings and every bare-string error -- replayed on the class with its device calls answered by the
+    JavaScript oracle (tests/js/mock_addon.cjs): the class's state machine and what it asks the native layer for, pixel for pixel."""
+    rc, res = _node("replay_golden.mjs", "--dry", timeout=900)
     assert res["failures"] == [] and rc == 0
-    assert res["cases"] >= 78 and res["warps"] >= 83
+    assert res["cases"] >= 144 and res["warps"] >= 340 and res["staleStateWarps"] >= 40 and res["expectedThrows"] >= 30 and res["cssStrings"] >= 20
+
+
+@needs_js
+@pytest.mark.skipif(not os.path.exists("/root/reference/Homography.js"), reason="the live reference exists only in the build container")
+def test_random_call_sequences_against_the_live_reference():
+    """Differential fuzz: random call sequences on the reference's own Homography.js and on the class (over the mock addon), op by op."""
+    rc, res = _node("fuzz_ref_sequences.mjs", "250", "11", timeout=900)
+    assert res["failures"] == [] and rc == 0
+    assert res["warps"] >= 800 and res["stateCalls"] >= 50
 
 
 @needs_js
@@ -80,7 +92,7 @@ def test_full_replay_on_gpu_matches_reference_hashes():
     _require_js_on_gpu()
     rc, res = _node("replay_golden.mjs", timeout=1500)
     assert res["failures"] == [] and rc == 0
-    assert res["mode"] == "gpu" and res["warps"] >= 83
+    assert res["mode"] == "gpu" and res["warps"] >= 340 and res["staleStateWarps"] >= 40
 
 
 @pytest.mark.gpu

@@ -91,6 +91,8 @@ def _warp_params():
     ps = []
     for c in GOLD["cases"]:
         for k, w in enumerate(c["warps"]):
+            if not G.is_pixel_warp(w):              # the reference's warp() threw there, or returned its blank 1 x 1 frame (JS replay)
+                continue
             marks = [pytest.mark.slow] if c["name"] in SLOW else []
             ps.append(pytest.param(c["name"], k, id=f"{c['name']}#{k}", marks=marks))
     return ps
@@ -102,9 +104,11 @@ def oracle_run_warp(case, k):
     img = G.case_images(case)[G.warp_image_key(case, k)]
     assert img.shape[1] == w["W"] and img.shape[0] == w["H"]
     path = w["path"]
+    if w["transform"] == "piecewiseaffine" and w.get("stale"):
+        return oracle_run_stale_warp(case, w, img)
     if w["transform"] == "piecewiseaffine":
         sp, dp = G.f32_from_bits(w["srcPoints"]), G.f32_from_bits(w["dstPoints"])
-        tris = G.case_triangles(case)
+        tris = G.warp_triangles(case, w)
         if path == "_inversePiecewiseAffineWarp":
             return O.warp_inverse_piecewise(sp, dp, tris, img, w["minSrcX"], w["minSrcY"], w["xOff"], w["yOff"], w["objW"], w["objH"], taps=True)
         fwd = O.piecewise_matrices(sp, dp, tris)
@@ -122,6 +126,37 @@ def oracle_run_warp(case, k):
         return O.warp_inverse_geometric(kind, m, img, w["xOff"], w["yOff"], w["objW"], w["objH"]), None, None, None
     m = G.f32_from_bits(w["matrix"]["f32"]).astype(np.float64) if kind == 0 else G.f64_from_hex(w["matrix"]["f64"])
     return O.warp_forward_geometric(kind, m, img, w["xOff"], w["yOff"], w["objW"], w["objH"]), None, None, None
+
+
+def stale_effective_map(w):
+    """What _piecewiseAffineWarp :957 reads when the shared field holds something else than the forward map of the current mesh
+    (SURVEY.md Appendix A-Q12): the stale map rasterised from ITS point set with ITS geometry, indexed (maxSrcX - minSrcX) cells per
+    row; cells past its end are `undefined` (-1 here).  Returns (the map as the reference held it, the cells the loop can index)."""
+    pts, mtris, mw, mh, myoff = G.stale_map_def(w)
+    own = mw * mh if mw > 0 and mh > 0 else 0
+    held = O.build_tri_map(pts, mtris, mw, myoff, own)
+    cells = max(w["maxSrcX"] - w["minSrcX"], 0) * max(w["maxSrcY"] - w["minSrcY"], 0)
+    eff = np.full(max(cells, 1), -1, np.int16)
+    eff[:min(own, cells)] = held[:min(own, cells)]
+    return held, eff
+
+
+def oracle_run_stale_warp(case, w, img):
+    """A warp whose loop read stale caches: the matrices as the reference held them (`fwd` blob) and, for the forward loop, the map the
+    shared field held -- composed from the oracle's own pieces (rasteriser, inverseAffineMatrix, the two loops)."""
+    fwd = G.blob(w["fwd"], np.float32).reshape(-1, 6)
+    assert fwd.shape[0] == w["stale"]["nMats"]
+    if w["path"] == "_inversePiecewiseAffineWarp":
+        dp, tris = G.f32_from_bits(w["dstPoints"]), G.warp_triangles(case, w)
+        n = w["objW"] * w["objH"]
+        map_ = O.build_tri_map(dp, tris, w["objW"], w["yOff"], n)
+        assert map_.max(initial=-1) < fwd.shape[0]
+        inv = np.stack([O.inverse_affine(m) for m in fwd]) if len(fwd) else np.zeros((0, 6), np.float32)
+        out = O.warp_inverse_piecewise_loop(map_, inv, img, w["minSrcX"], w["minSrcY"], w["xOff"], w["yOff"], w["objW"], w["objH"])
+        return out, map_, fwd, inv
+    held, eff = stale_effective_map(w)
+    out = O.warp_forward_piecewise(eff, fwd, img, w["minSrcX"], w["minSrcY"], w["maxSrcX"], w["maxSrcY"], w["xOff"], w["yOff"], w["objW"], w["objH"])
+    return out, held, fwd, None
 
 
 @pytest.mark.parametrize("name,k", _warp_params())
