@@ -256,7 +256,7 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
             FwdPwTiles p;
             p.fmap = c->d_fmap; p.fwd = c->d_fwd; p.bbox = c->d_fbbox; p.frames = c->d_pw_frames; p.rowext = c->d_frowext; p.rowoff = c->d_frowoff;
             p.tile_cnt = c->d_ftile_cnt; p.tile_ent = c->d_ftile_ent; p.status = c->d_fwd_status + (size_t)c->fwd_slot * c->fwd_status_stride;
-            p.host_flag = (c->h_flag && c->opt_upload_kernel != 0) ? c->h_flag + 1 : nullptr;
+            p.host_flag = c->h_flag ? c->h_flag + 1 : nullptr;
             p.T = c->n_tris; p.min_src_x = c->min_src_x; p.min_src_y = c->min_src_y; p.map_w = (int)map_w; p.map_h = (int)map_h;
             p.tsx = tsx; p.tsy = tsy; p.cap = c->fwd_pw_cap;
             launch_fwd_pw_tiles(p, n, mw, mh, c->d_img, c->n_imgs, c->img_stride, c->W, c->H, static_cast<uint8_t *>(d_out), c->stream);

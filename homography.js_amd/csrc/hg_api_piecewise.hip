@@ -294,7 +294,7 @@ static RowLists rows_of(const hg_ctx *c);
 PwFrames frames_of(const hg_ctx *c)
 {
     PwFrames f;
-    f.host_flag = c->opt_upload_kernel != 0 ? c->h_flag : nullptr;
+    f.host_flag = c->h_flag;                                 // (always armed: whether hg_sync may skip the status ring must not depend on an option that can change while runs are queued)
     f.frames = c->d_pw_frames; f.dst_pts = c->d_dst; f.trir = c->d_trir; f.trix = c->d_trix; f.segs = c->d_segs; f.fwd = c->d_fwd; f.inv = c->d_inv;
     f.status = c->status_ptr ? c->status_ptr : c->d_status; f.n_frames = (int)c->pw_frames.size();
     int mh = 0;
@@ -475,6 +475,10 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         else            launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
     } else {
         HG_TRY(hg_sync(c));                                  // (queued fast-path runs are settled against their own status ring first)
+        // the general path has no row lists, no self-span prologue and no candidate bands: frames_of() must not hand k_tri_setup the
+        // band buffers an earlier fast-path set was laid out for (sized for ITS frame count and height), and the next fast-path set
+        // starts from freshly zeroed counters
+        c->pw_self = false; c->pw_bands = false; c->pw_self_patch = false; c->pw_tile = false; c->pw_rows8 = false; c->rows_clean = false;
         c->status_ptr = c->d_status;
         HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * F, c->stream));
         launch_tri_setup(mesh_of(c), frames_of(c), c->stream);
@@ -613,11 +617,12 @@ extern "C" int hg_warp_inverse_piecewise_frames_device(hg_ctx *c, void *d_out)
     run_warp(c, static_cast<uint8_t *>(d_out), nullptr);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());
-    if (c->pw_fast) c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), c->status_slot, c->stage_cur, extent, layout});
+    const uint8_t path = (uint8_t)((c->pw_used_patch ? 1 : 0) | (c->pw_self ? 2 : 0) | (c->pw_self && c->pw_tile && c->pw_last_kernel == 5 ? 4 : 0));
+    if (c->pw_fast) c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), c->status_slot, c->stage_cur, extent, layout, path});
     else {                                                   // general path: one status set, checked right away
         HIP_TRY(c, hipMemcpyAsync(c->h_status, c->status_ptr, sizeof(int32_t) * c->pw_frames.size(), hipMemcpyDeviceToHost, c->stream));
         c->status_base = nullptr;
-        c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), 0, c->stage_cur, extent, layout});
+        c->pw_pending_out.push_back({static_cast<uint8_t *>(d_out), 0, c->stage_cur, extent, layout, 0});
         HG_TRY(hg_sync(c));
     }
     return HG_OK;
@@ -685,26 +690,35 @@ extern "C" int hg_sync(hg_ctx *c)
         // (all queued runs share one layout of the status ring: a set with another frame count settles them before it runs)
         const int st0 = pending.front().stage;
         const size_t F = (st0 >= 0 && c->stage[st0].h) ? (size_t)c->stage[st0].n : c->pw_frames.size();
-        const bool none_flagged = c->status_base && c->h_flag && c->opt_upload_kernel != 0 && *c->h_flag == 0;
+        const bool none_flagged = c->status_base && c->h_flag && *c->h_flag == 0;
         if (c->status_base && !none_flagged) {
             HIP_TRY(c, hipMemcpy(c->h_status, c->status_base, sizeof(int32_t) * F * kStatusRing, hipMemcpyDeviceToHost));
             if (c->h_flag) *c->h_flag = 0;                   // (the GPU is idle here)
         }
+        uint8_t over_paths = 0;                               // paths (Pending::path bits) of the runs that exceeded a kernel LIMIT (not merely irregular input)
         if (!none_flagged) for (size_t i = 0; i < pending.size(); i++)
-            for (size_t f = 0; f < F; f++)
-                if (c->h_status[(size_t)pending[i].slot * F + f] != FRAME_OK) { redo = true; c->pw_redone++; c->pw_last_flag = c->h_status[(size_t)pending[i].slot * F + f]; }
+            for (size_t f = 0; f < F; f++) {
+                const int32_t w = c->h_status[(size_t)pending[i].slot * F + f];
+                if (w == FRAME_OK) continue;
+                redo = true; c->pw_redone++; c->pw_last_flag = w;
+                if (w & FRAME_LDS_OVERFLOW) over_paths |= (uint8_t)(pending[i].path | 8);
+            }
         if (redo)
             HG_TRY(replay_queued(c, pending, [&](size_t) { return (int)F; },
                                  [&](size_t i, int f) { return c->h_status[(size_t)pending[i].slot * F + f] != FRAME_OK; },
                                  [&](size_t i, int f) { return redo_frame_staged(c, pending[i].stage, f, pending[i].out); }));
         if (redo) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (c->pw_used_patch) c->pw_patch_disabled = true;   // (its limits are tighter than k_pw_rows': do not pay the map path again)
-            if (c->pw_fast && c->row_cap < kRowSpanCapDense)      // denser mesh than assumed: larger lists next time
-                c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
+            // A run that exceeded a LIMIT of its kernel teaches the layout policy, by the path THAT run took; a frame that was merely
+            // irregular (NaN / absurd vertices: FRAME_IRREGULAR alone) goes through the map path and teaches nothing.
+            if (over_paths & 8) {
+                if ((over_paths & 1) && !(over_paths & 2)) c->pw_patch_disabled = true;   // k_pw_patch on row lists: its limits are tighter than k_pw_rows'
+                if (c->row_cap < kRowSpanCapDense)                // denser mesh than assumed: larger lists next time
+                    c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
+                if (over_paths & 4) c->pw_tile_disabled = true;  // a tile beyond its limits: k_pw_patch<SELF> for this mesh
+                else if (over_paths & 2) c->pw_self_disabled = true;   // the self-span path: more candidates / spans than its LDS blocks hold -> row lists for this mesh
+            }
             c->layout_age = 1 << 30;                             // ... and a fresh layout estimate for the next frame set
-            if (c->pw_self && c->pw_tile) c->pw_tile_disabled = true;         // a tile beyond its limits: k_pw_patch<SELF> for this mesh
-            else if (c->pw_self) c->pw_self_disabled = true;          // the self-span path flagged: more candidates / spans than its LDS blocks hold -> row lists for this mesh
         }
     }
     if (!c->fwd_pending.empty()) {
@@ -715,7 +729,7 @@ extern "C" int hg_sync(hg_ctx *c)
         pending.swap(c->fwd_pending);
         std::vector<int32_t> st(c->fwd_status_cap);
         // (as above: the status words are read only when a forward tile kernel set its host-visible flag word)
-        const bool none_flagged = c->h_flag && c->opt_upload_kernel != 0 && c->h_flag[1] == 0;
+        const bool none_flagged = c->h_flag && c->h_flag[1] == 0;
         if (!none_flagged) {
             HIP_TRY(c, hipMemcpy(st.data(), c->d_fwd_status, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost));
             if (c->h_flag) c->h_flag[1] = 0;

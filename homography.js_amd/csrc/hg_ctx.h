@@ -89,7 +89,8 @@ struct hg_ctx {
     // stage: which staged frame set (points + windows) the run warped; extent / layout: the bytes it writes from `out` on and a hash of
     // its frames' (offset, size) list -- a later call into the SAME layout supersedes its deferred redos frame by frame, any other
     // overlapping writer settles it first (settle_output_conflicts)
-    struct Pending { uint8_t *out; int slot; int stage; size_t extent; uint64_t layout; };
+    // path: which layout the run took (bit 0 k_pw_patch, bit 1 self-span prologue, bit 2 k_pw_tile): what hg_sync disables when the run exceeded a limit
+    struct Pending { uint8_t *out; int slot; int stage; size_t extent; uint64_t layout; uint8_t path; };
     std::vector<Pending> pw_pending_out;
     // Frame sets arrive through a ring of page-locked staging buffers (FrameDesc[F], then the F x n_pts x 2 destination
     // points): hg_piecewise_set_frames copies the caller's arrays there and queues stream-ordered uploads -- it neither waits
@@ -123,7 +124,7 @@ struct hg_ctx {
     bool pw_self_disabled = false;                             // a run on it flagged a frame (more candidates / spans than its LDS blocks hold): row lists for this mesh
     bool pw_rows8 = false;                                     // ... with 8-row workgroups (k_pw_rows8)
     bool pw_self_patch = false;                                // ... through k_pw_patch (dense / sheared meshes, one source per frame)
-    bool pw_tile = false;                                      // ... through k_pw_tile (sheared meshes: 16 x 512 tiles whose gathers follow the source rows)
+    bool pw_tile = false;                                      // ... through k_pw_tile (8-row x <= 2048-column tiles whose gathers follow the source rows)
     bool pw_tile_disabled = false;                             // a tile exceeded its limits once: k_pw_patch for this mesh
     int opt_tile = -1;                                         // option "tile": 1 whenever k_pw_patch<SELF> would run, 0 never, -1 by policy
     bool pw_bands = false;                                     // ... with candidate bands (meshes too large for every workgroup to scan)

@@ -81,6 +81,7 @@ __device__ __forceinline__ bool tri_setup_one(const PwMesh &mesh, const PwFrames
     return regular;
 }
 
+template <bool BANDS>      // BANDS: also file the triangle under its candidate bands (16 KB of LDS counters: only that instantiation carries them)
 __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
     const FrameDesc fd = fr.frames[f];
     TriRange tr = TriRange{0, 0, 0, 0};
     const bool regular = t < mesh.n_tris && tri_setup_one(mesh, fr, f, t, fd, tr);
-    if (!fr.band_ent) return;                               // (uniform)
+    if constexpr (BANDS) {
 
     // Self-span path, large meshes: the triangle is filed under every band of output rows one of its spans can reach -- rows
     // (y - yOff) + b .. + a for its rows y, and objH further down for spans whose fill() index wrapped (image 1).  Slots are handed
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256) void k_tri_setup(PwMesh mesh, PwFrames fr)
             __syncthreads();
         }
     }
+    }   // BANDS
 }
 
 // ------------------------------------------------------------------------------------------------ k_pw_fused
@@ -892,7 +894,8 @@ void launch_tri_setup(const PwMesh &mesh, const PwFrames &fr, hipStream_t stream
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
     dim3 grid((mesh.n_tris + 255) / 256, fr.n_frames);
-    hipLaunchKernelGGL(k_tri_setup, grid, dim3(256), 0, stream, mesh, fr);
+    if (fr.band_ent) hipLaunchKernelGGL(k_tri_setup<true>, grid, dim3(256), 0, stream, mesh, fr);
+    else             hipLaunchKernelGGL(k_tri_setup<false>, grid, dim3(256), 0, stream, mesh, fr);
 }
 
 void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16_t *map_out, hipStream_t stream)

@@ -128,7 +128,7 @@ constexpr int kPatchMaxW = 8192, kPatchMaxRowSpans = 215, kPatchMaxGroupTris = 2
 // global_records: the variant for up to 511 spans per row whose pixels read their matrix from the tap array instead of LDS
 constexpr int kPatchMaxRowSpansDense = 480;
 void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream);
-// Sheared meshes (self-span path only): tiles of 16 rows x 512 columns whose gathers follow the source rows (hg_k_tile.hip).
+// Sheared meshes (self-span path only): tiles of 8 rows x <= 2048 columns whose gathers follow the source rows (hg_k_tile.hip).
 void launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then

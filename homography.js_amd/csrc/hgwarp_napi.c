@@ -753,6 +753,7 @@ static napi_value fn_warp_inverse_piecewise_batch(napi_env env, napi_callback_in
     if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
     if (h->n_pts == 0 || nd < (size_t)F * 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold frames x mesh points x,y pairs (piecewiseSetMesh first)");
     size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
+    if (!offs) return throw_str(env, "hgwarp: out of memory (frame offsets)");
     size_t total = 0;
     hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
     int rc = HG_OK;
@@ -802,6 +803,7 @@ static napi_value fn_warp_inverse_geometric_batch(napi_env env, napi_callback_in
     if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
     if (nf < (size_t)F * per || nt < (size_t)F * per) return throw_str(env, "hgwarp: point sets must hold frames x points x,y pairs");
     size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
+    if (!offs) return throw_str(env, "hgwarp: out of memory (frame offsets)");
     size_t total = 0;
     hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
     int rc = HG_OK;
@@ -838,6 +840,7 @@ typedef int (*batch_run_fn)(handle_t *h, const hg_geom *geoms, const size_t *off
 static napi_value run_frame_batch(napi_env env, handle_t *h, const int32_t *gv, int F, batch_run_fn run, void *arg, const char *what)
 {
     size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
+    if (!offs) return throw_str(env, "hgwarp: out of memory (frame offsets)");
     size_t total = 0;
     hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
     int rc = HG_OK;

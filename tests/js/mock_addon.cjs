@@ -100,6 +100,12 @@ const mock = {
         for (let k = 0; k < g.length / 4; k++) out.push(core.forwardGeometricLoop(kind, mats.subarray(8 * k, 8 * k + 8), imageOf(c, k), c.W, c.H, g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3]));
         return out;
     },
+    // several devices, one host thread: the frames of a device list are the frames of one device
+    multiCreate: () => mock.create(), multiDestroy: () => {},
+    multiSetImage(m, data, w, h) { mock.setImage(m, data, w, h); },
+    multiSetMesh(m, src, tris, minX, minY) { mock.piecewiseSetMesh(m, src, tris, minX, minY); },
+    multiWarpBatch(m, pts, g, datas, w, h) { if (datas) mock.setImages(m, datas, w, h); return mock.warpInversePiecewiseBatch(m, pts, g); },
+    multiWarpGeometricBatch(m, kind, from, to, g, datas, w, h) { if (datas) mock.setImages(m, datas, w, h); return mock.warpInverseGeometricBatch(m, kind, from, to, g); },
     // frame pool: plain V8 arrays here
     poolPressure: () => false, poolCollected: () => {}, release: () => {}, setPinnedLimit: () => 0, poolStats: () => ({}),
 };

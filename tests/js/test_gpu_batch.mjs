@@ -100,25 +100,39 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
 {   // warpBatch() applies warp()'s dispatch rule per frame (:421-422, :426-427): a MIXED set -- some frames go down the forward
     // (scatter-semantics) loop, some down the inverse one -- equals the plain loop `setDestinyPoints(d); warp()` byte for byte;
     // {inverse: true} equals the loop with applyAlwaysInverse
-    const mh = new Homography('piecewiseaffine');
-    mh.setSourcePoints(src, lcgImage(W, H, 21), W, H, false);
+    // (every run starts from a FRESH instance: a forward frame reads whatever map the previous warps left in the shared field -- SURVEY.md
+    //  Appendix A-Q12 --, so a loop and a batch are only comparable from the same starting state.  The same sets against the REFERENCE's own
+    //  loop: golden cases seq_batch_mixed / seq_fuzz_*, tests/js/replay_golden.mjs.)
+    const fresh = () => { const h = new Homography('piecewiseaffine'); h.setSourcePoints(src, lcgImage(W, H, 21), W, H, false); return h; };
+    let mh = fresh();
     const scales = [0.95, 1.3, 0.9, 1.0, 0.6, 0.97];        // 0.95 / 0.9 / 0.97: not larger, >= input / 1.2 -> forward; 1.3 larger, 0.6 much smaller -> inverse
     const mixed = scales.map((k, f) => src.map(([x, y]) => [x * k + 2 * f, (y + Math.sin((8 * x) / Math.PI) * 3) * (k === 1.0 ? 0.93 : k) + f]));
     const paths = [];
     const loop = mixed.map((d) => { mh.setDestinyPoints(d, false); const o = mh.warp(); paths.push(mh._lastPath); return o; });
     ok(paths.includes('_piecewiseAffineWarp') && paths.includes('_inversePiecewiseAffineWarp'), `mixed set should take both loops, took ${paths}`);
+    mh.close(); mh = fresh();
     const bat = mh.warpBatch(mixed, { pointsAreNormalized: false });
     bat.forEach((b, f) => ok(b.width === loop[f].width && b.height === loop[f].height && sha(b.data) === sha(loop[f].data), `mixed piecewise batch frame ${f} (${paths[f]}) differs from the loop`));
     ok(mh._lastPath === paths[paths.length - 1], 'warpBatch leaves the path of the last frame behind');
+    // the forward frames behind the first inverse one read that frame's stale inverse map: not what a repaired instance computes
+    const rep = new Homography('piecewiseaffine', null, null, { repairStaleMap: true });
+    rep.setSourcePoints(src, lcgImage(W, H, 21), W, H, false);
+    const repaired = rep.warpBatch(mixed, { pointsAreNormalized: false });
+    ok(sha(repaired[0].data) === sha(bat[0].data) && sha(repaired[2].data) !== sha(bat[2].data), 'frame 2 (forward, behind an inverse frame) should show the stale-map quirk, frame 0 not');
+    rep.close();
     const loopInv = mixed.map((d) => { mh.setDestinyPoints(d, false); return mh.warp(null, false, true); });
     mh.warpBatch(mixed, { inverse: true, pointsAreNormalized: false }).forEach((b, f) => ok(sha(b.data) === sha(loopInv[f].data), `{inverse: true} frame ${f} differs from warp(null, false, true)`));
     ok(sha(loopInv[0].data) !== sha(loop[0].data), 'the forward and the inverse loop should differ on a shrunk frame (else this test proves nothing)');
     // ... with one source per frame (the video loop warp(image_f)), forward frames included
     const ims = [lcgImage(W, H, 81), lcgImage(W, H, 82), lcgImage(W, H, 83), lcgImage(W, H, 84)];
+    mh.close(); mh = fresh();
     const vloop = mixed.map((d, f) => { mh.setDestinyPoints(d, false); return mh.warp(ims[f % 4]); });
+    mh.close(); mh = fresh();
     mh.warpBatch(mixed, { images: ims, pointsAreNormalized: false }).forEach((b, f) => ok(sha(b.data) === sha(vloop[f].data), `mixed batch with per-frame sources: frame ${f} (${paths[f]}) differs from warp(image_f)`));
-    for (const devices of [[0], [0, 0, 0]])
+    for (const devices of [[0], [0, 0, 0]]) {
+        mh.close(); mh = fresh();
         mh.warpBatch(mixed, { images: ims, devices, pointsAreNormalized: false }).forEach((b, f) => ok(sha(b.data) === sha(vloop[f].data), `mixed batch over [${devices}]: frame ${f} differs`));
+    }
     // affine: frames of the source's size go forward (:427), the others inverse (:426)
     const im = lcgImage(480, 270, 33);
     const af = new Homography('affine');

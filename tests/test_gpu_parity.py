@@ -1042,6 +1042,96 @@ def test_self_span_path_policy_flags_and_falls_back():
         c.close()
 
 
+def test_general_path_between_two_banded_fast_path_sets():
+    """A context that ran the self-span path WITH candidate bands (a mesh beyond 256 triangles on k_pw_patch<SELF>), then a frame set
+    the fast kernels do not take (source minimum beyond 2^22: k_pw_fused through k_tri_setup alone) with MORE frames and TALLER windows
+    than the band buffers were laid out for, then the banded fast path again: k_tri_setup of the general path must not file triangles
+    into the old band buffers (round-4 advisor finding), and every step equals the oracle."""
+    c = HG.Context(0)
+    try:
+        W, H, nx, ny = 768, 512, 20, 16                         # 640 triangles
+        img = G.lcg_image(W, H, 77)
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        ms = WL.src_min(sp)
+        c.set_image(img)
+        c.set_option("min_row_groups", 0); c.set_option("patch", 1); c.set_option("self_spans", 1)
+
+        def step(F, scale, msx, msy, expect_self):
+            frames = [(WL.sin_dst(sp, 5.0 + f, 8 + (f % 3)).reshape(-1, 2) * np.float32(scale)).astype(np.float32).ravel() for f in range(F)]
+            geoms = [WL.piecewise_geom(d) for d in frames]
+            offs, total = HG.pack_offsets(geoms)
+            d_out = c.alloc(total)
+            try:
+                c.piecewise_set_mesh(sp, tris, msx, msy)
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                assert c.last_piecewise_self() == expect_self, (F, scale, msx, c.last_piecewise_kernel())
+                for f in range(F):
+                    g = geoms[f]
+                    want = O.warp_inverse_piecewise(sp, frames[f], tris, img, msx, msy, *g)
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want), (F, scale, msx, f)
+            finally:
+                c.free(d_out)
+
+        step(2, 1.0, ms[0], ms[1], 1)                           # fast path, candidate bands sized for 2 frames of ~520 rows
+        assert c.last_piecewise_kernel() == 3
+        step(5, 2.5, -(1 << 22) - 8, ms[1], 0)                  # general path: 5 frames of ~1300 rows
+        assert c.last_piecewise_kernel() == 4
+        step(2, 1.0, ms[0], ms[1], 1)                           # and back
+        step(3, 1.7, ms[0], ms[1], 1)
+        assert c.redone_frames() == 0
+    finally:
+        c.close()
+
+
+def test_flag_word_is_armed_whatever_the_upload_option_was_when_the_run_was_queued():
+    """hg_sync skips the status ring when the page-locked flag word is clear: the kernels must set that word for every queued run,
+    also for runs queued while option "upload_kernel" was 0 and synced after it went back to 1 (round-4 advisor finding).  A frame
+    with a NaN vertex is flagged (irregular) and must come back redone = equal to the oracle; and an irregular frame teaches the
+    layout policy nothing: the mesh keeps the self-span path."""
+    c = HG.Context(0)
+    try:
+        W, H, nx, ny, F = 640, 384, 6, 4, 10
+        img = G.lcg_image(W, H, 5)
+        sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+        ms = WL.src_min(sp)
+        frames = [WL.sin_dst(sp, 4.0 + f, 8) for f in range(F)]
+        geoms = [WL.piecewise_geom(d) for d in frames]
+        frames[3] = frames[3].copy(); frames[3][5] = np.nan       # an irregular frame (its window was derived before)
+        offs, total = HG.pack_offsets(geoms)
+        c.set_image(img); c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+        c.set_option("min_row_groups", 0)
+        d_out = c.alloc(total)
+        try:
+            want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(F)]
+
+            def check():
+                for f in range(F):
+                    g = geoms[f]
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), f
+
+            c.set_option("upload_kernel", 0)
+            c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+            c.warp_inverse_piecewise_frames_device(d_out)          # queued, not synced
+            c.set_option("upload_kernel", 1)
+            c.sync()
+            assert c.redone_frames() == 1
+            check()
+            c.set_option("self_spans", 1)
+            for rep in range(2):
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.sync()
+                assert c.last_piecewise_self() == 1, "an irregular frame must not disable the self-span path"
+                check()
+            assert c.redone_frames() == 3
+        finally:
+            c.free(d_out)
+    finally:
+        c.close()
+
+
 def test_fresh_point_sets_queue_without_settling_and_redo_from_their_own_set(ctx):
     """The reference's loop uploads new destination points before every warp (test/benchmark.js:107-110).  Here sets and runs
     are queued back to back with no sync in between, into different outputs; set 1 is a mesh too dense for the row lists (its
