@@ -191,6 +191,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "self_spans")) { c->opt_self = value < 0 ? -1 : (value ? 1 : 0); c->pw_self_disabled = false; }
     else if (!std::strcmp(key, "tri_threads")) c->opt_tri_threads = (value == 64 || value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "tri_group")) c->opt_tri_group = value < 0 ? -1 : (value >= 64 ? 64 : (value ? 16 : 0));
+    else if (!std::strcmp(key, "safe_spans")) c->opt_safe_spans = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "upload_kernel")) c->opt_upload_kernel = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "rows8")) c->opt_rows8 = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "rows1_threads")) c->opt_rows1_threads = (value == 128 || value == 256) ? value : -1;

@@ -337,6 +337,10 @@ PwFrames frames_of(const hg_ctx *c)
     // (self-span path: its instantiations fit 56 VGPRs / 78 SGPRs whatever the phase depth -- 8 workgroups per CU where the list-reading
     //  4-window form admits 7.  Same box, alternating order, 2 -> 4 windows per phase: C3 0.5697 -> 0.5685 ms, C4 0.2220 -> 0.2228, 512-triangle
     //  grid 0.6323 -> 0.6267: a wash to a slight gain, so one depth for every self-span set; EXPERIMENTS.md R4.10)
+    // Span flags "both end pixels inside the source window" (k_pw_rows: windows made of flagged spans skip the per-pixel bounds test).  Same box,
+    // alternating order, off -> on: C3 (1.5 spans per 256-pixel window) 0.562 -> 0.525 ms; C4 (4.5: one flag per span piece in the prologue, few
+    // windows wholly inside flagged spans) 0.217 -> 0.220.  Hence by the host's spans-per-window estimate; option "safe_spans" forces either.
+    f.safe_spans = c->opt_safe_spans >= 0 ? c->opt_safe_spans : (c->pw_spans_per_window < 3.0 ? 1 : 0);
     f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 || c->pw_self ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
     f.patch_blocks = c->opt_phase > 0 ? c->opt_phase : 8;    // (k_pw_patch: measured best in both source layouts, hg_k_patch.hip)
     return f;
@@ -712,7 +716,7 @@ extern "C" int hg_sync(hg_ctx *c)
             // A run that exceeded a LIMIT of its kernel teaches the layout policy, by the path THAT run took; a frame that was merely
             // irregular (NaN / absurd vertices: FRAME_IRREGULAR alone) goes through the map path and teaches nothing.
             if (over_paths & 8) {
-                if ((over_paths & 1) && !(over_paths & 2)) c->pw_patch_disabled = true;   // k_pw_patch on row lists: its limits are tighter than k_pw_rows'
+                if (over_paths & 1) c->pw_patch_disabled = true; // k_pw_patch (row lists or self-spans): its limits are tighter than k_pw_rows'
                 if (c->row_cap < kRowSpanCapDense)                // denser mesh than assumed: larger lists next time
                     c->row_cap = c->row_cap < kRowSpanCapFast ? kRowSpanCapFast : kRowSpanCapDense;
                 if (over_paths & 4) c->pw_tile_disabled = true;  // a tile beyond its limits: k_pw_patch<SELF> for this mesh

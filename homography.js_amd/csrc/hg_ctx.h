@@ -135,6 +135,7 @@ struct hg_ctx {
     int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate
     int opt_tri_group = -1;                                    // k_tri_spans_grouped: 16 / 64 triangles per workgroup, 0 never, -1 by mesh size
     int opt_upload_kernel = -1;                                // frame-set blocks up to 1 MB go up by k_upload (default) instead of hipMemcpyAsync (0)
+    int opt_safe_spans = -1;                                   // option "safe_spans": span flags + bounds-test-free windows in k_pw_rows: 1 / 0, -1 by the spans-per-window estimate
     int opt_rows8 = -1;                                        // k_pw_rows<SELF>: 8 rows per workgroup (1), 4 (0), -1 by policy
     int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
     int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4

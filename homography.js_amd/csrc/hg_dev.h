@@ -167,6 +167,23 @@ __device__ __forceinline__ void round_x4(double h[4], double r[4])
         : "s"(M));
 }
 
+// Math.round of four values KNOWN to lie inside the source window (|v| < 2^30) with ONE add each: r = RTN(v + (1.5 * 2^51 + 0.5)).
+// In [2^51, 2^52) a double's ulp is 0.5, so the constant is exact and r = 1.5 * 2^51 + (v + 0.5 rounded DOWN to the half grid): its low
+// dword holds floor(2 v + 1), and Math.round(v) = floor(v + 0.5) = that >> 1 (arithmetic: negative values floor too).  Used by the
+// pixel loops for windows whose spans are all flagged "wholly in bounds" (no bounds test, so no separate h = RTN(v + 0.5) is needed).
+__device__ __forceinline__ void round_half_x4(const double v[4], int r[4])
+{
+    const double C = 3377699720527872.5;
+    double t0, t1, t2, t3;
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
+        "v_add_f64 %0, %4, %8\n\t" "v_add_f64 %1, %5, %8\n\t" "v_add_f64 %2, %6, %8\n\t" "v_add_f64 %3, %7, %8\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(C));
+    r[0] = __double2loint(t0) >> 1; r[1] = __double2loint(t1) >> 1; r[2] = __double2loint(t2) >> 1; r[3] = __double2loint(t3) >> 1;
+}
+
 // The same for two doubles (the forward tile kernels): a, b become RTN(v + 0.5); ia, ib = Math.round(v) as int32, valid while |v| < 2^31.
 __device__ __forceinline__ void round_x2(double &a, double &b, int &ia, int &ib)
 {
@@ -199,6 +216,22 @@ __device__ __forceinline__ void span_max4(int best[4], int d, int len, int key)
         "v_cmpx_lt_u32_e32 vcc, %[d3], %[len]\n\t" "v_max_i32_e32 %[b3], %[b3], %[key]\n\t" "s_mov_b64 exec, %[sv]"
         : [b0] "+v"(best[0]), [b1] "+v"(best[1]), [b2] "+v"(best[2]), [b3] "+v"(best[3]), [sv] "=&s"(sv)
         : [d0] "v"(d), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [len] "v"(len), [key] "v"(key)
+        : "vcc");
+}
+
+// same with the span's length and key in SCALAR registers (broadcast out of a lane by v_readlane: no LDS round trip per span)
+__device__ __forceinline__ void span_max4s(int best[4], int d, int len, int key)
+{
+    const int d1 = d + 64, d2 = d + 128, d3 = d + 192;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_gt_u32_e32 vcc, %[len], %[d0]\n\t" "v_max_i32_e32 %[b0], %[key], %[b0]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_u32_e32 vcc, %[len], %[d1]\n\t" "v_max_i32_e32 %[b1], %[key], %[b1]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_u32_e32 vcc, %[len], %[d2]\n\t" "v_max_i32_e32 %[b2], %[key], %[b2]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_u32_e32 vcc, %[len], %[d3]\n\t" "v_max_i32_e32 %[b3], %[key], %[b3]\n\t" "s_mov_b64 exec, %[sv]"
+        : [b0] "+v"(best[0]), [b1] "+v"(best[1]), [b2] "+v"(best[2]), [b3] "+v"(best[3]), [sv] "=&s"(sv)
+        : [d0] "v"(d), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [len] "s"(len), [key] "s"(key)
         : "vcc");
 }
 

@@ -487,8 +487,12 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (KS)
     static_assert(CAP >= 64 * RG, "packed mode gives each of the RG rows a 64-slot block");
     static_assert(RG == kRowGroup || (RG == 8 && SELF == 1), "8-row groups exist for the self-span path only");
-    constexpr int KS = CAP * 48 <= (1 << kKeyShift) ? kKeyShift : kKeyShift + 1, KMASK = (1 << KS) - 1;   // id << KS | record offset
+    constexpr int KS = CAP * 48 <= (1 << kKeyShift) ? kKeyShift : kKeyShift + 1, KMASK = (1 << KS) - 1;   // id << KS | record offset | unsafe
     static_assert(CAP * 48 <= (1 << KS) && KS <= 15, "record offsets must fit below the 15-bit id");
+    // Record offsets are multiples of 48: the low four bits of a key are free.  Bit 0 = "unsafe": 0 only when BOTH end pixels of the
+    // span pass the source bounds test :1047 -- then every pixel between them does (sx, sy are monotone in x: one exact product, two
+    // monotone roundings), and a window whose pixels all resolve to such spans runs the pixel body without the bounds test.
+    constexpr int KADDR = KMASK & ~15;
 
     const int W = fd.obj_w;
     const int lane = threadIdx.x & 63;
@@ -532,6 +536,18 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     const HiBounds hb = make_hi_bounds((double)mesh.min_src_x + 0.5, (double)mesh.W + (double)mesh.min_src_x + 0.5,
                                        (double)mesh.min_src_y + 0.5, (double)mesh.H + (double)mesh.min_src_y + 0.5);
     const int pitch4 = mesh.W * 4;
+    // 1 unless both end pixels lo, hi - 1 of a span with record {m0, m2*y, m4, m1, m3*y, m5} are inside the source window, computed as
+    // the pixel body computes them (same fma, same rounding, same compares)
+    const bool flag_spans = fr.safe_spans != 0;             // (wave-uniform; host: by the rows' span density)
+    auto span_unsafe = [&](double m0, double m2y, double m4, double m1, double m3y, double m5, int lo, int hi) -> int {
+        if (!flag_spans) return 1;
+        const double xa = (double)(lo + fd.x_off), xb = (double)(hi - 1 + fd.x_off);
+        double h[4] = { fma(m0, xa, m2y) + m4, fma(m1, xa, m3y) + m5, fma(m0, xb, m2y) + m4, fma(m1, xb, m3y) + m5 }, rd[4];
+        round_x4(h, rd);
+        const bool a = HIB ? hi_inb(hb, h[0], h[1]) : (bool)((int)(h[0] >= bx_lo) & (int)(h[0] < bx_hi) & (int)(h[1] >= by_lo) & (int)(h[1] < by_hi));
+        const bool b = HIB ? hi_inb(hb, h[2], h[3]) : (bool)((int)(h[2] >= bx_lo) & (int)(h[2] < bx_hi) & (int)(h[3] >= by_lo) & (int)(h[3] < by_hi));
+        return (a && b) ? 0 : 1;
+    };
 
     const float *__restrict__ ginv = fr.inv + (size_t)f * mesh.n_tris * kInvStride;
     // row `row` of the group -> LDS slots [base, base + cnt) (+ a NaN record in slot base + nan_slot that pixels without a
@@ -555,7 +571,8 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                 m3 = (double)__uint_as_float(b.y); m4 = (double)__uint_as_float(b.z); m5 = (double)__uint_as_float(b.w);
             }
             const int elo = (int)(lh & 0xffffu), ehi = (int)(lh >> 16);
-            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo; s_key[base + i] = ((int)id << KS) | ((base + i) * 48);
+            s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo;
+            s_key[base + i] = ((int)id << KS) | ((base + i) * 48) | span_unsafe(m0, m2 * y, m4, m1, m3 * y, m5, elo, ehi);
             double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
             mrec[0] = make_double2(m0, m2 * y);              // {m0, m2*y, m4, m1, m3*y, m5}: m2*y and m3*y are the separately
             mrec[1] = make_double2(m4, m1);                  // rounded products of :1383-1384
@@ -687,11 +704,13 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     if (slot >= capr) continue;
                     const int at = (packed ? row * 64 : 0) + slot;
                     const double yr = (double)(r + fd.y_off);
-                    s_lo[at] = lo; s_hi[at] = hi; s_len[at] = hi - lo; s_key[at] = (t << KS) | (at * 48);
+                    const double m2y = (double)ma.z * yr, m3y = (double)ma.w * yr;
+                    s_lo[at] = lo; s_hi[at] = hi; s_len[at] = hi - lo;
+                    s_key[at] = (t << KS) | (at * 48) | span_unsafe((double)ma.x, m2y, (double)mb.x, (double)ma.y, m3y, (double)mb.y, lo, hi);
                     double2 *mrec = reinterpret_cast<double2 *>(s_m + at * 6);
-                    mrec[0] = make_double2((double)ma.x, (double)ma.z * yr);     // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
+                    mrec[0] = make_double2((double)ma.x, m2y);                   // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
                     mrec[1] = make_double2((double)mb.x, (double)ma.y);
-                    mrec[2] = make_double2((double)ma.w * yr, (double)mb.y);
+                    mrec[2] = make_double2(m3y, (double)mb.y);
                 }
             }
         }
@@ -710,7 +729,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // stores per step 4.7 TB/s, 16 + 16 per step 5.7 TB/s) shows what that costs once the source comes from HBM.
     auto do_row = [&](int row, int cnt, int base, int nan_slot, int w0, int wstep) {
         // "no triangle": smaller than every real key, its low bits address the NaN record
-        const int nan_key = (int)0x80000000u | ((base + nan_slot) * 48);
+        const int nan_key = (int)0x80000000u | ((base + nan_slot) * 48) | 1;      // (unsafe: its pixels must come out as offset 0xffffffff)
         const int r = r0 + row;
         const int64_t row_px = (int64_t)r * W;
         // Output row: raw buffer of 4*W bytes, so the ragged last window needs no per-pixel guard (stores past the row
@@ -720,6 +739,12 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         const bool vec_zero = ((W & 3) == 0) && (((fd.out_off + (uint64_t)row_px * 4) & 15) == 0);
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         const v4u zero4 = { 0u, 0u, 0u, 0u };
+        // Rows of up to 64 spans (every row of a packed group): lane i keeps span i in registers for the whole row, and the window loop
+        // takes the spans that reach a window out of those lanes with v_readlane -- no LDS round trip per (window, span), which was a
+        // dependent ds_read + wait in front of every span's four compares (C4: 4.5 spans per window).
+        const bool in_regs = cnt <= 64;                     // wave-uniform
+        int lo_r = 0x7fffffff, hi_r = 0, key_r = 0;
+        if (in_regs && lane < cnt) { lo_r = s_lo[base + lane]; hi_r = s_hi[base + lane]; key_r = s_key[base + lane]; }
         for (int wb = w0; wb < nwin; wb += wstep * PH) {
             uint32_t px[PH][4];
             bool empty[PH];                                 // wave-uniform
@@ -732,7 +757,17 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
 #pragma unroll
                 for (int k = 0; k < 4; k++) best[k] = nan_key;
                 unsigned long long any = 0ull;
-                if (!X::fake_search(best, any, base, w, cnt)) for (int j = 0; j < cnt; j += 64) {
+                if (X::fake_search(best, any, base, w, cnt)) { }
+                else if (in_regs) {
+                    unsigned long long mask = __ballot(lo_r < c0 + 256 && hi_r > c0);
+                    any = mask;
+                    while (mask) {
+                        const int bit = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const int lo = __builtin_amdgcn_readlane(lo_r, bit);
+                        span_max4s(best, cq - lo, __builtin_amdgcn_readlane(hi_r, bit) - lo, __builtin_amdgcn_readlane(key_r, bit));
+                    }
+                } else for (int j = 0; j < cnt; j += 64) {
                     const int idx = j + lane;
                     int lo = 0x7fffffff, hi = 0;
                     if (idx < cnt) { lo = s_lo[base + idx]; hi = s_hi[base + idx]; }
@@ -755,6 +790,29 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     // from 66 to 58 VGPRs (8 waves/SIMD instead of 7; C3 -1.4 %, and the 4-window one from 78 to 66).  With one
                     // window per phase (one source per frame) all four at once measured 2 % faster.
                     constexpr int STEP = PH == 1 ? 4 : 2;
+                    // every pixel of the window resolved to a span whose ends are inside the source window: no bounds test, and Math.round
+                    // with one add per coordinate (round_half_x4)
+                    const bool safe = flag_spans && __ballot(((best[0] | best[1] | best[2] | best[3]) & 1) != 0) == 0ull;      // wave-uniform
+                    if (safe) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk += 2) {
+                            if (kk == 2 && c0 + 128 >= W) { px[p][2] = px[p][3] = 0u; continue; }
+                            double v[4];
+                            int r[4];
+#pragma unroll
+                            for (int k = kk; k < kk + 2; k++) {
+                                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KADDR));
+                                const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+                                const double xd = X::pixel_x(xd0 + (double)(k * 64), c0, lane, k, fd.x_off);
+                                v[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
+                                v[2 * (k - kk) + 1] = X::pixel_hy(fma(m1.y, xd, m2.x) + m2.y, lane);
+                            }
+                            round_half_x4(v, r);
+#pragma unroll
+                            for (int k = kk; k < kk + 2; k++)
+                                px[p][k] = X::gather(src, (uint32_t)(__mul24(r[2 * (k - kk) + 1], pitch4) + (r[2 * (k - kk)] << 2)));     // :1048-1049
+                        }
+                    } else
 #pragma unroll
                     for (int kk = 0; kk < 4; kk += STEP) {
                         // the ragged last window of a row: a pair of 64-pixel pieces wholly past the row end is not computed at all (its
@@ -763,7 +821,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                         double h[2 * STEP], rd[2 * STEP];
 #pragma unroll
                         for (int k = kk; k < kk + STEP; k++) {
-                            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KMASK));
+                            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KADDR));
                             const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
                             const double xd = X::pixel_x(xd0 + (double)(k * 64), c0, lane, k, fd.x_off);
                             // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer

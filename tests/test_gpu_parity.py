@@ -22,12 +22,12 @@ GOLD = G.load()
 # results must not depend on it, so every test that takes `ctx` runs under each layout policy.
 # ("hi_bounds": 0 keeps the fp64 form of the source-bounds tests, "xcc" changes the block id -> row band mapping: both are folded
 #  into the existing layouts so that every kernel runs under either form without multiplying the suite.)
-LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds": 0, "xcc": 4, "self_spans": 0, "tri_group": 1, "compact": 1}, "rows1": {"min_row_groups": 1 << 30, "patch": 0, "xcc": 1, "xcc_rotate": 0, "compact": 0},
+LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds": 0, "xcc": 4, "self_spans": 0, "tri_group": 1, "compact": 1, "safe_spans": 1}, "rows1": {"min_row_groups": 1 << 30, "patch": 0, "xcc": 1, "xcc_rotate": 0, "compact": 0},
            "patch": {"min_row_groups": 0, "patch": 1, "phase": 2, "tri_group": 64}, "patch_global": {"min_row_groups": 0, "patch": 2, "hi_bounds": 0, "xcc": 2},
-           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0, "self_spans": 1},
+           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0, "self_spans": 1, "safe_spans": 0},
            "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16, "self_spans": 0, "xcc_rotate": 1, "tri_group": 0},
            "tile": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 1, "xcc_rotate": 1},
-           "rows8": {"min_row_groups": 0, "patch": 0, "self_spans": 1, "rows8": 1}}
+           "rows8": {"min_row_groups": 0, "patch": 0, "self_spans": 1, "rows8": 1, "safe_spans": 1}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))
@@ -1098,7 +1098,7 @@ def test_flag_word_is_armed_whatever_the_upload_option_was_when_the_run_was_queu
         ms = WL.src_min(sp)
         frames = [WL.sin_dst(sp, 4.0 + f, 8) for f in range(F)]
         geoms = [WL.piecewise_geom(d) for d in frames]
-        frames[3] = frames[3].copy(); frames[3][5] = np.nan       # an irregular frame (its window was derived before)
+        frames[3] = frames[3].copy(); frames[3][4] = np.nan       # an irregular frame: a NaN x over finite rows (its window was derived before)
         offs, total = HG.pack_offsets(geoms)
         c.set_image(img); c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
         c.set_option("min_row_groups", 0)

@@ -36,6 +36,7 @@ for t in range(trials):
     ctx.set_option("self_spans", int(rng.choice([-1, 1, 0])))
     ctx.set_option("tile", int(rng.choice([-1, 1, 1, 0])))
     ctx.set_option("rows8", int(rng.choice([-1, 1, 0])))
+    ctx.set_option("safe_spans", int(rng.choice([-1, 1, 0])))
     if TILE:
         ctx.set_option("self_spans", 1); ctx.set_option("patch", 0 if ROWS else 1); ctx.set_option("min_row_groups", 0)
     ctx.set_option("xcc_rotate", int(rng.choice([-1, 0, 1])))
