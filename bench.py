@@ -126,6 +126,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
     ap.add_argument("--also", default="", help="further configs measured in the same invocation, e.g. C4:64,C5:8 (config:frames per GPU per step); "
                                                "each is reported under \"also\" with the fields of the headline line")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --frames frames per GPU per step, per-GPU work fixed as N grows; strong: a FIXED batch of --batch frames "
+                         "per step split over the N GPUs (north_star: 'batch = 512 / 64 frames sharded over 8 GPUs'), total work fixed")
+    ap.add_argument("--batch", type=int, default=0, help="--scaling strong: frames per step over ALL GPUs (0 = 512 for C4, 64 otherwise)")
     ap.add_argument("--launch-dry-run", action="store_true", help="print the torchrun command --gpus N would re-execute under, and exit")
     args = ap.parse_args()
 
@@ -203,7 +207,11 @@ def measure(args, config, F, env, primary=True):
         ctx.set_image_device(img_t.data_ptr(), W, H)         # (N > 1: attached below, once the broadcast has delivered it)
 
     piecewise = cfg["kind"] in ("piecewise", "face")
-    frame_ids = hgdist.rank_frame_ids(rank, F)              # different ranks get different frames of the same sequence
+    batch = (args.batch or (512 if config == "C4" else 64)) if args.scaling == "strong" else F * world
+    frame_ids = hgdist.job_frame_ids(args.scaling, rank, world, F, batch)     # different ranks get different frames of the same sequence
+    F = len(frame_ids)                                       # (strong scaling: block sizes differ by at most one between ranks)
+    if F == 0:
+        raise SystemExit(f"bench.py: --batch {batch} leaves rank {rank} of {world} without a frame")
     if piecewise:
         if cfg["kind"] == "face":
             sp = wl.face_mesh(W, H, cfg["landmarks"])
@@ -226,7 +234,7 @@ def measure(args, config, F, env, primary=True):
         ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
         run_resident = ctx.warp_inverse_piecewise_frames_device
         workload = (f"{config}: {W}x{H} RGBA piecewise-affine, {mesh_txt} "
-                    f"({tris.size // 3} triangles), {F} frames/GPU/step")
+                    f"({tris.size // 3} triangles), " + (f"{batch} frames/step over {world} GPU(s)" if args.scaling == "strong" else f"{F} frames/GPU/step"))
     else:
         s4 = wl.corners(W, H)
         d4s = [wl.projective_dst(W, H, 0.0125 * (i % 10)) for i in frame_ids]
@@ -241,7 +249,8 @@ def measure(args, config, F, env, primary=True):
         ctx.geometric_set_frames_points(1, np.concatenate(d4s), np.tile(s4, F), geoms, offs)     # inverse: dst -> src (:994)
         solve_txt = ", 8x8 DLT solve per frame on the device inside the step"
         run_resident = ctx.warp_inverse_geometric_frames_device
-        workload = f"{config}: {W}x{H} RGBA projective, 4 corner points, {F} frames/GPU/step{solve_txt}"
+        workload = (f"{config}: {W}x{H} RGBA projective, 4 corner points, " +
+                    (f"{batch} frames/step over {world} GPU(s)" if args.scaling == "strong" else f"{F} frames/GPU/step") + solve_txt)
 
     run = run_resident
     # --points fresh: a ring of R point sets (the config's own sequence shifted by k frames), one uploaded per timed step
@@ -574,12 +583,21 @@ def measure(args, config, F, env, primary=True):
                     cpu["node"] = {"error": str(e)[:200]}
 
     step_ms_by_rank = [round(e * 1e3 / args.steps, 5) for e in region_stats[0]["elapsed_s_by_rank"]] if region_stats else None
+    # who ran what: every rank's device and block of frames (a heterogeneous or partitioned node, or a mis-sharded batch, shows here)
+    props = torch.cuda.get_device_properties(dev)
+    ranks = hgdist.gather_rank_info(dist, world, {"rank": rank, "device": local_rank, "device_name": props.name, "xcc": ctx.xcc_count(),
+                                                 "cus": props.multi_processor_count, "frames": F, "first_frame": frame_ids[0], "pixels_per_step": int(px_per_step)})
+    e2e_ms, e2e_value = hgdist.end_to_end(ms_per_step, broadcast_ms, px_all)
     line = {"metric": "Mpixels/s warped (piecewise-affine, 4K RGBA)" if config == "C3" else f"Mpixels/s warped ({config})",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8 pixels / f64 coordinates", "data": "synthetic",
             "config": {"workload": workload + (" on a shared source" if primary_src == "shared" else ", one source per frame"),
-                       "frames_per_gpu_per_step": F, "point_sets": pts_txt,
+                       "frames_per_gpu_per_step": F if args.scaling == "weak" else None, "frames_per_step_all_gpus": batch, "point_sets": pts_txt,
+                       "rccl_world": world, "ranks": ranks,
+                       "source_fanout": None if world == 1 else f"rank 0 -> {world} ranks: dist.scatter of 1/{world} slices + all_gather_into_tensor over RCCL (every xGMI link carries 1/{world} of the image)",
+                       "end_to_end": {"ms_per_batch_incl_broadcast": round(e2e_ms, 4), "value_mpixels_per_s_incl_broadcast": round(e2e_value, 1),
+                                      "note": "one step + the one-off fan-out of the shared source (broadcast_ms), as if every batch shipped a new source texture; `value` excludes it (inputs resident)"},
                        "output_pixels_per_step_per_gpu": int(px_per_step), "sources": primary_src,
                        "parallelism": f"frames sharded over {world} GPU(s); shared source broadcast once (scatter+all_gather over RCCL)",
                        "broadcast_ms": round(broadcast_ms, 3), "broadcast": broadcast, "gpus_on_node": n_devices,

@@ -71,6 +71,8 @@ extern "C" void hg_destroy(hg_ctx *c)
     { void *rp[] = { c->d_redo_frame, c->d_redo_dst, c->d_redo_trir, c->d_redo_trix, c->d_redo_segs, c->d_redo_fwd, c->d_redo_inv, c->d_redo_status, c->d_st_pts, c->d_st_tris, c->d_st_mats };
       for (void *q : rp) if (q) (void)hipFree(q); }
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->copy_event) (void)hipEventDestroy(c->copy_event);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -126,6 +128,30 @@ extern "C" int hg_enqueue_copy_to_host(hg_ctx *c, void *dst, const void *src, si
     HG_TRY(bind(c));
     if (!dst || !src) return fail(c, HG_ERR_INVALID, "NULL pointer");
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return HG_OK;
+}
+
+// Host -> device on the context's COPY stream (a second stream, created on first use): not ordered with the warp stream until
+// hg_fence_copies().  Lets a binding upload the source of frame f + 1 while frame f's pixels travel the other way on the warp stream
+// (PCIe is full duplex, the two directions have their own DMA engines).  Pageable `src` is staged by the runtime: the call then
+// returns once the caller's memory has been read (which is exactly what keeps the host busy while the opposite copy runs).
+extern "C" int hg_upload_on_copy_stream(hg_ctx *c, void *dst_device, const void *src_host, size_t bytes)
+{
+    HG_TRY(bind(c));
+    if (!dst_device || !src_host) return fail(c, HG_ERR_INVALID, "NULL pointer");
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, c->copy_stream));
+    return HG_OK;
+}
+
+// Everything queued on the warp stream after this call waits for the uploads queued on the copy stream so far.
+extern "C" int hg_fence_copies(hg_ctx *c)
+{
+    HG_TRY(bind(c));
+    if (!c->copy_stream) return HG_OK;
+    if (!c->copy_event) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_event, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->copy_event, c->copy_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_event, 0));
     return HG_OK;
 }
 

@@ -24,6 +24,8 @@ struct hg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t copy_stream = nullptr;                         // hg_upload_on_copy_stream: uploads that overlap the warp stream's work
+    hipEvent_t copy_event = nullptr;                           // hg_fence_copies
     std::string err;
     int deferred = HG_OK;
 

@@ -36,7 +36,9 @@ static napi_value throw_hg(napi_env env, hg_ctx *ctx, const char *what, int code
 /* d_batch: device buffer the frames of warpInversePiecewiseBatch are produced in (kept between calls, grown as needed) */
 /* n_pts / n_tris: the mesh last set, so that point-set and matrix buffers can be checked before the C ABI reads / fills them */
 /* d_imgs: device buffer of the per-frame sources of setImages() (kept, grown as needed) */
-typedef struct { hg_ctx *ctx; int obj_w, obj_h; void *d_batch; size_t d_batch_cap; size_t n_pts, n_tris; void *d_imgs; size_t d_imgs_cap; } handle_t;
+/* slab: page-locked memory behind ONE external ArrayBuffer whose views are the frames of a batch (see "batches" below) */
+typedef struct { void *ptr; size_t cap; napi_ref ab; } slab_t;
+typedef struct { hg_ctx *ctx; int obj_w, obj_h; void *d_batch; size_t d_batch_cap; size_t n_pts, n_tris; void *d_imgs; size_t d_imgs_cap; slab_t slab[2]; } handle_t;
 
 static void release_ctx(handle_t *h)
 {
@@ -48,11 +50,13 @@ static void release_ctx(handle_t *h)
     h->ctx = NULL; h->d_batch = NULL; h->d_batch_cap = 0; h->d_imgs = NULL; h->d_imgs_cap = 0;
 }
 
+static void slab_drop(napi_env env, slab_t *sl, int detach);
+
 static void handle_finalize(napi_env env, void *data, void *hint)
 {
-    (void)env; (void)hint;
+    (void)hint;
     handle_t *h = (handle_t *)data;
-    if (h) { release_ctx(h); free(h); }
+    if (h) { for (int k = 0; k < 2; k++) slab_drop(env, &h->slab[k], 0); release_ctx(h); free(h); }
 }
 
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
@@ -410,7 +414,12 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info)
     napi_value a[1];
     if (!get_args(env, info, 1, a)) return NULL;
     void *p = NULL;
-    if (napi_get_value_external(env, a[0], &p) == napi_ok && p) release_ctx((handle_t *)p);
+    if (napi_get_value_external(env, a[0], &p) == napi_ok && p) {
+        handle_t *h = (handle_t *)p;
+        if (h->ctx) (void)hg_sync(h->ctx);
+        for (int k = 0; k < 2; k++) slab_drop(env, &h->slab[k], 0);      /* (frames the caller still holds keep their memory: the ArrayBuffer owns it) */
+        release_ctx(h);
+    }
     return NULL;
 }
 
@@ -739,110 +748,100 @@ static napi_value fn_get_matrices(napi_env env, napi_callback_info info)
     return obj;
 }
 
-/* The caller loop `setDestinyPoints(dst_f); warp()` for F frames in one device pass: dst = F x 2N float32,
- * geoms = Int32Array F x 4 (xOff, yOff, objW, objH); returns an Array of F Uint8ClampedArray. */
-static napi_value fn_warp_inverse_piecewise_batch(napi_env env, napi_callback_info info)
+/* ---------------------------------------------------------------- batches: the caller loop `setDestinyPoints(dst_f); warp()` as device passes
+ * Frames come back as views of ONE page-locked slab owned by the context handle (two of them: slot 0 for the frames warp() sends down
+ * the inverse loops, slot 1 for the forward loops): one external ArrayBuffer per slab, created once and reused by the NEXT batch of the
+ * same kind on this instance -- frames of a batch are valid until then (or releaseBatch()), like `reuseOutput` for warp().  Nothing
+ * depends on the garbage collector: no per-frame ArrayBuffer, no finalizer has to run before memory comes back, no fall-back to V8
+ * arrays.  `ownFrames` (optional argument) = the old behaviour: every frame its own pooled buffer with a GC-bound life time.
+ * With per-frame sources ({images}: the video loop warp(image_f), README.md:121-137) the pass is pipelined frame by frame:
+ * H2D(f + 1) on the context's copy stream runs while D2H(f) travels the other way on the warp stream. */
+static void slab_finalize(napi_env env, void *data, void *hint) { (void)env; (void)hint; if (data) hg_host_free(data); }
+
+static void slab_drop(napi_env env, slab_t *sl, int detach)
 {
-    napi_value a[3];
-    if (!get_args(env, info, 3, a)) return NULL;
-    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
-    size_t nd, ng;
-    float *dst = (float *)get_typed(env, a[1], napi_float32_array, &nd, "dstPoints"); if (!dst) return NULL;
-    int32_t *gv = (int32_t *)get_typed(env, a[2], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
-    const int F = (int)(ng / 4);
-    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
-    if (h->n_pts == 0 || nd < (size_t)F * 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold frames x mesh points x,y pairs (piecewiseSetMesh first)");
-    size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
-    if (!offs) return throw_str(env, "hgwarp: out of memory (frame offsets)");
-    size_t total = 0;
-    hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
-    int rc = HG_OK;
-    if (total > h->d_batch_cap) {
-        if (h->d_batch) hg_device_free(h->ctx, h->d_batch);
-        h->d_batch = NULL; h->d_batch_cap = 0;
-        rc = hg_device_alloc(h->ctx, total, &h->d_batch);
-        if (rc == HG_OK) h->d_batch_cap = total;
+    if (sl->ab) {
+        if (detach) { napi_value ab = NULL; if (napi_get_reference_value(env, sl->ab, &ab) == napi_ok && ab) (void)napi_detach_arraybuffer(env, ab); }
+        napi_delete_reference(env, sl->ab);                   /* the ArrayBuffer's own finalizer frees the page-locked memory once no view is left */
     }
-    void *d_out = h->d_batch;
-    if (rc == HG_OK) rc = hg_warp_inverse_piecewise_batch_device(h->ctx, dst, (const hg_geom *)gv, offs, F, d_out);
-    napi_value arr = NULL;
-    if (rc == HG_OK && napi_create_array_with_length(env, F, &arr) == napi_ok) {
-        /* every frame's copy queues behind the kernels on the ctx stream (pinned pool memory: asynchronous DMA), one sync at the end */
-        for (int f = 0; f < F && rc == HG_OK; f++) {
-            const hg_geom *g = (const hg_geom *)gv + f;
-            const size_t px = (g->obj_w > 0 && g->obj_h > 0) ? (size_t)g->obj_w * g->obj_h : 0;
-            void *out; napi_value ta = make_pixels(env, px * 4, NULL, 0, &out);
-            if (!ta) { rc = HG_ERR_NOMEM; break; }
-            if (px) rc = hg_copy_to_host_async(h->ctx, out, (const uint8_t *)d_out + offs[f], px * 4);
-            napi_set_element(env, arr, f, ta);
-        }
-        const int rc2 = hg_sync(h->ctx);
-        if (rc == HG_OK) rc = rc2;
+    sl->ab = NULL; sl->ptr = NULL; sl->cap = 0;
+}
+
+/* JS array of F Uint8ClampedArray views, frame f at byte offs[f] of slab `slot` (grown to `total` bytes if needed) */
+static napi_value slab_frames(napi_env env, handle_t *h, int slot, const hg_geom *g, const size_t *offs, int F, size_t total, uint8_t **base)
+{
+    slab_t *sl = &h->slab[slot];
+    if (total > sl->cap || !sl->ab) {
+        slab_drop(env, sl, 0);
+        const size_t want = total + total / 8 + 4096;
+        void *p = NULL; napi_value ab;
+        if (hg_host_alloc(want, &p) != HG_OK) return throw_str(env, "hgwarp: cannot allocate the page-locked frame slab of this batch");
+        if (napi_create_external_arraybuffer(env, p, want, slab_finalize, NULL, &ab) != napi_ok) { hg_host_free(p); return throw_str(env, "hgwarp: cannot wrap the frame slab"); }
+        int64_t adj; napi_adjust_external_memory(env, (int64_t)want, &adj);
+        if (napi_create_reference(env, ab, 1, &sl->ab) != napi_ok) return throw_str(env, "hgwarp: cannot keep the frame slab");
+        sl->ptr = p; sl->cap = want;
     }
-    free(offs);
-    if (rc != HG_OK) return throw_hg(env, h->ctx, "warpInversePiecewiseBatch", rc);
+    napi_value ab, arr;
+    NAPI_OK(napi_get_reference_value(env, sl->ab, &ab));
+    NAPI_OK(napi_create_array_with_length(env, F, &arr));
+    for (int f = 0; f < F; f++) {
+        const size_t px = (g[f].obj_w > 0 && g[f].obj_h > 0) ? (size_t)g[f].obj_w * g[f].obj_h : 0;
+        napi_value ta;
+        NAPI_OK(napi_create_typedarray(env, napi_uint8_clamped_array, px * 4, ab, px ? offs[f] : 0, &ta));
+        NAPI_OK(napi_set_element(env, arr, f, ta));
+    }
+    *base = (uint8_t *)sl->ptr;
     return arr;
 }
 
-/* The caller loop `setDestinyPoints(dst_f); warp()` for an affine / projective transform as one device pass: from / to = F point
- * sets each (3 or 4 points x,y float32; the matrix of frame f maps from[f] -> to[f]: pass dst, src for the inverse warp, the
- * solves run on the GPU like the reference's :994 runs per warp), geoms = Int32Array F x 4; returns an Array of F frames. */
-static napi_value fn_warp_inverse_geometric_batch(napi_env env, napi_callback_info info)
+/* releaseBatch(ctx): the frames of the last batches become empty (their ArrayBuffers are detached), the slabs go */
+static napi_value fn_release_batch(napi_env env, napi_callback_info info)
 {
-    napi_value a[5];
-    if (!get_args(env, info, 5, a)) return NULL;
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
     handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
-    int kind; size_t nf, nt, ng;
-    if (!get_i32(env, a[1], &kind)) return NULL;
-    if (kind != HG_AFFINE && kind != HG_PROJECTIVE) return throw_str(env, "hgwarp: kind must be 0 (affine) or 1 (projective)");
-    float *from = (float *)get_typed(env, a[2], napi_float32_array, &nf, "fromPoints"); if (!from) return NULL;
-    float *to = (float *)get_typed(env, a[3], napi_float32_array, &nt, "toPoints"); if (!to) return NULL;
-    int32_t *gv = (int32_t *)get_typed(env, a[4], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
-    const int F = (int)(ng / 4);
-    const size_t per = kind == HG_AFFINE ? 6 : 8;
-    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
-    if (nf < (size_t)F * per || nt < (size_t)F * per) return throw_str(env, "hgwarp: point sets must hold frames x points x,y pairs");
-    size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
-    if (!offs) return throw_str(env, "hgwarp: out of memory (frame offsets)");
-    size_t total = 0;
-    hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
-    int rc = HG_OK;
-    if (total > h->d_batch_cap) {
-        if (h->d_batch) hg_device_free(h->ctx, h->d_batch);
-        h->d_batch = NULL; h->d_batch_cap = 0;
-        rc = hg_device_alloc(h->ctx, total, &h->d_batch);
-        if (rc == HG_OK) h->d_batch_cap = total;
-    }
-    if (rc == HG_OK) rc = hg_geometric_set_frames_points(h->ctx, kind, from, to, (const hg_geom *)gv, offs, F);
-    if (rc == HG_OK) rc = hg_warp_inverse_geometric_frames_device(h->ctx, h->d_batch);
-    napi_value arr = NULL;
-    if (rc == HG_OK && napi_create_array_with_length(env, F, &arr) == napi_ok) {
-        for (int f = 0; f < F && rc == HG_OK; f++) {
-            const hg_geom *g = (const hg_geom *)gv + f;
-            const size_t px = (g->obj_w > 0 && g->obj_h > 0) ? (size_t)g->obj_w * g->obj_h : 0;
-            void *out; napi_value ta = make_pixels(env, px * 4, NULL, 0, &out);
-            if (!ta) { rc = HG_ERR_NOMEM; break; }
-            if (px) rc = hg_copy_to_host_async(h->ctx, out, (const uint8_t *)h->d_batch + offs[f], px * 4);
-            napi_set_element(env, arr, f, ta);
-        }
-        const int rc2 = hg_sync(h->ctx);
-        if (rc == HG_OK) rc = rc2;
-    }
-    free(offs);
-    if (rc != HG_OK) return throw_hg(env, h->ctx, "warpInverseGeometricBatch", rc);
-    return arr;
+    (void)hg_sync(h->ctx);
+    for (int k = 0; k < 2; k++) slab_drop(env, &h->slab[k], 1);
+    return NULL;
 }
 
-/* Shared tail of the forward batches: room for the frames in the handle's device buffer, the launch through `run`, then every
- * frame's copy queued behind the kernels (pinned pool memory: asynchronous DMA) and one sync (which also settles frames the
- * tile kernels flagged). */
-typedef int (*batch_run_fn)(handle_t *h, const hg_geom *geoms, const size_t *offs, int F, void *d_out, void *arg);
-static napi_value run_frame_batch(napi_env env, handle_t *h, const int32_t *gv, int F, batch_run_fn run, void *arg, const char *what)
+enum { JOB_PW_INV, JOB_GEO_INV, JOB_PW_FWD, JOB_GEO_FWD };
+typedef struct { int type, kind; const float *dst, *from, *to; const double *m; int mx, my; size_t per; } batch_job;
+
+/* frames [f0, f0 + n) of the job into d_out at offs[f0 ..] */
+static int job_launch(handle_t *h, const batch_job *j, const hg_geom *g, const size_t *offs, int f0, int n, void *d_out)
 {
+    switch (j->type) {
+    case JOB_PW_INV:  return hg_warp_inverse_piecewise_batch_device(h->ctx, j->dst + (size_t)f0 * 2 * h->n_pts, g + f0, offs + f0, n, d_out);
+    case JOB_PW_FWD:  return hg_warp_forward_piecewise_batch_device(h->ctx, j->dst + (size_t)f0 * 2 * h->n_pts, j->mx, j->my, g + f0, offs + f0, n, d_out);
+    case JOB_GEO_FWD: return hg_warp_forward_geometric_batch_device(h->ctx, j->kind, j->m + (size_t)f0 * 8, g + f0, offs + f0, n, d_out);
+    default: {
+        int rc = hg_geometric_set_frames_points(h->ctx, j->kind, j->from + (size_t)f0 * j->per, j->to + (size_t)f0 * j->per, g + f0, offs + f0, n);
+        return rc == HG_OK ? hg_warp_inverse_geometric_frames_device(h->ctx, d_out) : rc;
+    }
+    }
+}
+
+/* opt[0] = ownFrames (boolean), opt[1] = images (Array of Uint8ClampedArray) or null / undefined, opt[2], opt[3] = their width, height */
+static napi_value run_batch(napi_env env, handle_t *h, const batch_job *job, const int32_t *gv, int F, int slot, const napi_value *opt, size_t n_opt, const char *what)
+{
+    const hg_geom *g = (const hg_geom *)gv;
+    bool own = false;
+    if (n_opt > 0) { napi_valuetype vt; if (napi_typeof(env, opt[0], &vt) == napi_ok && vt == napi_boolean) napi_get_value_bool(env, opt[0], &own); }
+    uint32_t n_img = 0;
+    int iw = 0, ih = 0;
+    if (n_opt > 1) {
+        bool is_arr = false;
+        if (napi_is_array(env, opt[1], &is_arr) == napi_ok && is_arr) {
+            NAPI_OK(napi_get_array_length(env, opt[1], &n_img));
+            if (n_img == 0 || n_opt < 4 || !get_i32(env, opt[2], &iw) || !get_i32(env, opt[3], &ih) || iw <= 0 || ih <= 0)
+                return throw_str(env, "hgwarp: a batch with per-frame sources needs a non-empty image list and their width, height");
+        }
+    }
     size_t *offs = (size_t *)malloc(sizeof(size_t) * F);
     if (!offs) return throw_str(env, "hgwarp: out of memory (frame offsets)");
     size_t total = 0;
-    hg_pack_offsets((const hg_geom *)gv, F, offs, &total);
+    hg_pack_offsets(g, F, offs, &total);
     int rc = HG_OK;
     if (total > h->d_batch_cap) {
         if (h->d_batch) hg_device_free(h->ctx, h->d_batch);
@@ -850,71 +849,139 @@ static napi_value run_frame_batch(napi_env env, handle_t *h, const int32_t *gv, 
         rc = hg_device_alloc(h->ctx, total, &h->d_batch);
         if (rc == HG_OK) h->d_batch_cap = total;
     }
-    if (rc == HG_OK) rc = run(h, (const hg_geom *)gv, offs, F, h->d_batch, arg);
+    if (rc != HG_OK) { free(offs); return throw_hg(env, h->ctx, what, rc); }
+    /* where the frames go */
     napi_value arr = NULL;
-    if (rc == HG_OK && napi_create_array_with_length(env, F, &arr) == napi_ok) {
-        for (int f = 0; f < F && rc == HG_OK; f++) {
-            const hg_geom *g = (const hg_geom *)gv + f;
-            const size_t px = (g->obj_w > 0 && g->obj_h > 0) ? (size_t)g->obj_w * g->obj_h : 0;
+    uint8_t *base = NULL;
+    uint8_t **outs = NULL;
+    if (!own) { arr = slab_frames(env, h, slot, g, offs, F, total, &base); if (!arr) { free(offs); return NULL; } }
+    else {
+        outs = (uint8_t **)calloc((size_t)F, sizeof *outs);
+        if (!outs || napi_create_array_with_length(env, F, &arr) != napi_ok) { free(offs); free(outs); return throw_str(env, "hgwarp: out of memory (frames)"); }
+        for (int f = 0; f < F; f++) {
+            const size_t px = (g[f].obj_w > 0 && g[f].obj_h > 0) ? (size_t)g[f].obj_w * g[f].obj_h : 0;
             void *out; napi_value ta = make_pixels(env, px * 4, NULL, 0, &out);
-            if (!ta) { rc = HG_ERR_NOMEM; break; }
-            if (px) rc = hg_copy_to_host_async(h->ctx, out, (const uint8_t *)h->d_batch + offs[f], px * 4);
+            if (!ta) { free(offs); free(outs); return NULL; }
+            outs[f] = (uint8_t *)out;
             napi_set_element(env, arr, f, ta);
         }
-        const int rc2 = hg_sync(h->ctx);
-        if (rc == HG_OK) rc = rc2;
     }
-    free(offs);
+    const uint8_t *d_out = (const uint8_t *)h->d_batch;
+    if (n_img == 0) {
+        /* one source for all frames: one pass; the copies queue behind the kernels on the warp stream (page-locked memory: asynchronous DMA) */
+        rc = job_launch(h, job, g, offs, 0, F, h->d_batch);
+        if (rc == HG_OK && !own) rc = hg_copy_to_host_async(h->ctx, base, d_out, total);       /* (the slab has the device layout: one copy) */
+        for (int f = 0; f < F && rc == HG_OK && own; f++) {
+            const size_t px = (g[f].obj_w > 0 && g[f].obj_h > 0) ? (size_t)g[f].obj_w * g[f].obj_h : 0;
+            if (px) rc = hg_copy_to_host_async(h->ctx, outs[f], d_out + offs[f], px * 4);
+        }
+    } else {
+        /* one source per frame (frame f reads images[f % n]): upload(f + 1) on the copy stream while frame f's pixels come down */
+        const size_t bytes = (size_t)iw * (size_t)ih * 4, stride = (bytes + 255) & ~(size_t)255;
+        const uint8_t **src = (const uint8_t **)calloc(n_img, sizeof *src);
+        if (!src) rc = HG_ERR_NOMEM;
+        for (uint32_t k = 0; k < n_img && rc == HG_OK; k++) {
+            napi_value el; size_t len;
+            if (napi_get_element(env, opt[1], k, &el) != napi_ok) { rc = HG_ERR_INVALID; break; }
+            src[k] = (const uint8_t *)get_typed(env, el, napi_uint8_clamped_array, &len, "images[k]");
+            if (!src[k]) { free(src); free(offs); free(outs); return NULL; }
+            if (len < bytes) { free(src); free(offs); free(outs); return throw_str(env, "hgwarp: an image is smaller than width*height*4"); }
+        }
+        if (rc == HG_OK && stride * n_img > h->d_imgs_cap) {
+            void *q = NULL;
+            rc = hg_device_alloc(h->ctx, stride * n_img, &q);
+            if (rc == HG_OK) rc = hg_set_images_device(h->ctx, q, iw, ih, 1, stride);      /* (the context's alias moves first: never dangling) */
+            if (rc == HG_OK) { if (h->d_imgs) hg_device_free(h->ctx, h->d_imgs); h->d_imgs = q; h->d_imgs_cap = stride * n_img; }
+            else if (q) hg_device_free(h->ctx, q);
+        }
+        if (rc == HG_OK) rc = hg_upload_on_copy_stream(h->ctx, h->d_imgs, src[0], bytes);
+        for (int f = 0; f < F && rc == HG_OK; f++) {
+            const size_t px = (g[f].obj_w > 0 && g[f].obj_h > 0) ? (size_t)g[f].obj_w * g[f].obj_h : 0;
+            rc = hg_set_images_device(h->ctx, (uint8_t *)h->d_imgs + stride * ((uint32_t)f % n_img), iw, ih, 1, stride);   /* (settles frame f - 1) */
+            if (rc == HG_OK) rc = hg_fence_copies(h->ctx);                                  /* the warp stream waits for image f */
+            if (rc == HG_OK) rc = job_launch(h, job, g, offs, f, 1, h->d_batch);
+            if (rc == HG_OK && px) rc = hg_copy_to_host_async(h->ctx, own ? outs[f] : base + offs[f], d_out + offs[f], px * 4);
+            if (rc == HG_OK && (uint32_t)(f + 1) < n_img && f + 1 < F)                      /* ... and image f + 1 goes up meanwhile */
+                rc = hg_upload_on_copy_stream(h->ctx, (uint8_t *)h->d_imgs + stride * (uint32_t)(f + 1), src[f + 1], bytes);
+        }
+        free(src);
+    }
+    const int rc2 = hg_sync(h->ctx);
+    if (rc == HG_OK) rc = rc2;
+    free(offs); free(outs);
     if (rc != HG_OK) return throw_hg(env, h->ctx, what, rc);
     return arr;
 }
 
-/* The caller loop `setDestinyPoints(dst_f); warp()` for the frames warp() sends down the FORWARD piecewise path (:421-422: output
- * not larger than the input and at least input / 1.2), one device pass: dst = F x 2N float32, maxSrcX / maxSrcY (:758),
- * geoms = Int32Array F x 4; returns an Array of F Uint8ClampedArray. */
-typedef struct { const float *dst; int mx, my; } fwd_pw_arg;
-static int run_fwd_pw(handle_t *h, const hg_geom *geoms, const size_t *offs, int F, void *d_out, void *arg)
+/* warpInversePiecewiseBatch(ctx, dstPoints F x 2N float32, geoms Int32Array F x 4 [, ownFrames, images, width, height]) */
+static napi_value fn_warp_inverse_piecewise_batch(napi_env env, napi_callback_info info)
 {
-    const fwd_pw_arg *a = (const fwd_pw_arg *)arg;
-    return hg_warp_forward_piecewise_batch_device(h->ctx, a->dst, a->mx, a->my, geoms, offs, F, d_out);
+    napi_value a[7]; size_t argc = 7;
+    if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 3) return throw_str(env, "hgwarp: wrong number of arguments");
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    size_t nd, ng; batch_job job = { JOB_PW_INV, 0, NULL, NULL, NULL, NULL, 0, 0, 0 };
+    job.dst = (const float *)get_typed(env, a[1], napi_float32_array, &nd, "dstPoints"); if (!job.dst) return NULL;
+    int32_t *gv = (int32_t *)get_typed(env, a[2], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
+    const int F = (int)(ng / 4);
+    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
+    if (h->n_pts == 0 || nd < (size_t)F * 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold frames x mesh points x,y pairs (piecewiseSetMesh first)");
+    return run_batch(env, h, &job, gv, F, 0, a + 3, argc - 3, "warpInversePiecewiseBatch");
 }
+
+/* warpInverseGeometricBatch(ctx, kind, from, to, geoms [, ownFrames, images, width, height]): from / to = F point sets each (3 or 4 points
+ * x,y float32; the matrix of frame f maps from[f] -> to[f]: pass dst, src for the inverse warp, the solves run on the GPU like the
+ * reference's :994 runs per warp) */
+static napi_value fn_warp_inverse_geometric_batch(napi_env env, napi_callback_info info)
+{
+    napi_value a[9]; size_t argc = 9;
+    if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 5) return throw_str(env, "hgwarp: wrong number of arguments");
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    size_t nf, nt, ng; batch_job job = { JOB_GEO_INV, 0, NULL, NULL, NULL, NULL, 0, 0, 0 };
+    if (!get_i32(env, a[1], &job.kind)) return NULL;
+    if (job.kind != HG_AFFINE && job.kind != HG_PROJECTIVE) return throw_str(env, "hgwarp: kind must be 0 (affine) or 1 (projective)");
+    job.from = (const float *)get_typed(env, a[2], napi_float32_array, &nf, "fromPoints"); if (!job.from) return NULL;
+    job.to = (const float *)get_typed(env, a[3], napi_float32_array, &nt, "toPoints"); if (!job.to) return NULL;
+    int32_t *gv = (int32_t *)get_typed(env, a[4], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
+    const int F = (int)(ng / 4);
+    job.per = job.kind == HG_AFFINE ? 6 : 8;
+    if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
+    if (nf < (size_t)F * job.per || nt < (size_t)F * job.per) return throw_str(env, "hgwarp: point sets must hold frames x points x,y pairs");
+    return run_batch(env, h, &job, gv, F, 0, a + 5, argc - 5, "warpInverseGeometricBatch");
+}
+
+/* warpForwardPiecewiseBatch(ctx, dstPoints, maxSrcX, maxSrcY, geoms [, ownFrames, images, width, height]): the frames warp() sends down the
+ * FORWARD piecewise path (:421-422: output not larger than the input and at least input / 1.2) */
 static napi_value fn_warp_forward_piecewise_batch(napi_env env, napi_callback_info info)
 {
-    napi_value a[5];
-    if (!get_args(env, info, 5, a)) return NULL;
+    napi_value a[9]; size_t argc = 9;
+    if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 5) return throw_str(env, "hgwarp: wrong number of arguments");
     handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
-    size_t nd, ng; fwd_pw_arg arg;
-    arg.dst = (const float *)get_typed(env, a[1], napi_float32_array, &nd, "dstPoints"); if (!arg.dst) return NULL;
-    if (!get_i32(env, a[2], &arg.mx) || !get_i32(env, a[3], &arg.my)) return NULL;
+    size_t nd, ng; batch_job job = { JOB_PW_FWD, 0, NULL, NULL, NULL, NULL, 0, 0, 0 };
+    job.dst = (const float *)get_typed(env, a[1], napi_float32_array, &nd, "dstPoints"); if (!job.dst) return NULL;
+    if (!get_i32(env, a[2], &job.mx) || !get_i32(env, a[3], &job.my)) return NULL;
     int32_t *gv = (int32_t *)get_typed(env, a[4], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
     const int F = (int)(ng / 4);
     if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
     if (h->n_pts == 0 || nd < (size_t)F * 2 * h->n_pts) return throw_str(env, "hgwarp: dstPoints must hold frames x mesh points x,y pairs (piecewiseSetMesh first)");
-    return run_frame_batch(env, h, gv, F, run_fwd_pw, &arg, "warpForwardPiecewiseBatch");
+    return run_batch(env, h, &job, gv, F, 1, a + 5, argc - 5, "warpForwardPiecewiseBatch");
 }
 
-/* The same for the affine frames warp() sends forward (:426-427: output of the source's size): mats = Float64Array F x 8, the
- * FORWARD matrices (6 used). */
-typedef struct { int kind; const double *m; } fwd_geo_arg;
-static int run_fwd_geo(handle_t *h, const hg_geom *geoms, const size_t *offs, int F, void *d_out, void *arg)
-{
-    const fwd_geo_arg *a = (const fwd_geo_arg *)arg;
-    return hg_warp_forward_geometric_batch_device(h->ctx, a->kind, a->m, geoms, offs, F, d_out);
-}
+/* warpForwardGeometricBatch(ctx, kind, mats Float64Array F x 8 (the FORWARD matrices, 6 used), geoms [, ownFrames, images, width, height]): the
+ * affine frames warp() sends forward (:426-427: output of the source's size) */
 static napi_value fn_warp_forward_geometric_batch(napi_env env, napi_callback_info info)
 {
-    napi_value a[4];
-    if (!get_args(env, info, 4, a)) return NULL;
+    napi_value a[8]; size_t argc = 8;
+    if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 4) return throw_str(env, "hgwarp: wrong number of arguments");
     handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
-    size_t nm, ng; fwd_geo_arg arg;
-    if (!get_i32(env, a[1], &arg.kind)) return NULL;
-    if (arg.kind != HG_AFFINE && arg.kind != HG_PROJECTIVE) return throw_str(env, "hgwarp: kind must be 0 (affine) or 1 (projective)");
-    arg.m = (const double *)get_typed(env, a[2], napi_float64_array, &nm, "matrices"); if (!arg.m) return NULL;
+    size_t nm, ng; batch_job job = { JOB_GEO_FWD, 0, NULL, NULL, NULL, NULL, 0, 0, 0 };
+    if (!get_i32(env, a[1], &job.kind)) return NULL;
+    if (job.kind != HG_AFFINE && job.kind != HG_PROJECTIVE) return throw_str(env, "hgwarp: kind must be 0 (affine) or 1 (projective)");
+    job.m = (const double *)get_typed(env, a[2], napi_float64_array, &nm, "matrices"); if (!job.m) return NULL;
     int32_t *gv = (int32_t *)get_typed(env, a[3], napi_int32_array, &ng, "geoms"); if (!gv) return NULL;
     const int F = (int)(ng / 4);
     if (F <= 0) return throw_str(env, "hgwarp: geoms must hold 4 integers per frame");
     if (nm < (size_t)F * 8) return throw_str(env, "hgwarp: matrices must hold 8 doubles per frame");
-    return run_frame_batch(env, h, gv, F, run_fwd_geo, &arg, "warpForwardGeometricBatch");
+    return run_batch(env, h, &job, gv, F, 1, a + 4, argc - 4, "warpForwardGeometricBatch");
 }
 
 /* ---------------------------------------------------------------- several GPUs (hg_multi_*) */
@@ -1126,6 +1193,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch }, { "warpInverseGeometricBatch", fn_warp_inverse_geometric_batch },
         { "warpForwardGeometric", fn_warp_forward_geometric }, { "warpForwardPiecewise", fn_warp_forward_piecewise },
         { "warpForwardPiecewiseBatch", fn_warp_forward_piecewise_batch }, { "warpForwardGeometricBatch", fn_warp_forward_geometric_batch },
+        { "releaseBatch", fn_release_batch },
         { "solveAffineTriangles", fn_solve_affine_triangles }, { "warpInversePiecewiseState", fn_warp_inverse_piecewise_state },
         { "warpForwardPiecewiseState", fn_warp_forward_piecewise_state },
         { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },

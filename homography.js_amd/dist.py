@@ -78,6 +78,32 @@ def rank_frame_ids(rank, frames_per_rank):
     return [rank * frames_per_rank + f for f in range(frames_per_rank)]
 
 
+def job_frame_ids(scaling, rank, world, frames_per_rank, batch):
+    """Which frames of the config's sequence `rank` warps per step.
+    weak   (default): `frames_per_rank` frames on every rank, rank r takes the r-th block: per-GPU work is fixed as N grows;
+    strong (north_star's wording, "batch = 512 / 64 frames sharded over 8 GPUs"): a FIXED batch of `batch` frames split by
+           shard_frames() -- contiguous blocks whose sizes differ by at most one; total work is fixed as N grows."""
+    if scaling == "strong":
+        return list(shard_frames(batch, rank, world))
+    return rank_frame_ids(rank, frames_per_rank)
+
+
+def end_to_end(ms_per_step, broadcast_ms, pixels_per_step_all):
+    """One batch INCLUDING the one-off fan-out of the shared source (paid once per batch, not per step): what a caller who ships a new
+    source texture with every batch sees.  Returns (ms per batch, Mpixels/s)."""
+    ms = float(ms_per_step) + float(broadcast_ms)
+    return ms, (float(pixels_per_step_all) / (ms * 1e-3) / 1e6 if ms > 0 else 0.0)
+
+
+def gather_rank_info(dist, world, info):
+    """Every rank's `info` dict (device name, XCC count, frames it owns ...) on every rank, in rank order."""
+    if world == 1:
+        return [info]
+    out = [None] * world
+    dist.all_gather_object(out, info)
+    return out
+
+
 def check_launch(world, rank, local_rank, n_devices):
     """A mis-launch must be loud: more ranks than GPUs on this node, or a local rank without a device, raise."""
     if not (0 <= rank < world):

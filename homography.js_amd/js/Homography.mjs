@@ -265,8 +265,14 @@ class Homography {
      *          {images: [...]} = the loop warp(image_f) (frame f reads images[f % images.length]); {devices: [...]} = the inverse
      *          frames spread over several GPUs of this node (forward frames run on this instance's own device);
      *          {pointsAreNormalized: bool} = the second argument of every setDestinyPoints (default: the reference's auto-detect).
+     *          {ownFrames: true} = every frame in a buffer of its own whose life time is the garbage collector's (see below).
      * Every setDestinyPoints(dst[f]) runs on the host exactly as in the loop (normalisation auto-detect, in-place scaling of typed
      * arrays, window derivation), so the instance ends in the state the loop would leave it in.
+     * LIFE TIME OF THE FRAMES (not the reference's API, so ours to define): by default the frames of a batch are views of ONE page-locked
+     * buffer owned by this instance, reused by the next warpBatch() on it -- consume (or copy) a batch before asking for the next one, like
+     * `reuseOutput` for warp().  The returned array has a `release()` method that gives the buffer back at once (the frames become empty).
+     * Nothing then depends on when V8 collects garbage: no 34-MB allocation per 4K frame, no fall-back to plain arrays in a loop that
+     * never yields.  With {images} the pass is pipelined: the upload of source f + 1 overlaps the download of frame f.
      */
     warpBatch(dstPointSets, options = {}) {
         if (this.transform === 'affine' || this.transform === 'projective') return this._warpBatchGeometric(dstPointSets, options);
@@ -306,7 +312,8 @@ class Homography {
             const images = options.images ? ids.map((f) => options.images[f % options.images.length]) : options.images;
             return { pts, g, images };
         };
-        const room = (g) => { let largest = 0; for (let k = 0; k < g.length / 4; k++) largest = Math.max(largest, g[4 * k + 2] * g[4 * k + 3] * 4); makeRoomFor(this._native, largest, g.length / 4); };
+        const own = options.ownFrames === true;
+        const room = (g) => { if (!own) return; let largest = 0; for (let k = 0; k < g.length / 4; k++) largest = Math.max(largest, g[4 * k + 2] * g[4 * k + 3] * 4); makeRoomFor(this._native, largest, g.length / 4); };
         const inv = pick(false), fwd = pick(true);
         if (inv.length) {
             const { pts, g, images } = subset(inv);
@@ -330,18 +337,16 @@ class Homography {
                     datas = this._native.multiWarpBatch(multi, pts, g);
                 }
             } else {
-                this._uploadSources(images);
                 this._uploadMesh();
-                datas = this._native.warpInversePiecewiseBatch(this._ctx, pts, g);
+                datas = this._batchSources(images, (...src) => this._native.warpInversePiecewiseBatch(this._ctx, pts, g, own, ...src));
             }
             inv.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
         if (fwd.length) {                                                                               // _piecewiseAffineWarp :948-972 for the frames warp() sends there
             const { pts, g, images } = subset(fwd);
             room(g);
-            this._uploadSources(images);
             this._uploadMesh();
-            const datas = this._native.warpForwardPiecewiseBatch(this._ctx, pts, this._maxSrcX, this._maxSrcY, g);
+            const datas = this._batchSources(images, (...src) => this._native.warpForwardPiecewiseBatch(this._ctx, pts, this._maxSrcX, this._maxSrcY, g, own, ...src));
             fwd.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
         for (const { f, map, mats } of stale) {                                                         // forward frames over a stale map: one by one, as they stand
@@ -352,7 +357,7 @@ class Homography {
         }
         for (let f = 0; f < F; f++) if (blank[f] === true) frames[f] = makeImageData(new Uint8ClampedArray(4), 1, 1);
         if (F > 0) this._lastPath = forward[F - 1] ? '_piecewiseAffineWarp' : '_inversePiecewiseAffineWarp';   // what the last warp() of the loop leaves behind
-        return frames;
+        return this._releasable(frames);
     }
 
     /**
@@ -384,7 +389,8 @@ class Homography {
         const kind = this.transform === 'affine' ? AFFINE : PROJECTIVE;
         const frames = new Array(F).fill(null);
         const pick = (want) => { const ids = []; for (let f = 0; f < F; f++) if (!blank[f] && forward[f] === want) ids.push(f); return ids; };
-        const room = (g) => { let largest = 0; for (let k = 0; k < g.length / 4; k++) largest = Math.max(largest, g[4 * k + 2] * g[4 * k + 3] * 4); makeRoomFor(this._native, largest, g.length / 4); };
+        const own = options.ownFrames === true;
+        const room = (g) => { if (!own) return; let largest = 0; for (let k = 0; k < g.length / 4; k++) largest = Math.max(largest, g[4 * k + 2] * g[4 * k + 3] * 4); makeRoomFor(this._native, largest, g.length / 4); };
         const sub = (arr, ids, w) => { if (ids.length === F) return arr; const o = new arr.constructor(ids.length * w); ids.forEach((f, k) => o.set(arr.subarray(f * w, (f + 1) * w), k * w)); return o; };
         const subImages = (ids) => (options.images && ids.length !== F ? ids.map((f) => options.images[f % options.images.length]) : options.images);
         const inv = pick(false), fwd = pick(true);
@@ -405,21 +411,19 @@ class Homography {
                     datas = this._native.multiWarpGeometricBatch(multi, kind, fr, tt, g);
                 }
             } else {
-                this._uploadSources(images);
-                datas = this._native.warpInverseGeometricBatch(this._ctx, kind, fr, tt, g);
+                datas = this._batchSources(images, (...src) => this._native.warpInverseGeometricBatch(this._ctx, kind, fr, tt, g, own, ...src));
             }
             inv.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
         if (fwd.length) {                                                                               // _geometricWarp :911-932
             const g = sub(geoms, fwd, 4), m = sub(mats, fwd, 8);
             room(g);
-            this._uploadSources(subImages(fwd));
-            const datas = this._native.warpForwardGeometricBatch(this._ctx, kind, m, g);
+            const datas = this._batchSources(subImages(fwd), (...src) => this._native.warpForwardGeometricBatch(this._ctx, kind, m, g, own, ...src));
             fwd.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
         for (let f = 0; f < F; f++) if (blank[f]) frames[f] = makeImageData(new Uint8ClampedArray(4), 1, 1);
         if (F > 0) this._lastPath = forward[F - 1] ? '_geometricWarp' : '_inverseGeometricWarp';
-        return frames;
+        return this._releasable(frames);
     }
 
     /** hg_multi handle for a device list (kept while the list stays the same). */
@@ -582,6 +586,21 @@ class Homography {
         if (images === undefined || images === null) return this._uploadImage();
         this._native.setImages(this._ctx, this._checkedSources(images), this._width, this._height);
         this._uploadedImage = null;                              // the next single-image warp uploads again
+    }
+
+    /** Runs a native batch with the instance's image (uploaded first) or with per-frame sources handed to the native side, which
+     *  pipelines their uploads with the downloads of the frames (frame f reads images[f % images.length]). */
+    _batchSources(images, run) {
+        if (images === undefined || images === null) { this._uploadImage(); return run(); }
+        const datas = run(this._checkedSources(images), this._width, this._height);
+        this._uploadedImage = null;                              // the next single-image warp uploads again
+        return datas;
+    }
+
+    /** The frames of a batch + `release()`: the page-locked buffer behind them goes back at once (they become empty). */
+    _releasable(frames) {
+        Object.defineProperty(frames, 'release', { value: () => { if (this._ctxHandle) this._native.releaseBatch(this._ctxHandle); }, enumerable: false });
+        return frames;
     }
 
     _uploadMesh() {

@@ -87,6 +87,12 @@ int hg_copy_to_host_async(hg_ctx *ctx, void *dst_host, const void *src_device, s
  * before waiting for any (hg_multi_*); frames a fused run only flagged are rewritten by the later hg_sync -- hg_redone_frames
  * tells -- and must then be copied again. */
 int hg_enqueue_copy_to_host(hg_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* Host -> device on the context's COPY stream (a second stream owned by the ctx), not ordered with the warp stream until
+ * hg_fence_copies(): the upload of frame f + 1's source overlaps frame f's D2H on the warp stream (full-duplex PCIe).  Pageable src:
+ * returns once the caller's memory has been read.  hg_fence_copies: everything queued on the warp stream afterwards waits for the
+ * uploads queued so far.  (The video loop `for (f) warp(image_f)`, README.md:121-137, through js/Homography.mjs warpBatch({images}).) */
+int hg_upload_on_copy_stream(hg_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+int hg_fence_copies(hg_ctx *ctx);
 /* Everything queued on the ctx stream after this call waits for hip_event (a hipEvent_t recorded on any stream of any device):
  * orders warps behind the caller's own uploads / peer copies without blocking the host. */
 int hg_stream_wait_event(hg_ctx *ctx, void *hip_event);

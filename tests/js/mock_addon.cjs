@@ -41,8 +41,8 @@ const mock = {
         fwd.forEach((mm, i) => { F.set(mm, 6 * i); I.set(core.inverseAffine(mm), 6 * i); });
         return { forward: F, inverse: I };
     },
-    warpInversePiecewiseBatch(c, pts, g) {
-        log('warpInversePiecewiseBatch'); needImage(c);
+    warpInversePiecewiseBatch(c, pts, g, own, images, w, h) {
+        log('warpInversePiecewiseBatch'); if (images) mock.setImages(c, images, w, h); needImage(c);
         const m = c.mesh, n = m.src.length, out = [];
         for (let k = 0; k < g.length / 4; k++)
             out.push(core.warpInversePiecewise(m.src, pts.subarray(k * n, (k + 1) * n), m.tris, imageOf(c, k), c.W, c.H, m.minX, m.minY, g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3]).out);
@@ -56,8 +56,8 @@ const mock = {
         const m = c.mesh, map = core.buildTriangleMap(m.src, m.tris, maxX - m.minX, maxY - m.minY, m.minY);
         return core.forwardPiecewiseLoop(core.piecewiseMatrices(m.src, dst, m.tris), map, imageOf(c, f), c.W, m.minX, m.minY, maxX, maxY, xo, yo, ow, oh);
     },
-    warpForwardPiecewiseBatch(c, pts, maxX, maxY, g) {
-        log('warpForwardPiecewiseBatch'); needImage(c);
+    warpForwardPiecewiseBatch(c, pts, maxX, maxY, g, own, images, w, h) {
+        log('warpForwardPiecewiseBatch'); if (images) mock.setImages(c, images, w, h); needImage(c);
         const n = c.mesh.src.length, out = [];
         for (let k = 0; k < g.length / 4; k++) out.push(mock._forward(c, pts.subarray(k * n, (k + 1) * n), maxX, maxY, g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3], k));
         return out;
@@ -80,8 +80,8 @@ const mock = {
         log('warpInverseGeometric'); needImage(c);
         return core.inverseGeometricLoop(kind, inv, imageOf(c, 0), c.W, c.H, xo, yo, ow, oh);
     },
-    warpInverseGeometricBatch(c, kind, from, to, g) {
-        log('warpInverseGeometricBatch'); needImage(c);
+    warpInverseGeometricBatch(c, kind, from, to, g, own, images, w, h) {
+        log('warpInverseGeometricBatch'); if (images) mock.setImages(c, images, w, h); needImage(c);
         const per = kind === 0 ? 6 : 8, out = [];
         for (let k = 0; k < g.length / 4; k++) {
             const a = from.subarray(k * per, (k + 1) * per), b = to.subarray(k * per, (k + 1) * per);
@@ -94,8 +94,8 @@ const mock = {
         log('warpForwardGeometric'); needImage(c);
         return core.forwardGeometricLoop(kind, m, imageOf(c, 0), c.W, c.H, xo, yo, ow, oh);
     },
-    warpForwardGeometricBatch(c, kind, mats, g) {
-        log('warpForwardGeometricBatch'); needImage(c);
+    warpForwardGeometricBatch(c, kind, mats, g, own, images, w, h) {
+        log('warpForwardGeometricBatch'); if (images) mock.setImages(c, images, w, h); needImage(c);
         const out = [];
         for (let k = 0; k < g.length / 4; k++) out.push(core.forwardGeometricLoop(kind, mats.subarray(8 * k, 8 * k + 8), imageOf(c, k), c.W, c.H, g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3]));
         return out;
@@ -104,10 +104,10 @@ const mock = {
     multiCreate: () => mock.create(), multiDestroy: () => {},
     multiSetImage(m, data, w, h) { mock.setImage(m, data, w, h); },
     multiSetMesh(m, src, tris, minX, minY) { mock.piecewiseSetMesh(m, src, tris, minX, minY); },
-    multiWarpBatch(m, pts, g, datas, w, h) { if (datas) mock.setImages(m, datas, w, h); return mock.warpInversePiecewiseBatch(m, pts, g); },
-    multiWarpGeometricBatch(m, kind, from, to, g, datas, w, h) { if (datas) mock.setImages(m, datas, w, h); return mock.warpInverseGeometricBatch(m, kind, from, to, g); },
+    multiWarpBatch(m, pts, g, datas, w, h) { return mock.warpInversePiecewiseBatch(m, pts, g, false, datas, w, h); },
+    multiWarpGeometricBatch(m, kind, from, to, g, datas, w, h) { return mock.warpInverseGeometricBatch(m, kind, from, to, g, false, datas, w, h); },
     // frame pool: plain V8 arrays here
-    poolPressure: () => false, poolCollected: () => {}, release: () => {}, setPinnedLimit: () => 0, poolStats: () => ({}),
+    poolPressure: () => false, poolCollected: () => {}, release: () => {}, releaseBatch: () => {}, setPinnedLimit: () => 0, poolStats: () => ({}),
 };
 for (const k of ['solveAffine', 'invertAffine', 'solveProjective', 'transformLimits', 'minmaxXY', 'triangulate', 'solveAffineTriangles'])
     if (real[k]) mock[k] = real[k];

@@ -192,6 +192,32 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     ok(threw, 'unknown device id must throw a string');
     mh.close();
 }
+{   // life time of batch frames: views of ONE page-locked buffer owned by the instance, reused by the next warpBatch() on it, released at
+    // once by frames.release(); {ownFrames: true} gives every frame a buffer of its own.  Nothing waits for the garbage collector: a loop
+    // of batches that never yields never falls back to plain V8 arrays.
+    const bh = new Homography('piecewiseaffine');
+    bh.setSourcePoints(src, lcgImage(W, H, 21), W, H, false);
+    const before = Homography.poolStats();
+    const b1 = bh.warpBatch(sets.slice(0, 3), { inverse: true });
+    const want1 = b1.map((o) => sha(o.data));
+    ok(new Set(b1.map((o) => o.data.buffer)).size === 1, 'the frames of a batch are views of one buffer');
+    ok(typeof b1.release === 'function' && Object.keys(b1).length === 3, 'release() is a non-enumerable method of the returned array');
+    const b2 = bh.warpBatch(sets.slice(2, 5), { inverse: true });
+    ok(b2[0].data.buffer === b1[0].data.buffer, 'the next batch reuses the buffer');
+    ok(sha(b2[0].data) === want1[2] && sha(b1[0].data) === sha(b2[0].data), 'the previous batch now shows the new frames (documented life time)');
+    const own = bh.warpBatch(sets.slice(0, 3), { inverse: true, ownFrames: true });
+    ok(new Set(own.map((o) => o.data.buffer)).size === 3 && own.every((o, f) => sha(o.data) === want1[f]), 'ownFrames: one buffer per frame, same bytes');
+    bh.warpBatch(sets.slice(2, 5), { inverse: true });
+    ok(own.every((o, f) => sha(o.data) === want1[f]), 'ownFrames survive later batches');
+    for (let it = 0; it < 40; it++) bh.warpBatch(sets, { inverse: true });                    // 200 frames of ~0.7 MB .. without yielding
+    const after = Homography.poolStats();
+    ok(after.fallbackToV8 === before.fallbackToV8, `a loop of batches must not fall back to V8 arrays (${JSON.stringify(after)})`);
+    const b3 = bh.warpBatch(sets.slice(0, 2), { inverse: true });
+    b3.release();
+    ok(b3.every((o) => o.data.length === 0), 'release() empties the frames');
+    ok(bh.warpBatch(sets.slice(0, 3), { inverse: true }).every((o, f) => sha(o.data) === want1[f]), 'a batch after release() gets a fresh buffer');
+    bh.close();
+}
 {   // frames of 1 MiB and more come from the page-locked pool as external ArrayBuffers; release() returns one at once
     const big = lcgImage(1024, 512, 5);
     const ph = new Homography('affine');

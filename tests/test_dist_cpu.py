@@ -157,6 +157,50 @@ def test_bench_bookkeeping_gloo_world2():
         assert ok_all is True
 
 
+def _strong_worker(rank, world, port, batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = _load("hg_dist", "dist.py")
+        ids = D.job_frame_ids("strong", rank, world, 64, batch)
+        # a rank's step takes as long as it has frames; its pixels are 10 per frame
+        agg = D.aggregate_step_stats(dist, world, torch.device("cpu"), elapsed_s=0.01 * len(ids), pixels_per_step=10.0 * len(ids), kernel_ms=0.1 * len(ids), verified=True)
+        info = D.gather_rank_info(dist, world, {"rank": rank, "frames": len(ids), "first_frame": ids[0] if ids else None})
+        q.put((rank, ids, agg, info))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch", [(2, 7), (2, 64), (4, 10)])
+def test_strong_scaling_bookkeeping_gloo(world, batch):
+    """bench.py --scaling strong: a FIXED batch split over the ranks (north_star: "batch = 512 / 64 frames sharded over 8 GPUs") -- every
+    frame owned exactly once, block sizes differ by at most one, pixels SUM to the whole batch, elapsed = the largest block's time,
+    every rank sees every rank's block (gather_rank_info); and the end-to-end figure adds the source fan-out once per batch."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [f for _, ids, _, _ in res for f in ids] == list(range(batch))
+    sizes = [len(ids) for _, ids, _, _ in res]
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == batch
+    for _, _, agg, info in res:
+        assert agg["pixels_per_step"] == 10.0 * batch and abs(agg["elapsed_s"] - 0.01 * max(sizes)) < 1e-12
+        assert [i["rank"] for i in info] == list(range(world)) and [i["frames"] for i in info] == sizes
+    D = _load("hg_dist", "dist.py")
+    assert D.job_frame_ids("weak", 1, 2, 5, 999) == [5, 6, 7, 8, 9]
+    ms, v = D.end_to_end(2.0, 0.5, 5.0e6)
+    assert ms == 2.5 and abs(v - 2000.0) < 1e-9
+
+
 def test_check_launch_is_loud():
     D = _load("hg_dist", "dist.py")
     D.check_launch(1, 0, 0, 1)

@@ -69,10 +69,37 @@ await settle();
     res.warp_batch8 = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
 }
 await settle();
+{   // one source per frame (the video loop warp(image_f)): uploads pipelined with the downloads, frames in the instance's slab
+    const F = 8, sets = Array.from({ length: F }, (_, f) => dsts[f % 4]);
+    const images = Array.from({ length: F }, (_, f) => ({ data: Uint8ClampedArray.from(data.subarray(0, data.length)), width: W, height: H }));
+    images.forEach((im, f) => { im.data[0] = f; });
+    h.warpBatch(sets, { images });
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) { const outs = h.warpBatch(sets, { images }); frames += F; for (const o of outs) px += o.width * o.height; }
+    const ms = now() - t0;
+    res.warp_batch8_images = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
+    // the same as the plain loop warp(image_f) with reuseOutput (upload, kernel, download one after the other)
+    h.reuseOutput = true;
+    frames = 0; px = 0; const t1 = now();
+    while (now() - t1 < budget * 1e3) { h.setDestinyPoints(dsts[frames % 4], false); out = h.warp(images[frames % F]); frames++; px += out.width * out.height; }
+    const ms1 = now() - t1;
+    res.warp_loop_images_reuse = { frames, ms_per_frame: +(ms1 / frames).toFixed(3), mpix_per_s: +(px / ms1 / 1e3).toFixed(1) , pool: snap() };
+    h.reuseOutput = false;
+    h.setImage({ data, width: W, height: H });
+}
+await settle();
+{   // the old life time of batch frames: every frame its own pooled buffer, back when V8 collects it ({ownFrames: true})
+    const F = 8, sets = Array.from({ length: F }, (_, f) => dsts[f % 4]);
+    let frames = 0, px = 0; const t0 = now();
+    while (now() - t0 < budget * 1e3) { const outs = h.warpBatch(sets, { ownFrames: true }); frames += F; for (const o of outs) px += o.width * o.height; }
+    const ms = now() - t0;
+    res.warp_batch8_own_frames = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
+}
+await settle();
 {   // batch with release of every frame after use
     const F = 8, sets = Array.from({ length: F }, (_, f) => dsts[f % 4]);
     let frames = 0, px = 0; const t0 = now();
-    while (now() - t0 < budget * 1e3) { const outs = h.warpBatch(sets); frames += F; for (const o of outs) { px += o.width * o.height; Homography.release(o); } }
+    while (now() - t0 < budget * 1e3) { const outs = h.warpBatch(sets, { ownFrames: true }); frames += F; for (const o of outs) { px += o.width * o.height; Homography.release(o); } }
     const ms = now() - t0;
     res.warp_batch8_release = { frames, ms_per_frame: +(ms / frames).toFixed(3), mpix_per_s: +(px / ms / 1e3).toFixed(1) , pool: snap() };
 }
