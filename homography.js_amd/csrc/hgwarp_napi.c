@@ -309,6 +309,21 @@ static napi_value fn_pool_test_frames(napi_env env, napi_callback_info info)
     return arr;
 }
 
+/* pinnedBuffer(bytes): a zeroed Uint8ClampedArray in pooled page-locked memory (a plain V8 array when the pool is off, exhausted, or the
+ * buffer is small): for SOURCE images the caller fills itself (decoded video frames ...) -- uploads out of page-locked memory are true
+ * asynchronous DMA at the full PCIe rate, uploads out of V8's pageable memory are staged by the runtime (~20 % slower and host-blocking). */
+static napi_value fn_pinned_buffer(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    double bytes;
+    if (napi_get_value_double(env, a[0], &bytes) != napi_ok || !(bytes >= 0) || bytes > 4.0e9) return throw_str(env, "hgwarp: pinnedBuffer(bytes)");
+    void *out = NULL;
+    napi_value ta = make_pixels(env, (size_t)bytes, NULL, 0, &out);
+    if (ta && out && bytes > 0) memset(out, 0, (size_t)bytes);
+    return ta;
+}
+
 /* poolPressure(bytes, n): should the caller run a collection before asking for n frames of `bytes` bytes?  True when the pool
  * cannot serve them from free (or already collected) buffers AND at least `g_next_gc_live` pooled frames are alive or the
  * cap would be exceeded.  A loop that allocates little JavaScript (warpBatch: 8 frames per call) can go a long time without
@@ -1193,7 +1208,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "warpInversePiecewiseBatch", fn_warp_inverse_piecewise_batch }, { "warpInverseGeometricBatch", fn_warp_inverse_geometric_batch },
         { "warpForwardGeometric", fn_warp_forward_geometric }, { "warpForwardPiecewise", fn_warp_forward_piecewise },
         { "warpForwardPiecewiseBatch", fn_warp_forward_piecewise_batch }, { "warpForwardGeometricBatch", fn_warp_forward_geometric_batch },
-        { "releaseBatch", fn_release_batch },
+        { "releaseBatch", fn_release_batch }, { "pinnedBuffer", fn_pinned_buffer },
         { "solveAffineTriangles", fn_solve_affine_triangles }, { "warpInversePiecewiseState", fn_warp_inverse_piecewise_state },
         { "warpForwardPiecewiseState", fn_warp_forward_piecewise_state },
         { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },

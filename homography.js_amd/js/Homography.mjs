@@ -750,6 +750,10 @@ Homography.triangulate = defaultTriangulate;
 /** Optional: hands the pooled page-locked buffer of a frame returned by warp() / warpBatch() back at once (its data becomes
  *  empty).  Without it the buffer returns when the frame is garbage-collected. */
 Homography.release = (imageData) => addon().release(imageData && imageData.data ? imageData.data : imageData);
+/** An ImageData-shaped, zero-filled SOURCE image whose pixels live in page-locked memory (to be filled by the caller: decoded video frames
+ *  ...): uploads out of it are asynchronous DMA at the full PCIe rate -- with warpBatch({images}) the upload of source f + 1 then really
+ *  overlaps the download of frame f.  Images in ordinary V8 memory work everywhere too (the runtime stages them: ~20 % slower uploads). */
+Homography.pinnedImage = (width, height) => makeImageData(addon().pinnedBuffer(width * height * 4), width, height);
 /** Cap of the page-locked frame pool in bytes (default 2 GiB; 0: plain V8 arrays only).  Returns the bytes currently pinned. */
 Homography.setPinnedLimit = (bytes) => addon().setPinnedLimit(bytes);
 Homography.poolStats = () => addon().poolStats();

@@ -107,6 +107,7 @@ const mock = {
     multiWarpBatch(m, pts, g, datas, w, h) { return mock.warpInversePiecewiseBatch(m, pts, g, false, datas, w, h); },
     multiWarpGeometricBatch(m, kind, from, to, g, datas, w, h) { return mock.warpInverseGeometricBatch(m, kind, from, to, g, false, datas, w, h); },
     // frame pool: plain V8 arrays here
+    pinnedBuffer: (n) => new Uint8ClampedArray(n),
     poolPressure: () => false, poolCollected: () => {}, release: () => {}, releaseBatch: () => {}, setPinnedLimit: () => 0, poolStats: () => ({}),
 };
 for (const k of ['solveAffine', 'invertAffine', 'solveProjective', 'transformLimits', 'minmaxXY', 'triangulate', 'solveAffineTriangles'])

@@ -202,9 +202,17 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     const want1 = b1.map((o) => sha(o.data));
     ok(new Set(b1.map((o) => o.data.buffer)).size === 1, 'the frames of a batch are views of one buffer');
     ok(typeof b1.release === 'function' && Object.keys(b1).length === 3, 'release() is a non-enumerable method of the returned array');
-    const b2 = bh.warpBatch(sets.slice(2, 5), { inverse: true });
+    const b2 = bh.warpBatch([sets[2], sets[1], sets[0]], { inverse: true });                  // (a batch that fits the buffer as it stands)
     ok(b2[0].data.buffer === b1[0].data.buffer, 'the next batch reuses the buffer');
-    ok(sha(b2[0].data) === want1[2] && sha(b1[0].data) === sha(b2[0].data), 'the previous batch now shows the new frames (documented life time)');
+    ok(sha(b2[0].data) === want1[2] && sha(b2[2].data) === want1[0], 'the next batch holds its own frames');
+    ok(sha(b1[0].data.subarray(0, 4096)) === sha(b2[0].data.subarray(0, 4096)), 'the previous batch now shows the new frames (documented life time)');
+    {   // per-frame sources out of page-locked memory (Homography.pinnedImage) == out of plain arrays
+        const ims = [lcgImage(W, H, 61), lcgImage(W, H, 62), lcgImage(W, H, 63)];
+        const pinned = ims.map((im) => { const p = Homography.pinnedImage(W, H); p.data.set(im.data); return p; });
+        const wantI = bh.warpBatch(sets.slice(0, 3), { inverse: true, images: ims, ownFrames: true }).map((o) => sha(o.data));
+        ok(bh.warpBatch(sets.slice(0, 3), { inverse: true, images: pinned }).every((o, f) => sha(o.data) === wantI[f]), 'pinned sources give the same frames');
+        ok(wantI[0] !== want1[0], 'per-frame sources should differ from the instance image');
+    }
     const own = bh.warpBatch(sets.slice(0, 3), { inverse: true, ownFrames: true });
     ok(new Set(own.map((o) => o.data.buffer)).size === 3 && own.every((o, f) => sha(o.data) === want1[f]), 'ownFrames: one buffer per frame, same bytes');
     bh.warpBatch(sets.slice(2, 5), { inverse: true });

@@ -1,5 +1,5 @@
 // calib_d2h.hip -- device -> page-locked host: the copy engine (hipMemcpyAsync) against a kernel that stores into the host block,
-// for one 4K RGBA frame (34.4 MB) and a few other sizes.  tools/bin/calib_d2h
+// for one 4K RGBA frame (34.4 MB) and a few other sizes; and both directions at once (duplex).  tools/bin/calib_d2h
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -27,6 +27,19 @@ int main()
         const double c = timeit([&] { hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, st); });
         const double e = timeit([&] { hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, (uint4 *)d, (const uint4 *)h, bytes / 16); });
         printf("{\"bytes\": %zu, \"h2d_memcpy_us\": %.1f, \"h2d_memcpy_GBs\": %.1f, \"h2d_kernel_us\": %.1f, \"h2d_kernel_GBs\": %.1f}\n", bytes, c, bytes / c / 1e3, e, bytes / e / 1e3);
+        {   // both directions at once on two streams (what a pipelined video loop asks of the link): upload into d2 while d comes down
+            void *d2 = nullptr, *h2 = nullptr; hipStream_t st2;
+            CK(hipMalloc(&d2, bytes)); CK(hipHostMalloc(&h2, bytes, hipHostMallocDefault)); CK(hipStreamCreate(&st2));
+            std::memset(h2, 1, bytes);
+            auto both = [&] { hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st); hipMemcpyAsync(d2, h2, bytes, hipMemcpyHostToDevice, st2); };
+            both(); hipStreamSynchronize(st); hipStreamSynchronize(st2);
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < 10; i++) both();
+            hipStreamSynchronize(st); hipStreamSynchronize(st2);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 10;
+            printf("{\"bytes\": %zu, \"duplex_us_per_pair\": %.1f, \"duplex_GBs_each_way\": %.1f}\n", bytes, us, bytes / us / 1e3);
+            hipFree(d2); hipHostFree(h2); hipStreamDestroy(st2);
+        }
         hipFree(d); hipHostFree(h);
     }
     return 0;
