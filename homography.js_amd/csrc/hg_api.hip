@@ -210,18 +210,14 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "phase")) c->opt_phase = value;
     else if (!std::strcmp(key, "geo_windows")) c->opt_geo_nw = value;
     else if (!std::strcmp(key, "hi_bounds")) c->opt_hi_bounds = value != 0;
-    else if (!std::strcmp(key, "sgpr_cap")) c->opt_sgpr_cap = value;
     else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
     else if (!std::strcmp(key, "compact")) c->opt_compact = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "tile")) { c->opt_tile = value < 0 ? -1 : (value ? 1 : 0); c->pw_tile_disabled = false; }
     else if (!std::strcmp(key, "self_spans")) { c->opt_self = value < 0 ? -1 : (value ? 1 : 0); c->pw_self_disabled = false; }
-    else if (!std::strcmp(key, "tri_threads")) c->opt_tri_threads = (value == 64 || value == 128 || value == 256) ? value : -1;
     else if (!std::strcmp(key, "tri_group")) c->opt_tri_group = value < 0 ? -1 : (value >= 64 ? 64 : (value ? 16 : 0));
     else if (!std::strcmp(key, "safe_spans")) c->opt_safe_spans = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "upload_kernel")) c->opt_upload_kernel = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "rows8")) c->opt_rows8 = value < 0 ? -1 : (value ? 1 : 0);
-    else if (!std::strcmp(key, "rows1_threads")) c->opt_rows1_threads = (value == 128 || value == 256) ? value : -1;
-    else if (!std::strcmp(key, "col_split")) c->opt_col_split = (value == 1 || value == 2 || value == 4) ? value : -1;
     else if (!std::strcmp(key, "lds_pad")) c->opt_lds_pad = std::min(std::max(value, -1), 40);
     else if (!std::strcmp(key, "xcc")) {                      // block id -> XCD band mapping for `value` XCCs (a power of two <= 64); speed only
         if (value < 1 || value > 64 || (value & (value - 1))) return fail(c, HG_ERR_INVALID, "hg_set_option: xcc must be a power of two in 1..64");

@@ -265,7 +265,6 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     // k_tri_spans: one thread per triangle row and round.  Measured round 3 (step ms, 64 / 128 / 256 threads): C5 (~150 rows per
     // triangle, 8 frames) 0.475 / 0.463 / 0.489, C3 (~300 rows, 64 frames) 0.612 / 0.589 / 0.603; a single 4K frame 25.4 / 23.4 / 22.6 us
     c->pw_tri_threads = tri_rows <= 96.0 ? 64 : ((int64_t)F * c->n_tris <= 2048 && tri_rows > 128.0 ? 256 : 128);
-    if (c->opt_tri_threads > 0) c->pw_tri_threads = c->opt_tri_threads;
     if (cover > 48 && c->row_cap < kRowSpanCapFast) c->row_cap = kRowSpanCapFast;   // dense rows: size the span lists up front
     if (cover > 200 && c->row_cap < kRowSpanCapDense) c->row_cap = kRowSpanCapDense;
     // (the row counters and the status ring are reused as they are when their layout -- frame count, rows per frame, list
@@ -323,17 +322,9 @@ PwFrames frames_of(const hg_ctx *c)
     f.xcc_rotate = c->opt_xcc_rotate >= 0 ? (c->opt_xcc_rotate != 0) : (c->n_imgs > 1 || c->pw_fill > 1.08);
     f.xcc_log2 = c->xcc_log2; f.no_hi_bounds = c->opt_hi_bounds ? 0 : 1;
     f.rows8 = c->pw_rows8 ? 1 : 0;
-    f.sgpr_cap = c->opt_sgpr_cap >= 0 ? (c->opt_sgpr_cap != 0) : (c->n_imgs <= 1);
+    f.sgpr_cap = c->n_imgs <= 1;
     f.lds_pad_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : (c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0);
     f.lds_pad_patch_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : 0;
-    {   // small frame sets: split every row group's windows over 2 or 4 workgroups until the launch has ~4000 of them
-        int64_t groups = 0;
-        const int rg = c->pw_row_group == kRowGroup ? kRowGroup : 1;
-        for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0 && d.obj_h > 0) groups += (d.obj_h + rg - 1) / rg;
-        f.col_split = c->opt_col_split > 0 ? c->opt_col_split : 1;
-        f.rows1_threads = c->opt_rows1_threads > 0 ? c->opt_rows1_threads : 256;
-        (void)groups;
-    }
     // (self-span path: its instantiations fit 56 VGPRs / 78 SGPRs whatever the phase depth -- 8 workgroups per CU where the list-reading
     //  4-window form admits 7.  Same box, alternating order, 2 -> 4 windows per phase: C3 0.5697 -> 0.5685 ms, C4 0.2220 -> 0.2228, 512-triangle
     //  grid 0.6323 -> 0.6267: a wash to a slight gain, so one depth for every self-span set; EXPERIMENTS.md R4.10)
@@ -362,12 +353,7 @@ static RowLists rows_of(const hg_ctx *c)
 // Would the next fused warp of this frame set go through k_pw_patch (the parity tap, which passes a map, never does)?
 static bool patch_preferred(const hg_ctx *c, bool *global_records)
 {
-#ifdef HG_EXPERIMENTS
-    static const int env_force = getenv("HG_PATCH") ? atoi(getenv("HG_PATCH")) : -1;    // experiments build only: 0 = never, 1 = whenever allowed by size
-#else
-    constexpr int env_force = -1;                            // the shipped library reads no environment variable
-#endif
-    const int force = c->opt_patch >= 0 ? c->opt_patch : env_force;
+    const int force = c->opt_patch;                          // option "patch": -1 by estimate
     int mw = 0;
     for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
     if (global_records) *global_records = force == 2 ? true : (force == 1 ? false : c->pw_patch_dense);

@@ -84,7 +84,6 @@ struct hg_ctx {
     int opt_min_row_groups = 1152, opt_patch = -1, opt_phase = -1, opt_geo_nw = 8;   // hg_set_option()
     int xcc_log2 = 3;                                          // log2(XCCs of the device): hipDeviceAttributeNumberOfXccs at hg_create, option "xcc"
     int opt_lds_pad = -1;                                       // KB of dynamic LDS padding per k_pw_rows workgroup (occupancy experiments)
-    int opt_sgpr_cap = -1;                                     // -1 auto (shared source), 0 never, 1 always: k_pw_rows_s80
     int opt_hi_bounds = 1;                                     // 0: fp64 bounds compares instead of the high-dword form (hg_dev.h)
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync
@@ -134,13 +133,10 @@ struct hg_ctx {
     int band_cap = 0, n_bands = 0;
     int opt_self = -1;                                         // option "self_spans": 1 whenever eligible, 0 never, -1 by policy (run_setup)
     int rows_parity = 0;                                       // which of the two counter sets the current step counts into (ping-pong, hg_kernels.h)
-    int opt_tri_threads = -1;                                  // k_tri_spans workgroup size (64 / 128 / 256), -1 by estimate
     int opt_tri_group = -1;                                    // k_tri_spans_grouped: 16 / 64 triangles per workgroup, 0 never, -1 by mesh size
     int opt_upload_kernel = -1;                                // frame-set blocks up to 1 MB go up by k_upload (default) instead of hipMemcpyAsync (0)
     int opt_safe_spans = -1;                                   // option "safe_spans": span flags + bounds-test-free windows in k_pw_rows: 1 / 0, -1 by the spans-per-window estimate
     int opt_rows8 = -1;                                        // k_pw_rows<SELF>: 8 rows per workgroup (1), 4 (0), -1 by policy
-    int opt_rows1_threads = -1;                                // -1 by frame-set size, else 128 or 256
-    int opt_col_split = -1;                                    // k_pw_rows workgroups per row group: -1 by frame-set size, else 1, 2 or 4
     // layout estimates of the last frame set, reused for the next set of the same shape (the kernels check the real counts)
     struct LayoutKey { int n = -1, n_tris = -1, max_w = -1, max_h = -1; uint64_t mesh_gen = 0; bool quick = false; } layout_key;
     uint64_t mesh_gen = 0; int layout_age = 0;

@@ -16,23 +16,6 @@ __device__ __forceinline__ void flag_frame(const PwFrames &fr, int f, int32_t bi
 }
 
 
-// ------------------------------------------------------------------------------------------------ experiment hooks
-// The warp kernels call these hooks at the few places the timing ablations of EXPERIMENTS.md alter.  The product translation
-// units only ever instantiate NoExperiment, whose hooks are identities; the ablation policies (which write WRONG pixels by
-// design) live in csrc/experiments/hg_ablate.h and are compiled only into lib/libhgwarp_exp.so (`make experiments`).
-struct NoExperiment {
-    // k_pw_rows
-    __device__ static __forceinline__ size_t list_base(size_t own, int, int, int, int, int, int, int) { return own; }
-    __device__ static __forceinline__ bool fake_search(int *, unsigned long long &, int, int, int) { return false; }
-    __device__ static __forceinline__ double pixel_x(double xd, int, int, int, int) { return xd; }
-    __device__ static __forceinline__ double pixel_hy(double hy, int) { return hy; }
-    __device__ static __forceinline__ uint32_t gather(__amdgpu_buffer_rsrc_t src, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0); }
-    __device__ static __forceinline__ bool skip_store(const uint32_t *) { return false; }
-    // k_tri_spans
-    __device__ static __forceinline__ int slot(int32_t *cnt, int, int64_t) { return atomicAdd(cnt, 1); }
-    static constexpr bool store_entries = true;
-    static constexpr bool tri_solve = true;                 // k_tri_spans_grouped: the per-triangle solves run
-};
 
 // ------------------------------------------------------------------------------------------------ bounds on the high dwords
 // The bounds tests :1047 / :1001 are made on h = RTN(s + 0.5):  a <= s < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).

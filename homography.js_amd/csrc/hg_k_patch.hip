@@ -333,25 +333,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             const bool inb = HIB ? hi_inb(hb, h[2 * k], h[2 * k + 1])
                                  : (bool)((int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi));   // :1047 (NaN fails)
             const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
-#if defined(HG_PATCH_EXP) && HG_PATCH_EXP == 1
-            // timing experiment (wrong pixels): the gather addresses of an identity map -- a 16 px x 4 row patch reads 4 source rows x 64 B
-            const uint32_t oid = (uint32_t)(__mul24(min(r0 + rr, mesh.H - 1), pitch4) + (min(c0 + ck[k], mesh.W - 1) << 2));
-            px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? oid : 0xffffffffu, 0, 0);
-#elif defined(HG_PATCH_EXP) && HG_PATCH_EXP == 2
-            // timing experiment (wrong pixels): 4 runs of 16 px, each along ONE source row, but the four runs 16 source rows apart
-            const uint32_t oid = (uint32_t)(__mul24(min(r0 + rr * 16, mesh.H - 1), pitch4) + (min(c0 + ck[k], mesh.W - 1) << 2));
-            px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? oid : 0xffffffffu, 0, 0);
-#elif defined(HG_PATCH_EXP) && HG_PATCH_EXP == 3
-            // timing experiment (wrong pixels): 8 runs of 8 px, each along ONE source row, the runs 8 source rows apart
-            const uint32_t oid = (uint32_t)(__mul24(min(r0 + (lane >> 3) * 8, mesh.H - 1), pitch4) + (min(c0 + 16 * k + (lane & 7) + ((k & 1) << 3), mesh.W - 1) << 2));
-            px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? oid : 0xffffffffu, 0, 0);
-#elif defined(HG_PATCH_EXP) && HG_PATCH_EXP == 4
-            // timing experiment (wrong pixels): 4 runs of 16 px, each straddling TWO source rows (a run along a non-integer slope), runs 16 rows apart
-            const uint32_t oid = (uint32_t)(__mul24(min(r0 + rr * 16 + ((lane >> 1) & 1), mesh.H - 1), pitch4) + (min(c0 + ck[k], mesh.W - 1) << 2));
-            px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? oid : 0xffffffffu, 0, 0);
-#else
             px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
-#endif
         }
     };
     // 64 x 4 transpose through this wave's LDS tile (wave-synchronous: no barrier), so that each store instruction

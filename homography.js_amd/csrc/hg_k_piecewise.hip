@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_pw_fused(PwMesh mesh, PwFrames fr, uint
 // |min_src_x/y| < 2^22.
 
 
-template <class X, bool COMPACT>      // X: experiment hooks (hg_dev.h); the product only instantiates NoExperiment
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void k_tri_spans(PwMesh mesh, PwFrames fr, RowLists rl)
 {
     const int t = blockIdx.x, f = blockIdx.y;
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
         if (r < 0 || r >= fd.obj_h || k < r * W || k >= (r + 1) * W) r = k / W;
         for (; r * W < fin; r++) {
             const int64_t lo = (k > r * W ? k : r * W) - r * W, hi = (fin < (r + 1) * W ? fin : (r + 1) * W) - r * W;
-            const int slot = X::slot(&rowcnt[r], t, y);
-            if (slot < rl.cap && X::store_entries) {
+            const int slot = atomicAdd(&rowcnt[r], 1);
+            if (slot < rl.cap) {
                 const size_t idx = ent0 + (size_t)r * rl.cap + slot;
                 const uint32_t lh = (uint32_t)lo | ((uint32_t)hi << 16);
                 if (COMPACT) static_cast<uint2 *>(rl.ent)[idx] = make_uint2(lh, (uint32_t)t);
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
 // wave-uniform values.  The 8 waves per workgroup keep ~6 waves per SIMD in flight on C3 for the returning slot atomics.
 constexpr int kTriGroupThreads = 512;
 
-template <class X, bool COMPACT, int kTriGroup>       // kTriGroup: 16, or 64 (a full wave of solves) for dense meshes
+template <bool COMPACT, int kTriGroup>       // kTriGroup: 16, or 64 (a full wave of solves) for dense meshes
 __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh mesh, PwFrames fr, RowLists rl)
 {
     __shared__ Seg s_seg[kTriGroup][3];
@@ -379,8 +379,7 @@ __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh m
             }
         }
         float fwd[6], inv[6];
-        if (X::tri_solve) { solve_affine(s, d, fwd); invert_affine(fwd, inv); }
-        else { for (int k = 0; k < 6; k++) { fwd[k] = d[k]; inv[k] = s[k]; } }
+        solve_affine(s, d, fwd); invert_affine(fwd, inv);
         Seg seg[3];
         define_seg(d[0], d[1], d[2], d[3], seg[0]);     // p0->p1
         define_seg(d[0], d[1], d[4], d[5], seg[1]);     // p0->p2
@@ -431,8 +430,8 @@ __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh m
             if (r < 0 || r >= fd.obj_h || k < r * W || k >= (r + 1) * W) r = k / W;
             for (; r * W < fin; r++) {
                 const int64_t lo = (k > r * W ? k : r * W) - r * W, hi = (fin < (r + 1) * W ? fin : (r + 1) * W) - r * W;
-                const int slot = X::slot(&rowcnt[r], t, y);
-                if (slot < rl.cap && X::store_entries) {
+                const int slot = atomicAdd(&rowcnt[r], 1);
+                if (slot < rl.cap) {
                     const size_t idx = ent0 + (size_t)r * rl.cap + slot;
                     const uint32_t lh = (uint32_t)lo | ((uint32_t)hi << 16);
                     if (COMPACT) static_cast<uint2 *>(rl.ent)[idx] = make_uint2(lh, (uint32_t)t);
@@ -448,7 +447,7 @@ __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh m
 }
 
 
-template <int CAP, class X, bool MAP, int PH, bool COMPACT, bool HIB, int SELF, int RG = kRowGroup>      // SELF: 0 row lists, 1 own spans, 2 the same with all three edges in flight (small frame sets); RG: rows per group in packed mode (8: k_pw_rows8, SELF only)
+template <int CAP, bool MAP, int PH, bool COMPACT, bool HIB, int SELF, int RG = kRowGroup>      // SELF: 0 row lists, 1 own spans, 2 the same with all three edges in flight (small frame sets); RG: rows per group in packed mode (8: k_pw_rows8, SELF only)
 __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *__restrict__ out,
                                              int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
                                              int32_t *__restrict__ status_next)
@@ -457,11 +456,8 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // for dense meshes (there, rows that share source lines should run side by side in different workgroups).  1-D grid decoded so that XCD x (= block id % number of XCCs of the device -- hipDeviceAttributeNumberOfXccs, hg_create --, the observed
     // dispatch order; speed only, never correctness) walks a contiguous band of rows of one frame: vertically adjacent
     // output rows share source cache lines, which then stay in that XCD's L2 instead of being fetched by up to 8 of them.
-    // Small frame sets (a single 4K frame is 2239 one-row workgroups for 256 CUs, each a chain of two list round trips and ~4
-    // windows per wave): fr.col_split workgroups share a row group, each taking a contiguous range of its windows.
     const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1);
-    int bi = bid >> fr.xcc_log2, seg = 0;
-    if (fr.col_split > 1) { seg = bi % fr.col_split; bi /= fr.col_split; }
+    const int bi = bid >> fr.xcc_log2;
     const int f = bi / groups_per_xcd;
     // (fr.xcc_rotate: the band an XCD takes rotates with the frame.  Where rows differ in cost -- C4's face mesh fills the middle
     //  bands and leaves the top and bottom ones nearly empty -- a fixed band per XCD hands the same XCD the expensive band of EVERY
@@ -473,15 +469,12 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // housekeeping for the NEXT step (saves its memset): the next status set is cleared here, and every workgroup zeroes the
     // span counters of its rows in the OTHER of the two counter sets -- the one the previous step consumed and the next step's
     // k_tri_spans will count into (ping-pong: nobody reads it during this launch, so no ordering against this launch's readers)
-    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;       // 256 threads; 128 for one-row workgroups of small frame sets (launcher)
+    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;       // 256 threads (512: k_pw_rows8)
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += nthreads) status_next[i] = 0;
     // (every row of the frame's counter block, not only the rows of THIS step's window: the other set was filled under the
     //  previous step's geometry, whose frame may have been a row taller)
     if ((int)threadIdx.x < rows_per_group && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0) return;
-#if defined(HG_ROWS_EXP) && HG_ROWS_EXP == 6                     // timing experiment: the launch alone
-    if (fd.obj_w > 0) return;
-#endif
 
     __shared__ __align__(16) double s_m[CAP * 6];
     __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (KS)
@@ -498,8 +491,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: the window loop runs on the scalar unit
     const int nwin_row = (W + 255) >> 8;
-    const int w_lo = fr.col_split > 1 ? (seg * nwin_row) / fr.col_split : 0;              // this workgroup's windows of each row
-    const int nwin = fr.col_split > 1 ? ((seg + 1) * nwin_row) / fr.col_split : nwin_row;   // (exclusive end)
+    const int w_lo = 0, nwin = nwin_row;
     const int nrows = min(rows_per_group, fd.obj_h - r0);
 
     // ---- span counts of the group's rows.  Packed mode (every row has at most 63 spans: the common case): all four
@@ -554,7 +546,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // triangle point at); threads t0, t0 + step, ... of the caller's thread set do the copying
     auto load_row = [&](int row, int cnt, int base, int nan_slot, int t0, int step) {
         const double y = (double)(r0 + row + fd.y_off);
-        const size_t e0 = X::list_base(((size_t)f * rl.row_stride + r0 + row) * rl.cap, xcd, groups_per_xcd, bi, f, rows_per_group, row, rl.cap);
+        const size_t e0 = ((size_t)f * rl.row_stride + r0 + row) * rl.cap;
         for (int i = t0; i < cnt; i += step) {
             uint32_t lh, id;
             double m0, m1, m2, m3, m4, m5;
@@ -757,8 +749,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
 #pragma unroll
                 for (int k = 0; k < 4; k++) best[k] = nan_key;
                 unsigned long long any = 0ull;
-                if (X::fake_search(best, any, base, w, cnt)) { }
-                else if (in_regs) {
+                if (in_regs) {
                     unsigned long long mask = __ballot(lo_r < c0 + 256 && hi_r > c0);
                     any = mask;
                     while (mask) {
@@ -803,14 +794,14 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                             for (int k = kk; k < kk + 2; k++) {
                                 const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KADDR));
                                 const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                                const double xd = X::pixel_x(xd0 + (double)(k * 64), c0, lane, k, fd.x_off);
+                                const double xd = xd0 + (double)(k * 64);
                                 v[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
-                                v[2 * (k - kk) + 1] = X::pixel_hy(fma(m1.y, xd, m2.x) + m2.y, lane);
+                                v[2 * (k - kk) + 1] = fma(m1.y, xd, m2.x) + m2.y;
                             }
                             round_half_x4(v, r);
 #pragma unroll
                             for (int k = kk; k < kk + 2; k++)
-                                px[p][k] = X::gather(src, (uint32_t)(__mul24(r[2 * (k - kk) + 1], pitch4) + (r[2 * (k - kk)] << 2)));     // :1048-1049
+                                px[p][k] = __builtin_amdgcn_raw_buffer_load_b32(src, (uint32_t)(__mul24(r[2 * (k - kk) + 1], pitch4) + (r[2 * (k - kk)] << 2)), 0, 0);     // :1048-1049
                         }
                     } else
 #pragma unroll
@@ -823,11 +814,11 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                         for (int k = kk; k < kk + STEP; k++) {
                             const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KADDR));
                             const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                            const double xd = X::pixel_x(xd0 + (double)(k * 64), c0, lane, k, fd.x_off);
+                            const double xd = xd0 + (double)(k * 64);
                             // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
                             // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
                             h[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
-                            h[2 * (k - kk) + 1] = X::pixel_hy(fma(m1.y, xd, m2.x) + m2.y, lane);
+                            h[2 * (k - kk) + 1] = fma(m1.y, xd, m2.x) + m2.y;
                         }
                         if constexpr (STEP == 4) round_x8(h, rd); else round_x4(h, rd);
 #pragma unroll
@@ -837,7 +828,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                                                  : (bool)((int)(h[q] >= bx_lo) & (int)(h[q] < bx_hi) & (int)(h[q + 1] >= by_lo) & (int)(h[q + 1] < by_hi));   // NaN fails
                             const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[q + 1]), pitch4) + ((int)dlo(rd[q]) << 2));     // :1048-1049
                             const uint32_t off = inb ? o : 0xffffffffu;
-                            px[p][k] = X::gather(src, off);                 // range-checked buffer load: outside the array -> 0
+                            px[p][k] = __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0);                 // range-checked buffer load: outside the array -> 0
                         }
                     }
                 }
@@ -852,7 +843,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                 const int w = wb + p * wstep;
                 if (w >= nwin) break;
                 const int cq = (w << 8) + lane;
-                if (X::skip_store(px[p])) continue;
                 if (empty[p] && vec_zero) {                 // 1 KB of zeros: which lane writes which pixel does not matter -> one 16-byte store per lane
                     __builtin_amdgcn_raw_buffer_store_b128(zero4, dst, ((w << 8) + lane * 4) * 4, 0, kStoreNT);
                 } else {
@@ -871,9 +861,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
             if (threadIdx.x == 0) flag_frame(fr, f, FRAME_LDS_OVERFLOW);
             return;
         }
-#if defined(HG_ROWS_EXP) && HG_ROWS_EXP == 3                     // timing experiment (tools/variants.sh): the prologue alone
-        if (nrows > 0) return;
-#endif
         const int row = packed ? wave : 0;
         int cnt_row = 0;
 #pragma unroll
@@ -894,11 +881,11 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     }
 }
 
-template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, int SELF = 0>
+template <int CAP, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, int SELF = 0>
 __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int16_t *__restrict__ map_out,
                                                  int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
 {
-    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, SELF>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
+    pw_rows_body<CAP, MAP, PH, COMPACT, HIB, SELF>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
 }
 
 // 8-row groups of the self-span path (512 threads, wave j walks row r0 + j): one candidate scan and one launch slot per EIGHT rows -- the
@@ -906,7 +893,7 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
 template <int PH, bool HIB>
 __global__ __launch_bounds__(512) void k_pw_rows8(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int groups_per_xcd, int32_t *__restrict__ status_next)
 {
-    pw_rows_body<kRowSpanCapDense, NoExperiment, false, PH, false, HIB, 1, 8>(mesh, fr, rl, out, nullptr, groups_per_xcd, 8, status_next);
+    pw_rows_body<kRowSpanCapDense, false, PH, false, HIB, 1, 8>(mesh, fr, rl, out, nullptr, groups_per_xcd, 8, status_next);
 }
 
 // The same kernel held to 80 SGPRs.  A 256-thread workgroup puts one wave on each SIMD and a SIMD has 800 SGPRs, allocated in
@@ -914,20 +901,14 @@ __global__ __launch_bounds__(512) void k_pw_rows8(PwMesh mesh, PwFrames fr, RowL
 // 8; capped, ~20 scalars move into VGPR lanes and 8 workgroups fit.  Measured on one box (round 3): with a shared,
 // cache-resident source (instruction-bound) 2 windows per phase 0.555 -> 0.543 ms on C3; with one source per frame (HBM-bound) the
 // extra waves LOSE 1-3 %, and C4's 4-windows-per-phase layout loses 6 % -- so only the shared-source PH = 2 layout takes it.
-template <int CAP, class X, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, int SELF = 0>
+template <int CAP, bool MAP, int PH = 1, bool COMPACT = false, bool HIB = false, int SELF = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_pw_rows_s80(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out,
                                                  int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group, int32_t *__restrict__ status_next)
 {
-    pw_rows_body<CAP, X, MAP, PH, COMPACT, HIB, SELF>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
+    pw_rows_body<CAP, MAP, PH, COMPACT, HIB, SELF>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-#ifdef HG_EXPERIMENTS
-} // namespace hg
-#include "experiments/hg_ablate.h"      // ablation policies + their launch switches; never part of libhgwarp.so
-namespace hg {
-#endif
-
 // A frame set's block (a few KB .. a few hundred KB) from its page-locked staging slot to the device by a KERNEL that reads host memory: the
 // copy engine's start-up latency made the stream-ordered hipMemcpyAsync of 36 KB cost 13 us of a 233-us step (EXPERIMENTS.md R4.13).
 __global__ __launch_bounds__(256) void k_upload(UploadSegs sg)
@@ -976,40 +957,36 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
 {
     if (mesh.n_tris <= 0 || fr.n_frames <= 0) return;
     const dim3 grid(mesh.n_tris, fr.n_frames), block(fr.tri_threads == 64 ? 64 : (fr.tri_threads >= 256 ? 256 : 128));
-#ifdef HG_EXPERIMENTS
-    if (launch_tri_spans_ablated(mesh, fr, rl, grid, block, stream)) return;      // experiments/hg_ablate.h
-#endif
     if (fr.tri_group) {                                      // thousands of (frame, triangle) pairs: the solves of 16 triangles on 16 lanes
         const int G = fr.tri_group >= 64 ? 64 : 16;
         const dim3 ggrid((mesh.n_tris + G - 1) / G, fr.n_frames), gblock(kTriGroupThreads);
         if (G == 64) {
-            if (rl.compact) hipLaunchKernelGGL((k_tri_spans_grouped<NoExperiment, true, 64>), ggrid, gblock, 0, stream, mesh, fr, rl);
-            else            hipLaunchKernelGGL((k_tri_spans_grouped<NoExperiment, false, 64>), ggrid, gblock, 0, stream, mesh, fr, rl);
+            if (rl.compact) hipLaunchKernelGGL((k_tri_spans_grouped<true, 64>), ggrid, gblock, 0, stream, mesh, fr, rl);
+            else            hipLaunchKernelGGL((k_tri_spans_grouped<false, 64>), ggrid, gblock, 0, stream, mesh, fr, rl);
         } else {
-            if (rl.compact) hipLaunchKernelGGL((k_tri_spans_grouped<NoExperiment, true, 16>), ggrid, gblock, 0, stream, mesh, fr, rl);
-            else            hipLaunchKernelGGL((k_tri_spans_grouped<NoExperiment, false, 16>), ggrid, gblock, 0, stream, mesh, fr, rl);
+            if (rl.compact) hipLaunchKernelGGL((k_tri_spans_grouped<true, 16>), ggrid, gblock, 0, stream, mesh, fr, rl);
+            else            hipLaunchKernelGGL((k_tri_spans_grouped<false, 16>), ggrid, gblock, 0, stream, mesh, fr, rl);
         }
         return;
     }
-    if (rl.compact) hipLaunchKernelGGL((k_tri_spans<NoExperiment, true>), grid, block, 0, stream, mesh, fr, rl);
-    else            hipLaunchKernelGGL((k_tri_spans<NoExperiment, false>), grid, block, 0, stream, mesh, fr, rl);
+    if (rl.compact) hipLaunchKernelGGL((k_tri_spans<true>), grid, block, 0, stream, mesh, fr, rl);
+    else            hipLaunchKernelGGL((k_tri_spans<false>), grid, block, 0, stream, mesh, fr, rl);
 }
 
 void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
 {
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
-    const bool rows8 = fr.self_spans == 1 && fr.rows8 && fr.row_group == kRowGroup && !map_out && fr.col_split <= 1;
+    const bool rows8 = fr.self_spans == 1 && fr.rows8 && fr.row_group == kRowGroup && !map_out;
     const int rg = rows8 ? 8 : (fr.row_group == kRowGroup ? kRowGroup : 1);
     const int nx = 1 << fr.xcc_log2;                                            // XCCs of this device (partition mode), hg_create
     const int rpx = ((fr.max_obj_h + rg - 1) / rg + nx - 1) / nx;               // row groups per XCD band
-    dim3 grid((unsigned)rpx * (unsigned)nx * (unsigned)fr.n_frames * (unsigned)std::max(fr.col_split, 1));
+    dim3 grid((unsigned)rpx * (unsigned)nx * (unsigned)fr.n_frames);
     // bounds :1047 on the high dwords of the rounded coordinates (hg_dev.h) whenever the source window allows it; the fp64
     // compares otherwise (negative source minimum, sources beyond 2^20 pixels a side) and in the parity-tap instantiations
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-    // one-row workgroups of a SMALL frame set may run with 2 waves instead of 4 (option rows1_threads; measured round 3: no gain)
-    const dim3 block(rg == 1 && fr.rows1_threads == 128 ? 128 : 256);
+    const dim3 block(256);
     const size_t pad = (size_t)fr.lds_pad_kb * 1024;
-#define HG_ROWS(CAP, MAPF, PHV, CMP, HB, SF) hipLaunchKernelGGL((k_pw_rows<CAP, NoExperiment, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
+#define HG_ROWS(CAP, MAPF, PHV, CMP, HB, SF) hipLaunchKernelGGL((k_pw_rows<CAP, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
 #define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true, 0); else HG_ROWS(CAP, false, 1, CMP, false, 0); } while (0)
     if (rows8) {
         if (hib) hipLaunchKernelGGL((k_pw_rows8<4, true>), grid, dim3(512), pad, stream, mesh, fr, rl, out, rpx, status_next);
@@ -1023,7 +1000,7 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
         switch (fr.phase) {
         case 4:  HG_ROWS(kRowSpanCapFast, false, 4, false, true, 1); break;
         case 2:
-            if (fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true, 1>), grid, block, pad, stream,
+            if (fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, false, 2, false, true, 1>), grid, block, pad, stream,
                                                 mesh, fr, rl, out, map_out, rpx, rg, status_next);
             else HG_ROWS(kRowSpanCapFast, false, 2, false, true, 1);
             break;
@@ -1041,15 +1018,10 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
         if (fr.phase >= 2) HG_ROWS_B(kRowSpanCapFast, 2, true); else HG_ROWS_B(kRowSpanCapFast, 1, true);     // (no 4-window instantiation here)
         return;
     }
-#ifdef HG_EXPERIMENTS
-    // Timing experiments of EXPERIMENTS.md (ablated variants produce WRONG pixels): only in the separate experiments build
-    // (`make experiments` -> lib/libhgwarp_exp.so); the shipped library has neither the instantiations nor the switch.
-    if (launch_pw_rows_ablated(mesh, fr, rl, out, map_out, rpx, rg, status_next, grid, stream)) return;     // experiments/hg_ablate.h
-#endif
     switch (fr.phase) {
     case 4:  HG_ROWS_B(kRowSpanCapFast, 4, false); break;
     case 2:
-        if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, NoExperiment, false, 2, false, true, false>), grid, block, pad, stream,
+        if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, false, 2, false, true, false>), grid, block, pad, stream,
                                                    mesh, fr, rl, out, map_out, rpx, rg, status_next);
         else HG_ROWS_B(kRowSpanCapFast, 2, false);
         break;

@@ -41,9 +41,6 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
     // the OTHER counter set, every row of the frame's block: clean for the next step (ping-pong, see k_pw_rows; the band counters live there)
     if (ct == 0 && (int)threadIdx.x < kTileRows && r0 + (int)threadIdx.x < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + threadIdx.x] = 0;
     if (r0 >= fd.obj_h || fd.obj_w <= 0 || t0 >= fd.obj_w) return;
-#if defined(HG_TILE_EXP) && HG_TILE_EXP == 6                     // timing experiment: the launch alone
-    if (fd.obj_w > 0) return;
-#endif
 
     __shared__ __align__(16) double s_rec[(kTileRecs + 1) * 6];               // {m0, m2, m4, m1, m3, m5} per candidate entry; last = NaN record
     __shared__ uint32_t s_lohi[kTileRows * kTileSpanPitch];                          // span cells [lo, hi) of the row, relative to the tile's first column
@@ -118,9 +115,6 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
     }
     __syncthreads();
     const int nc = s_ncand;
-#if defined(HG_TILE_EXP) && HG_TILE_EXP == 4                     // timing experiment: launch + LDS init + candidate scan alone
-    if (nc >= 0) return;
-#endif
     if (nc > kTileRecs) { if (threadIdx.x == 0) s_fail = 1 | (nc << 8); }
     // ---- (2) spans: 8 lanes per candidate entry, one source row each (predictXLimits :1172-1197 + the fill() indices :1124, the lean
     // form of span_cells: see k_pw_rows<SELF>); pieces cut at output-row boundaries, then to the tile's columns
@@ -184,9 +178,6 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
         }
     }
     __syncthreads();
-#if defined(HG_TILE_EXP) && HG_TILE_EXP == 5                     // timing experiment: ... + the spans and bins
-    if (nc >= 0) return;
-#endif
     // ---- (3) limits: every thread reads the eight row counts (no further barrier)
     int fail = s_fail;
 #pragma unroll
@@ -264,11 +255,7 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
                 const bool inb = HIB ? hi_inb(hb, h[2 * k], h[2 * k + 1])
                                      : (bool)((int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi));   // :1047 (NaN fails)
                 const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
-#if defined(HG_TILE_EXP) && HG_TILE_EXP == 1                     // timing experiment (tools/variants.sh): no source traffic
-                px[4 * half + k] = __builtin_amdgcn_raw_buffer_load_b32(src, (inb && o == 0x7fffffffu) ? o : 0xffffffffu, 0, 0);
-#else
                 px[4 * half + k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
-#endif
             }
         }
     };
@@ -284,11 +271,7 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
 #pragma unroll
         for (int rw = 0; rw < kTileRows; rw++) {
             const uint32_t v = tile[rw * kTilePitch + lane];
-#if defined(HG_TILE_EXP) && HG_TILE_EXP == 2                     // timing experiment: no output traffic (the stores are issued and rejected)
-            __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && rw < nrows && v == 0x12345678u) ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
-#else
             __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && rw < nrows) ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
-#endif
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -312,9 +295,6 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
         sl = fminf(fmaxf(sl, -1.f), 1.f);
         return (int)rintf(sl * (float)c);
     };
-#if defined(HG_TILE_EXP) && HG_TILE_EXP == 3                     // timing experiment: the prologue alone
-    if (s_fail == 0) return;
-#endif
     // this wave's blocks: wave, wave + 4, ...; kTilePB of them in flight before the first is transposed and stored
     for (int blk = wave; blk < nblk; blk += 4 * kTilePB) {
         uint32_t px[kTilePB][8];

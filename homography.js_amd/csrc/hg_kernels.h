@@ -68,8 +68,6 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t xcc_rotate;             // 1: XCD x takes band (x + frame) mod XCCs instead of band x (uneven rows, or no source shared between frames)
     int32_t xcc_log2;               // log2 of the device's XCC count (8 on an unpartitioned MI355X): block id -> XCD row band
     int32_t patch_blocks;           // k_pw_patch: 64-pixel column blocks per gather / store phase (1, 2, 4, 8)
-    int32_t rows1_threads;          // k_pw_rows with one row per workgroup: 256 threads, or 128 for small frame sets (more workgroups resident)
-    int32_t col_split;              // k_pw_rows: workgroups per row group, each with a contiguous share of the windows (small frame sets)
     int32_t lds_pad_kb;             // option "lds_pad": KB of unused dynamic LDS per k_pw_rows workgroup (caps the workgroups resident per CU)
     int32_t lds_pad_patch_kb;       // the same for k_pw_patch / k_pw_tile (explicit option only: they lose with fewer workgroups)
     int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only

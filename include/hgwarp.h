@@ -361,11 +361,6 @@ long hg_layout_walks(hg_ctx *ctx);
  *           rows differ in cost or the frames share no source; 0: fixed bands (a shared source's band stays in that XCD's L2);
  *   "xcc" (default: hipDeviceAttributeNumberOfXccs of the device, 8 on an unpartitioned MI355X): number of XCCs the
  *           block id -> row band mapping of the warp kernels assumes; a power of two in 1..64;
- *   "sgpr_cap" (default -1 = only with a shared source): 1 / 0: the k_pw_rows instantiation held to 80 scalar registers (8 instead
- *           of 7 workgroups per CU) for the 2-windows-per-phase layout / never;
- *   "tri_threads" (default -1 = by the triangles' height and the set size): 64, 128 or 256 threads per k_tri_spans workgroup;
- *   "rows1_threads" (default -1 = 256): 128 or 256 threads per one-row k_pw_rows workgroup (small frame sets);
- *   "col_split" (default -1 = 1): 1, 2 or 4 k_pw_rows workgroups per row group, each taking a contiguous share of its windows;
  *   "lds_pad" (default -1 = 12-16 KB with one source per frame on 4-row groups, else 0): KB of unused dynamic LDS per k_pw_rows
  *           workgroup, 0..40: fewer, deeper-queued workgroups per CU where the kernel is HBM-bound;
  *   "upload_kernel" (default -1 = on): frame-set blocks of up to 1 MB go from their page-locked staging slot to the device by a small kernel
