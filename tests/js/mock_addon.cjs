@@ -7,7 +7,7 @@
 // native layer for the right thing.  That the native layer then computes it bit-exactly is what the `-m gpu` parity tests prove.
 'use strict';
 const path = require('path');
-const real = require(path.join(__dirname, '..', '..', 'homography.js_amd', 'lib', 'hgwarp.node'));
+const real = require(process.env.HGWARP_REAL_ADDON || path.join(__dirname, '..', '..', 'homography.js_amd', 'lib', 'hgwarp.node'));
 const core = require(path.join(__dirname, '..', '..', 'oracle', 'hg_oracle_core.cjs'));
 
 const calls = [];                                            // names of the device entry points hit, in order (the fuzzer reads and clears it)

@@ -15,7 +15,10 @@ const HERE = path.dirname(fileURLToPath(import.meta.url));
 const G = JSON.parse(fs.readFileSync(path.join(HERE, '..', 'golden', 'golden.json'), 'utf8'));
 const BLOBS = fs.readFileSync(path.join(HERE, '..', 'golden', 'golden_blobs.bin'));
 const dry = process.argv.includes('--dry');
-if (dry) process.env.HGWARP_ADDON = path.join(HERE, 'mock_addon.cjs');
+if (dry) {                                                // (an addon chosen by the caller -- the sanitizer build -- stays the one behind the mock's host functions)
+    if (process.env.HGWARP_ADDON) process.env.HGWARP_REAL_ADDON = process.env.HGWARP_ADDON;
+    process.env.HGWARP_ADDON = path.join(HERE, 'mock_addon.cjs');
+}
 const only = process.argv.find((a) => a.startsWith('--only='));
 const skipBig = process.argv.includes('--skip-big');
 
