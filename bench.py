@@ -405,8 +405,10 @@ def measure(args, config, F, env, primary=True):
         rf = roofline_block(k_ms, k_launches, "shared", elapsed)
         comp = compulsory_bytes_shared / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         rf["hbm_compulsory_frac"] = round(comp / HBM_PEAK_GBS, 4)
-        rf["note"] += ("; all frames share ONE source, whose reads are largely served by L2 / the 256 MiB Infinity Cache: "
-                       "hbm_compulsory_frac prices only what must cross HBM (every output byte once + the source once); "
+        rf["note"] += ("; all frames share ONE source, whose reads are largely served by L2 / the 256 MiB Infinity Cache, so the ALGORITHMIC "
+                       "rate (SURVEY.md 8d: the source read is counted per frame) can exceed the HBM peak -- frac > 1 then says 'faster than a "
+                       "kernel that fetched every source pixel from HBM could be', not 'HBM at more than 100 %': hbm_compulsory_frac prices only "
+                       "what must cross HBM (every output byte once + the source once) and `traffic` is what did (PMC); "
                        "roofline_distinct is the layout where algorithmic bytes are HBM bytes")
         res["shared"] = (elapsed, rf)
         if not args.no_verify:                      # the bytes the timed kernels wrote (untimed checks)

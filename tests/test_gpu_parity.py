@@ -1042,6 +1042,85 @@ def test_self_span_path_policy_flags_and_falls_back():
         c.close()
 
 
+def test_reference_state_entry_points_match_oracle_on_fresh_seeds():
+    """hg_warp_inverse_piecewise_state / hg_warp_forward_piecewise_state (the reference's loops over its STALE caches)
+    against the oracle's own pieces on random inputs: matrices solved from one pair of point sets, the map rasterised from ANOTHER point set /
+    triangle list / window (smaller and larger than the source bounding box the forward loop indexes it with, offset windows, folded meshes),
+    an empty map, and a map that names more triangles than there are matrices (-> HG_ERR_RANGE, the reference's TypeError)."""
+    rng = np.random.default_rng(20250)
+    c = HG.Context(0)
+    try:
+        n_fwd = n_inv = n_range = 0
+        for trial in range(70):
+            W, H = int(rng.integers(40, 300)), int(rng.integers(30, 200))
+            nx, ny = int(rng.integers(1, 7)), int(rng.integers(1, 6))
+            img = G.lcg_image(W, H, 900 + trial)
+            sp = WL.grid_points(W, H, nx, ny).reshape(-1, 2).astype(np.float64)
+            sp = (sp * rng.uniform(0.6, 1.0) + rng.uniform(0, 12, 2)).astype(np.float32)          # source mesh somewhere inside the image
+            tris = WL.grid_triangles(nx, ny)
+
+            def points(scale_lo, scale_hi):
+                jit = rng.uniform(0, 0.3)
+                d = (sp.astype(np.float64) + rng.uniform(-jit, jit, sp.shape) * [W / nx, H / ny]) * rng.uniform(scale_lo, scale_hi, 2) + rng.uniform(-15, 25, 2)
+                if rng.random() < 0.3:
+                    d[rng.integers(0, d.shape[0])] += rng.uniform(-40, 40, 2)                       # a fold
+                return d.astype(np.float32).ravel()
+
+            dst_pm, dst_map, dst_now = points(0.5, 1.6), points(0.5, 1.8), points(0.7, 1.1)
+            mats = HG.solve_affine_triangles(sp.ravel(), dst_pm, tris)
+            assert _nan_eq(mats.ravel(), O.piecewise_matrices(sp.ravel(), dst_pm, tris).ravel())
+            mm = [int(v) for v in O.minmax_xy(sp.ravel())]
+            c.set_image(img)
+            # --- forward loop over a stale INVERSE map (what a forward warp after an inverse one reads)
+            gm = WL.piecewise_geom(dst_map)                          # the window of the inverse warp that left the map
+            mw, mh, myo = (0, 0, 0) if trial % 9 == 0 else (gm[2], gm[3], gm[1])
+            tris_map = tris[:3 * max(1, tris.size // 3 - int(rng.integers(0, 3)))] if trial % 4 == 1 else tris
+            geom = WL.piecewise_geom(dst_now)
+            held = O.build_tri_map(dst_map, tris_map, mw, myo, mw * mh) if mw * mh > 0 else np.zeros(0, np.int16)
+            cells = max(mm[2] - mm[0], 0) * max(mm[3] - mm[1], 0)
+            eff = np.full(max(cells, 1), -1, np.int16)
+            eff[:min(held.size, cells)] = held[:min(held.size, cells)]
+            n_mats = tris.size // 3 if trial % 7 else max(1, tris.size // 3 - 2)                   # sometimes fewer matrices than the map's ids
+            too_few = bool(eff[:min(held.size, cells)].max(initial=-1) >= n_mats)
+            try:
+                got = c.warp_forward_piecewise_state(mats[:n_mats], dst_map, tris_map, mw, mh, myo, mm[0], mm[1], mm[2], mm[3], geom)
+                assert not too_few, trial
+                want = O.warp_forward_piecewise(eff, mats[:n_mats], img, mm[0], mm[1], mm[2], mm[3], *geom)
+                assert np.array_equal(got, want), (trial, "forward state")
+                n_fwd += 1
+            except HG.HgError as e:
+                assert too_few and e.code == 6, (trial, str(e))
+                n_range += 1
+            # --- inverse loop with stale matrices over the map of the current destiny points
+            gi = WL.piecewise_geom(dst_now)
+            imap = O.build_tri_map(dst_now, tris_map, gi[2], gi[1], gi[2] * gi[3])
+            too_few = bool(imap.max(initial=-1) >= n_mats)
+            try:
+                got = c.warp_inverse_piecewise_state(mats[:n_mats], dst_now, tris_map, mm[0], mm[1], gi)
+                assert not too_few, trial
+                inv = np.stack([O.inverse_affine(m) for m in mats[:n_mats]])
+                want = O.warp_inverse_piecewise_loop(imap, inv, img, mm[0], mm[1], *gi)
+                assert np.array_equal(got, want), (trial, "inverse state")
+                n_inv += 1
+            except HG.HgError as e:
+                assert too_few and e.code == 6, (trial, str(e))
+                n_range += 1
+        assert n_fwd >= 40 and n_inv >= 40 and n_range >= 3, (n_fwd, n_inv, n_range)
+        # the usual entry points of the context are untouched by the state calls
+        sp0, tr0 = WL.grid_points(128, 96, 4, 3), WL.grid_triangles(4, 3)
+        dp0 = WL.sin_dst(sp0, 3.0, 8)
+        g0 = WL.piecewise_geom(dp0)
+        img0 = G.lcg_image(128, 96, 4)
+        c.set_image(img0)
+        c.piecewise_set_mesh(sp0, tr0, 0, 0)
+        c.piecewise_prepare(dp0, g0)
+        first = c.warp_inverse_piecewise()
+        c.warp_forward_piecewise_state(HG.solve_affine_triangles(sp0, dp0, tr0), dp0, tr0, g0[2], g0[3], g0[1], 0, 0, 128, 96, g0)
+        assert np.array_equal(c.warp_inverse_piecewise(), first) and np.array_equal(first, O.warp_inverse_piecewise(sp0, dp0, tr0, img0, 0, 0, *g0))
+    finally:
+        c.close()
+
+
 def test_general_path_between_two_banded_fast_path_sets():
     """A context that ran the self-span path WITH candidate bands (a mesh beyond 256 triangles on k_pw_patch<SELF>), then a frame set
     the fast kernels do not take (source minimum beyond 2^22: k_pw_fused through k_tri_setup alone) with MORE frames and TALLER windows

@@ -22,7 +22,7 @@ published = {  # README.md:270-328, "rest of frames" ms on an i5-7500 / Chrome 9
 }
 
 def timeit(f, n=200):
-    for _ in range(10): f()
+    for _ in range(40): f()                              # (past the one-time buffer growth and layout walk of a new mesh / window shape)
     ctx.sync(); t0 = time.perf_counter()
     for _ in range(n): f()
     ctx.sync()
