@@ -136,7 +136,7 @@ extern "C" int hg_warp_inverse_geometric_frames_device(hg_ctx *c, void *d_out)
     launch_geo(c->geo_kind, c->geo_f32_exact, c->d_geo_frames, c->d_mats, (int)c->geo_frames.size(), mw, mh, c->d_img, c->W, c->H,
                c->n_imgs, (uint64_t)c->img_stride, static_cast<uint8_t *>(d_out),
                (c->geo_from_points && c->geo_kind == HG_PROJECTIVE) ? c->d_geo_plain : nullptr, c->opt_geo_nw,
-               c->n_imgs > 1 ? 0 : c->xcc_log2,              // (one source per frame: plain block order measured faster, 0.234 -> 0.199 ms on C2)
+               c->xcc_log2, c->opt_xcc_rotate >= 0 ? c->opt_xcc_rotate != 0 : c->n_imgs > 1,   // (XCD bands; rotating with the frame when every frame reads its own source)
                c->stream);
     HG_TRY(time_end(c));
     HIP_TRY(c, hipGetLastError());

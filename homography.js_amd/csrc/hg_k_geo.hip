@@ -3,6 +3,7 @@
 // source selection is bit-identical to the reference's JS doubles.
 // Citations are file:line into the reference's Homography.js (v1.8.0).  Design notes: DESIGN.md §4.
 #include "hg_dev.h"
+#include <type_traits>
 
 namespace hg {
 
@@ -100,14 +101,17 @@ __global__ void k_selftest_division(uint64_t seed, uint64_t n_per_thread, unsign
 template <int KIND, int NW>
 __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ frames, const double *__restrict__ mats,
                                                   const uint8_t *__restrict__ img0, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *__restrict__ out,
-                                                  const int32_t *__restrict__ plain, int xcc_log2, int groups_per_xcd, int chunks)
+                                                  const int32_t *__restrict__ plain, int xcc_log2, int groups_per_xcd, int chunks, int rotate)
 {
     // 1-D grid decoded like k_pw_rows': XCD x (= block id % number of XCCs) walks a contiguous band of 4-row groups of one frame, so
     // that vertically adjacent output rows -- which share source cache lines wherever the map is not an exact row copy -- meet in
     // ONE L2 instead of being fetched by up to 8 of them (round 3: fabric reads of C2 with one source per frame 1.39 x algorithmic before).
     const int bid = blockIdx.x, xcd = bid & ((1 << xcc_log2) - 1), bi = bid >> xcc_log2;
     const int chunk = bi % chunks, bj = bi / chunks;
-    const int fz = bj / groups_per_xcd, rgroup = xcd * groups_per_xcd + (bj - fz * groups_per_xcd);
+    // `rotate` (one source per frame): XCD x takes band (x + frame) mod XCCs.  C2's top and bottom bands miss the source on a third of
+    // their pixels -- with fixed bands the XCDs holding the middle of every frame finish last (0.220 ms against 0.195 in plain block order);
+    // rotated, the bands' HBM reads stay at 1.03 x the lines the frame touches (plain order 1.40 x) and the kernel takes 0.188 ms.
+    const int fz = bj / groups_per_xcd, band = (xcd + (rotate ? fz : 0)) & ((1 << xcc_log2) - 1), rgroup = band * groups_per_xcd + (bj - fz * groups_per_xcd);
     const FrameDesc fd = frames[fz];
     const uint8_t *__restrict__ img = n_imgs > 1 ? img0 + (uint64_t)(fz % n_imgs) * img_stride : img0;
     // one wave per row of the block.  threadIdx.y is the same in all 64 lanes of a wave, but the compiler cannot know: made scalar
@@ -134,35 +138,42 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
     const bool use_plain = KIND == 4 && __builtin_amdgcn_readfirstlane(plain[fz]) != 0;
     // NW windows per wave, gathers of all of them issued before the first store (see k_pw_rows: loads and stores share vmcnt)
     uint32_t px[NW][4];
+    // (the plain / IEEE choice of KIND 4 is wave-uniform: taken once around the whole gather loop, not once per pixel -- the per-pixel
+    // form kept every pixel's dependent chain behind a scalar branch)
+    auto gather = [&](auto plain_tag) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;
 #pragma unroll
-    for (int p = 0; p < NW; p++) {
-        const int c0 = cb + p * 256;
-        if (c0 >= OW) break;                               // wave-uniform
-        double h[8], rd[8];
+        for (int p = 0; p < NW; p++) {
+            const int c0 = cb + p * 256;
+            if (c0 >= OW) break;                           // wave-uniform
+            double h[8], rd[8];
+            const double x0 = (double)(c0 + lane + fd.x_off);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double x = (double)(c0 + lane + k * 64 + fd.x_off);
-            if (KIND == 0) {                               // f32-valued matrix: exact product, fma == mul then add
-                h[2 * k] = fma(m[0], x, cx) + m[4];
-                h[2 * k + 1] = fma(m[1], x, cy) + m[5];
-            } else if (KIND == 2) {                        // arbitrary doubles: keep both roundings
-                h[2 * k] = ((m[0] * x) + cx) + m[4];
-                h[2 * k + 1] = ((m[1] * x) + cy) + m[5];
-            } else {
-                const double den = ((m[6] * x) + ad) + 1.0;
-                const double nx = ((m[0] * x) + cx) + m[2], ny = ((m[3] * x) + cy) + m[5];
-                if (KIND == 3 || (KIND == 4 && use_plain)) div2_plain(nx, ny, den, h[2 * k], h[2 * k + 1]);     // same bits, one reciprocal (proved range)
-                else { h[2 * k] = nx / den; h[2 * k + 1] = ny / den; }
+            for (int k = 0; k < 4; k++) {
+                const double x = x0 + (double)(k * 64);    // (exact: integers far below 2^53)
+                if (KIND == 0) {                           // f32-valued matrix: exact product, fma == mul then add
+                    h[2 * k] = fma(m[0], x, cx) + m[4];
+                    h[2 * k + 1] = fma(m[1], x, cy) + m[5];
+                } else if (KIND == 2) {                    // arbitrary doubles: keep both roundings
+                    h[2 * k] = ((m[0] * x) + cx) + m[4];
+                    h[2 * k + 1] = ((m[1] * x) + cy) + m[5];
+                } else {
+                    const double den = ((m[6] * x) + ad) + 1.0;
+                    const double nx = ((m[0] * x) + cx) + m[2], ny = ((m[3] * x) + cy) + m[5];
+                    if (PLAIN) div2_plain(nx, ny, den, h[2 * k], h[2 * k + 1]);     // same bits, one reciprocal (proved range)
+                    else { h[2 * k] = nx / den; h[2 * k + 1] = ny / den; }
+                }
+            }
+            round_x8(h, rd);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool inb = hi_inb(hb, h[2 * k], h[2 * k + 1]);                                     // :1001 (NaN fails)
+                const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2)); // :1005
+                px[p][k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
             }
         }
-        round_x8(h, rd);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const bool inb = hi_inb(hb, h[2 * k], h[2 * k + 1]);                                     // :1001 (NaN fails)
-            const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2)); // :1005
-            px[p][k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
-        }
-    }
+    };
+    if (KIND == 3 || (KIND == 4 && use_plain)) gather(std::true_type{}); else gather(std::false_type{});
 #pragma unroll
     for (int p = 0; p < NW; p++) {
         const int c0 = cb + p * 256;
@@ -173,18 +184,19 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
 }
 
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
-                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, int xcc_log2, hipStream_t stream)
+                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, int xcc_log2, bool rotate_bands, hipStream_t stream)
 {
+    const int rotate = rotate_bands ? 1 : 0;
     if (n_frames <= 0 || max_w <= 0 || max_h <= 0) return;
     const bool fast = ((int64_t)H + 2) * W * 4 < ((int64_t)1 << 31) && hi_bounds_ok(0, W, 0, H) && max_w < (1 << 28);
     if (fast) {
         const int NW = nw == 1 ? 1 : (nw == 2 ? 2 : (nw >= 8 ? 8 : 4));        // windows per wave (measured on C2, 1 -> 2 -> 4: 0.198 -> 0.177 -> 0.171 ms; round 3, 4 -> 8: 0.162 -> 0.153, one source per frame 0.219 -> 0.199)
         const int nx = 1 << xcc_log2, chunks = (max_w + 256 * NW - 1) / (256 * NW), gpx = ((max_h + 3) / 4 + nx - 1) / nx;
         dim3 grid((unsigned)chunks * (unsigned)gpx * (unsigned)nx * (unsigned)n_frames);
-#define HG_GEO(K) do { if (NW == 1) hipLaunchKernelGGL((k_geo_fast<K, 1>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks); \
-                       else if (NW == 4) hipLaunchKernelGGL((k_geo_fast<K, 4>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks); \
-                       else if (NW == 8) hipLaunchKernelGGL((k_geo_fast<K, 8>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks); \
-                       else hipLaunchKernelGGL((k_geo_fast<K, 2>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks); } while (0)
+#define HG_GEO(K) do { if (NW == 1) hipLaunchKernelGGL((k_geo_fast<K, 1>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks, rotate); \
+                       else if (NW == 4) hipLaunchKernelGGL((k_geo_fast<K, 4>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks, rotate); \
+                       else if (NW == 8) hipLaunchKernelGGL((k_geo_fast<K, 8>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks, rotate); \
+                       else hipLaunchKernelGGL((k_geo_fast<K, 2>), grid, dim3(64, 4), 0, stream, frames, mats, img, W, H, n_imgs, img_stride, out, plain, xcc_log2, gpx, chunks, rotate); } while (0)
         if (kind == 1 && plain) HG_GEO(4);
         else if (kind == 1 && f32_exact) HG_GEO(3);
         else if (kind == 1) HG_GEO(1);

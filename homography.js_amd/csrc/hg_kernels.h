@@ -144,7 +144,7 @@ void launch_fill_i32(int32_t *p, size_t n, int32_t v, hipStream_t stream);      
 // f32_exact: every affine matrix entry is a float value and |x| < 2^28 (lets the kernel use an exact-product fma).
 // n_imgs / img_stride: frame f reads the source at img + (f % n_imgs) * img_stride.
 void launch_geo(int kind, bool f32_exact, const FrameDesc *frames, const double *mats, int n_frames, int max_w, int max_h,
-                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, int xcc_log2, hipStream_t stream);
+                const uint8_t *img, int W, int H, int n_imgs, uint64_t img_stride, uint8_t *out, const int32_t *plain, int nw, int xcc_log2, bool rotate_bands, hipStream_t stream);
 // Per-frame matrix solves on the device (one lane per frame): kind 1 = projective 8x8 DLT in numeric.js' LU order, 4 points
 // per set; kind 0 = affine closed form, 3 points per set.  mats = F x 8 doubles; plain[f] = 1 where the projective frame's
 // window stays in the plain division range (launch_geo then takes the per-frame flag instead of a host proof).
