@@ -701,6 +701,55 @@ def test_one_source_per_frame(ctx):
         ctx.free(d_src)
 
 
+def test_geometric_frame_sets_of_uneven_frames_on_their_own_sources(ctx):
+    """k_geo_fast's XCD bands rotate with the frame when every frame reads its own source: frame sets whose frames differ in size by two
+    orders of magnitude (rows past a frame's end, bands a small frame does not reach), affine and projective, with each rotation setting."""
+    W, H, NI = 320, 200, 4
+    imgs = [G.lcg_image(W, H, 300 + k) for k in range(NI)]
+    stride = W * H * 4 + 256
+    rng = np.random.default_rng(5)
+    d_src = ctx.alloc(stride * NI)
+    try:
+        for k in range(NI):
+            ctx.to_device(d_src, imgs[k], k * stride)
+        ctx.set_images_device(d_src, W, H, NI, stride)
+        for kind in (0, 1):
+            mats, geoms = [], []
+            for f in range(11):
+                sc = [1.0, 0.04, 0.6, 2.3, 0.015, 1.3, 0.3, 3.1, 0.9, 0.11, 1.7][f]
+                if kind == 0:
+                    s = np.array([0, 0, 0, H, W, 0], np.float32)
+                    d = (np.array([3, 2, 10, H, W, 7], np.float32) * np.float32(sc) + rng.uniform(-2, 2, 6).astype(np.float32)).astype(np.float32)
+                    fwd = HG.solve_affine(s, d).astype(np.float64); inv = HG.solve_affine(d, s).astype(np.float64)
+                    lim = HG.transform_limits(0, fwd, W, H)
+                    mats.append(np.concatenate([inv, [0.0, 0.0]]))
+                else:
+                    s = WL.corners(W, H)
+                    d = (WL.projective_dst(W, H, 0.01 * f) * np.float32(sc)).astype(np.float32)
+                    lim = HG.transform_limits(1, HG.solve_projective(s, d), W, H)
+                    mats.append(HG.solve_projective(d, s))
+                geoms.append(tuple(int(v) for v in lim))
+            offs, total = HG.pack_offsets(geoms)
+            d_out = ctx.alloc(total)
+            try:
+                want = [O.warp_inverse_geometric(kind, mats[f][:6] if kind == 0 else mats[f], imgs[f % NI], *geoms[f]) for f in range(11)]
+                for rot in (-1, 0, 1):
+                    ctx.set_option("xcc_rotate", rot)
+                    ctx.geometric_set_frames(kind, np.concatenate(mats), geoms, offs)
+                    ctx.warp_inverse_geometric_frames_device(d_out)
+                    ctx.sync()
+                    for f in range(11):
+                        g = geoms[f]
+                        got = ctx.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4)
+                        assert np.array_equal(got, want[f]), (kind, rot, f, g)
+            finally:
+                ctx.set_option("xcc_rotate", -1)
+                ctx.free(d_out)
+    finally:
+        ctx.set_image(imgs[0])
+        ctx.free(d_src)
+
+
 def test_device_side_frame_solves(ctx):
     """hg_geometric_set_frames_points: the inverse matrices are solved on the device at every warp (k_solve_frames, one lane
     per frame, numeric.js LU order).  Bit patterns == host solve == golden vectors; the warped frames == frames warped from

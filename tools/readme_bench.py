@@ -23,10 +23,14 @@ published = {  # README.md:270-328, "rest of frames" ms on an i5-7500 / Chrome 9
 
 def timeit(f, n=200):
     for _ in range(40): f()                              # (past the one-time buffer growth and layout walk of a new mesh / window shape)
-    ctx.sync(); t0 = time.perf_counter()
-    for _ in range(n): f()
-    ctx.sync()
-    return (time.perf_counter() - t0) / n * 1e3
+    best = None
+    for _ in range(3):                                   # best of three passes: a pass that caught a host hiccup (ms-scale, seen on shared boxes) does not count
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(n): f()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / n * 1e3
+        best = dt if best is None else min(best, dt)
+    return best
 
 rows = []
 for size in (200, 400, 800):
