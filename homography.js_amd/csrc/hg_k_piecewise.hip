@@ -3,7 +3,6 @@
 // source selection is bit-identical to the reference's JS doubles.
 // Citations are file:line into the reference's Homography.js (v1.8.0).  Design notes: DESIGN.md §4.
 #include "hg_dev.h"
-#include <type_traits>
 
 namespace hg {
 
@@ -34,7 +33,7 @@ __device__ __forceinline__ bool tri_setup_one(const PwMesh &mesh, const PwFrames
 #pragma unroll
     for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];
     *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
-    *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], affine_fusable(inv, coord_bits(fd.x_off, fd.obj_w), coord_bits(fd.y_off, fd.obj_h)) ? 1.f : 0.f, 0.f);   // [6]: one-fma form admissible (hg_math.h)
+    *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
 
     Seg *sg = fr.segs + ft * 3;
     Seg a, b, c;
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(256) void k_tri_spans(PwMesh mesh, PwFrames fr, Row
 #pragma unroll
         for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];
         *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
-        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], affine_fusable(inv, coord_bits(fd.x_off, fd.obj_w), coord_bits(fd.y_off, fd.obj_h)) ? 1.f : 0.f, 0.f);   // [6]: one-fma form admissible (hg_math.h)
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
         fr.segs[ft * 3] = seg[0]; fr.segs[ft * 3 + 1] = seg[1]; fr.segs[ft * 3 + 2] = seg[2];
         TriRange tr; tr.y_min = y_min; tr.y_end = y_end; tr.a = 0; tr.b = 0;
         fr.trir[ft] = tr;
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh m
 #pragma unroll
         for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];                                 // taps + inputs of the map path
         *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
-        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], affine_fusable(inv, coord_bits(fd.x_off, fd.obj_w), coord_bits(fd.y_off, fd.obj_h)) ? 1.f : 0.f, 0.f);   // [6]: one-fma form admissible (hg_math.h)
+        *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
         fr.segs[ft * 3] = seg[0]; fr.segs[ft * 3 + 1] = seg[1]; fr.segs[ft * 3 + 2] = seg[2];
         TriRange tr; tr.y_min = y_min; tr.y_end = y_end; tr.a = 0; tr.b = 0;
         fr.trir[ft] = tr;
@@ -486,7 +485,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // Record offsets are multiples of 48: the low four bits of a key are free.  Bit 0 = "unsafe": 0 only when BOTH end pixels of the
     // span pass the source bounds test :1047 -- then every pixel between them does (sx, sy are monotone in x: one exact product, two
     // monotone roundings), and a window whose pixels all resolve to such spans runs the pixel body without the bounds test.
-    // Bit 1 = "two roundings": 0 when the span's record holds the one-fma form (put_record below).
     constexpr int KADDR = KMASK & ~15;
 
     const int W = fd.obj_w;
@@ -544,18 +542,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     };
 
     const float *__restrict__ ginv = fr.inv + (size_t)f * mesh.n_tris * kInvStride;
-    // A span's record: {m0, A, m1, B, m4', m5'}.  As filed by load_row / the self-span prologue: (A, B, m4', m5') = (m2*y, m3*y, m4, m5) -- m2*y
-    // and m3*y are the separately rounded products of :1383-1384.  For a triangle whose sums are exact (affine_fusable, hg_math.h; key bit 1
-    // clear) the wave that walks the row rewrites it to (m2*y + m4, m3*y + m5, -0, -0) before its first window (do_row): a window whose pixels
-    // all resolved to such spans computes sx = fma(m0, x, A), sy = fma(m1, x, B) and nothing else (the same bits, one rounding where the
-    // reference's two do not round); any other window adds m4', m5' as always -- adding -0 changes no value, so mixed windows need no
-    // per-pixel choice.  (Not in the prologue itself: two more live doubles there cost the kernel a wave per SIMD.)
-    auto put_record = [&](int at, double m0, double m1, double m2y, double m3y, double m4, double m5) {
-        double2 *mrec = reinterpret_cast<double2 *>(s_m + at * 6);
-        mrec[0] = make_double2(m0, m2y);
-        mrec[1] = make_double2(m1, m3y);
-        mrec[2] = make_double2(m4, m5);
-    };
     // row `row` of the group -> LDS slots [base, base + cnt) (+ a NaN record in slot base + nan_slot that pixels without a
     // triangle point at); threads t0, t0 + step, ... of the caller's thread set do the copying
     auto load_row = [&](int row, int cnt, int base, int nan_slot, int t0, int step) {
@@ -578,9 +564,11 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
             }
             const int elo = (int)(lh & 0xffffu), ehi = (int)(lh >> 16);
             s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo;
-            // (bit 1 always set: the row lists serve small frame sets, whose launches do not fill the chip -- their records keep the two-rounding form)
-            s_key[base + i] = ((int)id << KS) | ((base + i) * 48) | 2 | span_unsafe(m0, m2 * y, m4, m1, m3 * y, m5, elo, ehi);
-            put_record(base + i, m0, m1, m2 * y, m3 * y, m4, m5);
+            s_key[base + i] = ((int)id << KS) | ((base + i) * 48) | span_unsafe(m0, m2 * y, m4, m1, m3 * y, m5, elo, ehi);
+            double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
+            mrec[0] = make_double2(m0, m2 * y);              // {m0, m2*y, m4, m1, m3*y, m5}: m2*y and m3*y are the separately
+            mrec[1] = make_double2(m4, m1);                  // rounded products of :1383-1384
+            mrec[2] = make_double2(m3 * y, m5);
         }
         if (t0 < 3) reinterpret_cast<double2 *>(s_m + (base + nan_slot) * 6)[t0] = make_double2(NAN, NAN);
     };
@@ -661,8 +649,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
             if (jj >= n) continue;
             const Seg *__restrict__ sg = gseg + (size_t)t * 3;
             const float4 ma = *reinterpret_cast<const float4 *>(ginv + (size_t)t * kInvStride);
-            const float4 mb = *reinterpret_cast<const float4 *>(ginv + (size_t)t * kInvStride + 4);
-            const bool fus = mb.z != 0.f;
+            const float2 mb = *reinterpret_cast<const float2 *>(ginv + (size_t)t * kInvStride + 4);
             for (int j = jj; j < n; j += lpc) {
                 const int ys = ylo + j;
                 const double y = (double)ys;
@@ -711,8 +698,11 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     const double yr = (double)(r + fd.y_off);
                     const double m2y = (double)ma.z * yr, m3y = (double)ma.w * yr;
                     s_lo[at] = lo; s_hi[at] = hi; s_len[at] = hi - lo;
-                    put_record(at, (double)ma.x, (double)ma.y, m2y, m3y, (double)mb.x, (double)mb.y);
-                    s_key[at] = (t << KS) | (at * 48) | (fus ? 0 : 2) | span_unsafe((double)ma.x, m2y, (double)mb.x, (double)ma.y, m3y, (double)mb.y, lo, hi);
+                    s_key[at] = (t << KS) | (at * 48) | span_unsafe((double)ma.x, m2y, (double)mb.x, (double)ma.y, m3y, (double)mb.y, lo, hi);
+                    double2 *mrec = reinterpret_cast<double2 *>(s_m + at * 6);
+                    mrec[0] = make_double2((double)ma.x, m2y);                   // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
+                    mrec[1] = make_double2((double)mb.x, (double)ma.y);
+                    mrec[2] = make_double2(m3y, (double)mb.y);
                 }
             }
         }
@@ -730,7 +720,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // requests per wave are ever in flight.  A streaming copy in the same instruction forms (tools/calib_fetch: 4 loads + 4
     // stores per step 4.7 TB/s, 16 + 16 per step 5.7 TB/s) shows what that costs once the source comes from HBM.
     auto do_row = [&](int row, int cnt, int base, int nan_slot, int w0, int wstep) {
-        const bool wave_owns_row = wstep == 1;              // (packed groups: windows w0, w0 + 1, ... all belong to this wave)
         // "no triangle": smaller than every real key, its low bits address the NaN record
         const int nan_key = (int)0x80000000u | ((base + nan_slot) * 48) | 1;      // (unsafe: its pixels must come out as offset 0xffffffff)
         const int r = r0 + row;
@@ -748,19 +737,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         const bool in_regs = cnt <= 64;                     // wave-uniform
         int lo_r = 0x7fffffff, hi_r = 0, key_r = 0;
         if (in_regs && lane < cnt) { lo_r = s_lo[base + lane]; hi_r = s_hi[base + lane]; key_r = s_key[base + lane]; }
-        // the one-fma form of the records whose triangles admit it (put_record above).  Only where this wave alone walks the row (packed
-        // groups: its 64-slot block is private from here on); rows shared by the four waves keep the two-rounding form for every window.
-        const bool fuse_row = SELF != 0 && wave_owns_row;
-        if (fuse_row) {
-            for (int i = lane; i < cnt; i += 64) {
-                if (s_key[base + i] & 2) continue;
-                double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
-                const double2 ra = mrec[0], rb = mrec[1], rc = mrec[2];
-                mrec[0] = make_double2(ra.x, ra.y + rc.x);
-                mrec[1] = make_double2(rb.x, rb.y + rc.y);
-                mrec[2] = make_double2(-0.0, -0.0);
-            }
-        }
         for (int wb = w0; wb < nwin; wb += wstep * PH) {
             uint32_t px[PH][4];
             bool empty[PH];                                 // wave-uniform
@@ -807,47 +783,21 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     constexpr int STEP = PH == 1 ? 4 : 2;
                     // every pixel of the window resolved to a span whose ends are inside the source window: no bounds test, and Math.round
                     // with one add per coordinate (round_half_x4)
-                    const int flags = best[0] | best[1] | best[2] | best[3];
-                    const bool safe = flag_spans && __ballot((flags & 1) != 0) == 0ull;      // wave-uniform
-                    const bool fused = fuse_row && __ballot((flags & 2) != 0) == 0ull;      // wave-uniform: every record of the window in the one-fma form
-                    // :1383-1384 for pixels k0, k0 + 1 .. of the window.  (m0*x) + (m2*y) + m4: m0*x is exact in fp64 (24-bit f32 significand
-                    // times an integer below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit; FUSED: see put_record.
-                    auto coords = [&](auto n_tag, int k0, double *v) {
-                        constexpr int N = decltype(n_tag)::value;
-                        if constexpr (SELF == 0) {          // (row lists: never fused -- the form this path has always had)
-#pragma unroll
-                            for (int k = 0; k < N; k++) {
-                                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k0 + k] & KADDR));
-                                const double2 ra = mrec[0], rb = mrec[1], rc = mrec[2];
-                                const double xd = xd0 + (double)((k0 + k) * 64);
-                                v[2 * k] = fma(ra.x, xd, ra.y) + rc.x; v[2 * k + 1] = fma(rb.x, xd, rb.y) + rc.y;
-                            }
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < N; k++) {
-                                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k0 + k] & KADDR));
-                                const double2 ra = mrec[0], rb = mrec[1];
-                                const double xd = xd0 + (double)((k0 + k) * 64);
-                                v[2 * k] = fma(ra.x, xd, ra.y); v[2 * k + 1] = fma(rb.x, xd, rb.y);
-                            }
-                            if (!fused) {                   // (wave-uniform branch around 2 N additions and N LDS reads)
-#pragma unroll
-                                for (int k = 0; k < N; k++) {
-                                    const double2 rc = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k0 + k] & KADDR))[2];
-                                    v[2 * k] += rc.x; v[2 * k + 1] += rc.y;
-                                }
-                            }
-                        }
-                    };
-                    typedef std::integral_constant<int, 2> two_t;
-                    typedef std::integral_constant<int, STEP> step_t;
+                    const bool safe = flag_spans && __ballot(((best[0] | best[1] | best[2] | best[3]) & 1) != 0) == 0ull;      // wave-uniform
                     if (safe) {
 #pragma unroll
                         for (int kk = 0; kk < 4; kk += 2) {
                             if (kk == 2 && c0 + 128 >= W) { px[p][2] = px[p][3] = 0u; continue; }
                             double v[4];
                             int r[4];
-                            coords(two_t{}, kk, v);
+#pragma unroll
+                            for (int k = kk; k < kk + 2; k++) {
+                                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KADDR));
+                                const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+                                const double xd = xd0 + (double)(k * 64);
+                                v[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
+                                v[2 * (k - kk) + 1] = fma(m1.y, xd, m2.x) + m2.y;
+                            }
                             round_half_x4(v, r);
 #pragma unroll
                             for (int k = kk; k < kk + 2; k++)
@@ -860,7 +810,16 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                         // stores would be dropped by the range check anyway; wave-uniform test) -- a 2170-pixel row has 2 dead pieces in 36
                         if (STEP == 2 && kk == 2 && c0 + 128 >= W) { px[p][2] = px[p][3] = 0u; continue; }
                         double h[2 * STEP], rd[2 * STEP];
-                        if constexpr (STEP == 4 && SELF != 0) { coords(two_t{}, kk, h); coords(two_t{}, kk + 2, h + 4); } else coords(step_t{}, kk, h);
+#pragma unroll
+                        for (int k = kk; k < kk + STEP; k++) {
+                            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KADDR));
+                            const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
+                            const double xd = xd0 + (double)(k * 64);
+                            // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
+                            // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
+                            h[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
+                            h[2 * (k - kk) + 1] = fma(m1.y, xd, m2.x) + m2.y;
+                        }
                         if constexpr (STEP == 4) round_x8(h, rd); else round_x4(h, rd);
 #pragma unroll
                         for (int k = kk; k < kk + STEP; k++) {

@@ -701,51 +701,6 @@ def test_one_source_per_frame(ctx):
         ctx.free(d_src)
 
 
-def test_rows_with_one_fma_and_two_rounding_spans_side_by_side(ctx):
-    """k_pw_rows<SELF> evaluates a span's coordinates with one fma where the triangle's sums are exact (hg_affine_one_fma_form) and
-    with the reference's two roundings elsewhere; a window takes the short form only when ALL its pixels resolved to such spans.
-    Mesh: a pure translation (every sum exact) in which a few vertices are moved by one ulp -- shears of 2^-23, far too small
-    against the unit scale for exact sums -- so rows cross both kinds of triangle.  Every frame against the oracle, with the self-span
-    kernel forced (min_row_groups = 0) and under the default policy, safe spans on and off."""
-    W = H = 256
-    img = G.lcg_image(W, H, 77)
-    sp, tris = WL.grid_points(W, H, 4, 4), WL.grid_triangles(4, 4)
-    base = (sp.reshape(-1, 2) + np.array([3, 2], np.float32)).astype(np.float32)
-    frames = []
-    for f in range(6):
-        d = base.copy()
-        for v in ((6 + f) % 25, (12 + 2 * f) % 25, 18):                    # vertices nudged by one unit in the last place
-            d[v, f % 2] = np.nextafter(d[v, f % 2], np.float32(1e9), dtype=np.float32)
-        if f == 5: d[7] += np.float32(0.375)                                # + an ordinary deformation
-        frames.append(d.ravel())
-    geoms = [WL.piecewise_geom(d) for d in frames]
-    ms = WL.src_min(sp)
-    # the mesh really holds both kinds
-    kinds = set()
-    for f in range(6):
-        fwd = HG.solve_affine_triangles(sp, frames[f], tris).reshape(-1, 6)
-        kinds |= {HG.affine_one_fma_form(HG.invert_affine(m), geoms[f]) for m in fwd}
-    assert kinds == {True, False}
-    offs, total = HG.pack_offsets(geoms)
-    want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(6)]
-    with HG.Context(0) as c:
-        c.set_image(img); c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
-        d_out = c.alloc(total)
-        try:
-            for mrg in (0, -1):
-                for safe in (1, 0, -1):
-                    if mrg >= 0: c.set_option("min_row_groups", mrg)
-                    c.set_option("safe_spans", safe)
-                    c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
-                    c.warp_inverse_piecewise_frames_device(d_out); c.sync()
-                    for f in range(6):
-                        g = geoms[f]
-                        assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), (mrg, safe, f)
-                    if mrg == 0: assert c.last_piecewise_self() != 0
-        finally:
-            c.free(d_out)
-
-
 def test_geometric_frame_sets_of_uneven_frames_on_their_own_sources(ctx):
     """k_geo_fast's XCD bands rotate with the frame when every frame reads its own source: frame sets whose frames differ in size by two
     orders of magnitude (rows past a frame's end, bands a small frame does not reach), affine and projective, with each rotation setting."""
