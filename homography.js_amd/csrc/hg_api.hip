@@ -61,7 +61,7 @@ extern "C" void hg_destroy(hg_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_img && !c->img_aliased) (void)hipFree(c->d_img);
-    void *ptrs[] = { c->d_src, c->d_tris, c->d_set, c->d_trir, c->d_trix, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_rowcnt, c->d_rowent, c->d_bands,
+    void *ptrs[] = { c->d_src, c->d_tris, c->d_set, c->d_trir, c->d_trix, c->d_segs, c->d_fwd, c->d_inv, c->d_status, c->d_two_round, c->d_rowcnt, c->d_rowent, c->d_bands,
                      c->d_geo_frames, c->d_mats, c->d_geo_pts, c->d_geo_plain, c->d_map32, c->d_fmap, c->d_win32, c->d_fwd_par, c->d_fbbox, c->d_frowoff, c->d_frowext, c->d_ftile_cnt, c->d_fwd_status, c->d_ftile_ent, c->d_map16, c->d_out_tmp };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->h_status) (void)hipHostFree(c->h_status);

@@ -199,7 +199,7 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
         HG_TRY(hg_piecewise_set_frames(c, c->h_src.data(), &gmap, &zero, 1));
         c->status_ptr = c->d_status;
         HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t), c->stream));
-        { PwFrames fr_ = frames_of(c); fr_.band_ent = nullptr; launch_tri_setup(mesh_of(c), fr_, c->stream); }   // (no candidate bands: the forward kernels have their own tile lists)
+        { PwFrames fr_ = frames_of(c); fr_.band_ent = nullptr; fr_.two_round = nullptr; launch_tri_setup(mesh_of(c), fr_, c->stream); }   // (no candidate bands: the forward kernels have their own tile lists)
         HG_TRY(ensure(c, c->d_fmap, c->fmap_cap, n_map));
         launch_map_build(mesh_of(c), frames_of(c), 0, c->pw_frames[0], c->d_fmap, c->stream);
         HG_TRY(ensure(c, c->d_fbbox, c->fbbox_cap, (size_t)4 * std::max(c->n_tris, 1)));
@@ -214,7 +214,7 @@ extern "C" int hg_warp_forward_piecewise_batch_device(hg_ctx *c, const float *ds
     c->pw_quick_layout = false;
     HG_TRY(rc_frames);
     c->status_ptr = c->d_status;                             // (k_tri_setup only ORs flags into these words and nothing on the forward path reads them: not cleared)
-    { PwFrames fr_ = frames_of(c); fr_.band_ent = nullptr; launch_tri_setup(mesh_of(c), fr_, c->stream); }   // (no candidate bands: the forward kernels have their own tile lists)
+    { PwFrames fr_ = frames_of(c); fr_.band_ent = nullptr; fr_.two_round = nullptr; launch_tri_setup(mesh_of(c), fr_, c->stream); }   // (no candidate bands: the forward kernels have their own tile lists)
     c->pw_setup_done = false;
     size_t out_extent = 0;
     uint64_t out_layout = 0;

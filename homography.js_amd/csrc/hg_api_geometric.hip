@@ -9,6 +9,11 @@ extern "C" int hg_projective_plain_range(const double *m, hg_geom geom)
     return (m && geo_plain_division(m, geom)) ? 1 : 0;
 }
 
+extern "C" int hg_affine_one_fma_form(const float inv[6], hg_geom geom)
+{
+    return (inv && affine_fusable(inv, coord_bits(geom.x_off, geom.obj_w), coord_bits(geom.y_off, geom.obj_h))) ? 1 : 0;
+}
+
 extern "C" int hg_selftest_division(hg_ctx *c, uint64_t samples, uint64_t seed, uint64_t *mismatches)
 {
     HG_TRY(bind(c));

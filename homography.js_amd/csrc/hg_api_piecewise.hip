@@ -159,6 +159,7 @@ static int pw_set_frames_impl(hg_ctx *c, const float *dst, const hg_geom *geoms,
     HG_TRY(ensure(c, c->d_fwd, c->fwd_cap, F * T * 6));
     HG_TRY(ensure(c, c->d_inv, c->inv_cap, F * T * kInvStride));
     HG_TRY(ensure(c, c->d_status, c->status_cap, F));
+    HG_TRY(ensure(c, c->d_two_round, c->two_round_cap, F));   // (never cleared: a stale word can only equal the step number by accident, which costs speed, not bits)
     if (!c->h_flag) {
         void *q = nullptr;
         hipError_t e = hipHostMalloc(&q, 64, hipHostMallocDefault);
@@ -296,6 +297,7 @@ PwFrames frames_of(const hg_ctx *c)
     f.host_flag = c->h_flag;                                 // (always armed: whether hg_sync may skip the status ring must not depend on an option that can change while runs are queued)
     f.frames = c->d_pw_frames; f.dst_pts = c->d_dst; f.trir = c->d_trir; f.trix = c->d_trix; f.segs = c->d_segs; f.fwd = c->d_fwd; f.inv = c->d_inv;
     f.status = c->status_ptr ? c->status_ptr : c->d_status; f.n_frames = (int)c->pw_frames.size();
+    f.two_round = c->d_two_round; f.gen = c->pw_gen;
     int mh = 0;
     for (const FrameDesc &d : c->pw_frames) if (d.obj_w > 0) mh = std::max(mh, d.obj_h);
     f.max_obj_h = mh;
@@ -461,6 +463,7 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         c->status_ptr = c->status_base + (size_t)c->status_slot * F;
         c->status_next = c->status_base + (size_t)((c->status_slot + 1) % (int)kStatusRing) * F;
         c->rows_clean = false;                               // dirty until the warp kernel has run: it consumes the counters and clears the next status set
+        if (c->pw_self) c->pw_gen = c->pw_gen >= 0x7ffffff0 ? 1 : c->pw_gen + 1;   // (PwFrames::gen: k_tri_setup and the warp kernel behind it see the same number)
         if (c->pw_self) launch_tri_setup(mesh_of(c), frames_of(c), c->stream);     // solves, edge equations, row reach (+ candidate bands, counted in the row counters' place)
         else            launch_tri_spans(mesh_of(c), frames_of(c), rl, c->stream);
     } else {
@@ -549,6 +552,7 @@ static int redo_frame_staged(hg_ctx *c, int stage, int f, uint8_t *d_out)
     PwMesh mesh = mesh_of(c);
     mesh.img = frame_img(mesh, f); mesh.n_imgs = 1;          // this frame's own source
     PwFrames fr = frames_of(c);
+    fr.two_round = nullptr;                                  // (a set-up of its own, outside the frame set's step numbering)
     fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.host_flag = nullptr; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
     fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
     launch_tri_setup(mesh, fr, c->stream);
@@ -582,6 +586,7 @@ int redo_forward_frame_staged(hg_ctx *c, int stage, int f, int max_src_x, int ma
     HIP_TRY(c, hipMemcpyAsync(c->d_redo_frame, st.h + sizeof(FrameDesc) * (size_t)f, sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_redo_dst, pts, sizeof(float) * 2 * c->n_pts, hipMemcpyHostToDevice, c->stream));
     PwFrames fr = frames_of(c);
+    fr.two_round = nullptr;                                  // (a set-up of its own, outside the frame set's step numbering)
     fr.frames = c->d_redo_frame; fr.dst_pts = c->d_redo_dst; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.host_flag = nullptr; fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd;
     fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
     launch_tri_setup(mesh_of(c), fr, c->stream);

@@ -62,6 +62,7 @@ static int build_state_map(hg_ctx *c, const hg_tri_map_def *map, size_t cells)
     PwMesh mesh = mesh_of(c);
     mesh.src_pts = c->d_st_pts; mesh.tris = c->d_st_tris; mesh.n_pts = map->n_points; mesh.n_tris = map->n_triangles;
     PwFrames fr = frames_of(c);
+    fr.two_round = nullptr;                                  // (a set-up of its own, outside the frame set's step numbering)
     fr.frames = c->d_redo_frame; fr.dst_pts = c->d_st_pts; fr.trir = c->d_redo_trir; fr.trix = c->d_redo_trix; fr.band_ent = nullptr; fr.host_flag = nullptr;
     fr.segs = c->d_redo_segs; fr.fwd = c->d_redo_fwd; fr.inv = c->d_redo_inv; fr.status = c->d_redo_status; fr.n_frames = 1; fr.max_obj_h = fd.obj_h;
     if (map->n_triangles > 0) launch_tri_setup(mesh, fr, c->stream);       // edge equations + row ranges of the map's own triangles (its solves are not used)
@@ -117,6 +118,7 @@ extern "C" int hg_warp_inverse_piecewise_state(hg_ctx *c, const float *fwd_mats,
     PwMesh mesh = mesh_of(c);
     mesh.img = frame_img(mesh, 0); mesh.n_imgs = 1; mesh.min_src_x = msx; mesh.min_src_y = msy; mesh.n_tris = n_mats;
     PwFrames fr = frames_of(c);
+    fr.two_round = nullptr;                                  // (a set-up of its own, outside the frame set's step numbering)
     fr.inv = c->d_st_mats;
     FrameDesc fd; fd.x_off = geom.x_off; fd.y_off = geom.y_off; fd.obj_w = geom.obj_w; fd.obj_h = geom.obj_h; fd.out_off = 0; fd.map_off = 0;
     launch_pw_from_map(mesh, fr, 0, fd, c->d_map32, c->d_out_tmp, c->stream);       // :1042-1056

@@ -53,6 +53,7 @@ struct hg_ctx {
     float *d_fwd = nullptr; size_t fwd_cap = 0;
     float *d_inv = nullptr; size_t inv_cap = 0;
     int32_t *d_status = nullptr; size_t status_cap = 0;
+    int32_t *d_two_round = nullptr; size_t two_round_cap = 0; int32_t pw_gen = 0;   // PwFrames::two_round / gen
     int32_t *status_ptr = nullptr;                             // where this frame set's status words live (d_status, or the tail of d_rowcnt)
     int32_t *h_status = nullptr; size_t h_status_cap = 0;      // pinned
     int32_t *h_flag = nullptr;                                 // pinned, device-visible: set to 1 by any fused kernel that flags a frame (PwFrames::host_flag)

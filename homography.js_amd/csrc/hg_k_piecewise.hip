@@ -3,6 +3,7 @@
 // source selection is bit-identical to the reference's JS doubles.
 // Citations are file:line into the reference's Homography.js (v1.8.0).  Design notes: DESIGN.md §4.
 #include "hg_dev.h"
+#include <type_traits>
 
 namespace hg {
 
@@ -34,6 +35,7 @@ __device__ __forceinline__ bool tri_setup_one(const PwMesh &mesh, const PwFrames
     for (int k = 0; k < 6; k++) fr.fwd[ft * 6 + k] = fwd[k];
     *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride) = make_float4(inv[0], inv[1], inv[2], inv[3]);
     *reinterpret_cast<float4 *>(fr.inv + ft * kInvStride + 4) = make_float4(inv[4], inv[5], 0.f, 0.f);
+    const bool one_fma = affine_fusable(inv, coord_bits(fd.x_off, fd.obj_w), coord_bits(fd.y_off, fd.obj_h));     // (hg_math.h)
 
     Seg *sg = fr.segs + ft * 3;
     Seg a, b, c;
@@ -78,6 +80,9 @@ __device__ __forceinline__ bool tri_setup_one(const PwMesh &mesh, const PwFrames
     }
     if (!regular) fr.trix[ft] = make_int2(0, -1);
     fr.trir[ft] = tr;
+    // a triangle with rows whose sums of :1383 may round twice: the frame keeps the two-rounding pixel body (PwFrames::two_round; plain
+    // store -- every writer of a step writes the same number)
+    if (fr.two_round && !one_fma && tr.y_end > tr.y_min) fr.two_round[f] = fr.gen;      // (nullptr: the single-frame redo / reference-state set-ups, whose consumers never ask)
     return regular;
 }
 
@@ -531,6 +536,12 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // 1 unless both end pixels lo, hi - 1 of a span with record {m0, m2*y, m4, m1, m3*y, m5} are inside the source window, computed as
     // the pixel body computes them (same fma, same rounding, same compares)
     const bool flag_spans = fr.safe_spans != 0;             // (wave-uniform; host: by the rows' span density)
+    // One fma per coordinate for the whole frame: (m0 x) + (m2 y) + m4 of :1383 rounds twice, but where m0 x + m2 y and m2 y + m4 are exactly
+    // representable for every pixel of the window -- k_tri_setup checked every triangle of the frame that has rows (affine_fusable, hg_math.h:
+    // both are multiples of the smallest ulp of the f32 entries involved, bounded by the window) -- fma(m0, x, A) with A = (m2 y) + m4 has the same
+    // bits.  The span records of such a frame hold {m0, A, m1, B}: 32 bytes of LDS per pixel instead of 48, which is what this kernel runs
+    // on (EXPERIMENTS.md R5.8).  Uniform for the workgroup; the row lists (small frame sets) keep the long form.
+    const bool one_fma = SELF != 0 && fr.two_round && __builtin_amdgcn_readfirstlane(fr.two_round[f]) != fr.gen;
     auto span_unsafe = [&](double m0, double m2y, double m4, double m1, double m3y, double m5, int lo, int hi) -> int {
         if (!flag_spans) return 1;
         const double xa = (double)(lo + fd.x_off), xb = (double)(hi - 1 + fd.x_off);
@@ -566,9 +577,9 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
             s_lo[base + i] = elo; s_hi[base + i] = ehi; s_len[base + i] = ehi - elo;
             s_key[base + i] = ((int)id << KS) | ((base + i) * 48) | span_unsafe(m0, m2 * y, m4, m1, m3 * y, m5, elo, ehi);
             double2 *mrec = reinterpret_cast<double2 *>(s_m + (base + i) * 6);
-            mrec[0] = make_double2(m0, m2 * y);              // {m0, m2*y, m4, m1, m3*y, m5}: m2*y and m3*y are the separately
-            mrec[1] = make_double2(m4, m1);                  // rounded products of :1383-1384
-            mrec[2] = make_double2(m3 * y, m5);
+            mrec[0] = make_double2(m0, m2 * y);              // {m0, m2*y, m1, m3*y, m4, m5}: m2*y and m3*y are the separately
+            mrec[1] = make_double2(m1, m3 * y);              // rounded products of :1383-1384
+            mrec[2] = make_double2(m4, m5);
         }
         if (t0 < 3) reinterpret_cast<double2 *>(s_m + (base + nan_slot) * 6)[t0] = make_double2(NAN, NAN);
     };
@@ -700,9 +711,14 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     s_lo[at] = lo; s_hi[at] = hi; s_len[at] = hi - lo;
                     s_key[at] = (t << KS) | (at * 48) | span_unsafe((double)ma.x, m2y, (double)mb.x, (double)ma.y, m3y, (double)mb.y, lo, hi);
                     double2 *mrec = reinterpret_cast<double2 *>(s_m + at * 6);
-                    mrec[0] = make_double2((double)ma.x, m2y);                   // {m0, m2*y, m4, m1, m3*y, m5}, see load_row
-                    mrec[1] = make_double2((double)mb.x, (double)ma.y);
-                    mrec[2] = make_double2(m3y, (double)mb.y);
+                    if (one_fma) {                                               // {m0, A, m1, B}
+                        mrec[0] = make_double2((double)ma.x, m2y + (double)mb.x);
+                        mrec[1] = make_double2((double)ma.y, m3y + (double)mb.y);
+                    } else {                                                     // {m0, m2*y, m1, m3*y, m4, m5}, see load_row
+                        mrec[0] = make_double2((double)ma.x, m2y);
+                        mrec[1] = make_double2((double)ma.y, m3y);
+                        mrec[2] = make_double2((double)mb.x, (double)mb.y);
+                    }
                 }
             }
         }
@@ -783,6 +799,38 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     constexpr int STEP = PH == 1 ? 4 : 2;
                     // every pixel of the window resolved to a span whose ends are inside the source window: no bounds test, and Math.round
                     // with one add per coordinate (round_half_x4)
+                    // :1383-1384 for pixels k0 .. k0 + N - 1 of the window: (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times
+                    // an integer below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit; a one_fma frame's records already hold
+                    // A = (m2*y) + m4 in that place and nothing is added (the branch is uniform for the workgroup)
+                    auto coords = [&](auto n_tag, int k0, double *v) {
+                        constexpr int N = decltype(n_tag)::value;
+                        if constexpr (SELF == 0) {          // (row lists: always the long form)
+#pragma unroll
+                            for (int k = 0; k < N; k++) {
+                                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k0 + k] & KADDR));
+                                const double2 ra = mrec[0], rb = mrec[1], rc = mrec[2];
+                                const double xd = xd0 + (double)((k0 + k) * 64);
+                                v[2 * k] = fma(ra.x, xd, ra.y) + rc.x; v[2 * k + 1] = fma(rb.x, xd, rb.y) + rc.y;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < N; k++) {
+                                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k0 + k] & KADDR));
+                                const double2 ra = mrec[0], rb = mrec[1];
+                                const double xd = xd0 + (double)((k0 + k) * 64);
+                                v[2 * k] = fma(ra.x, xd, ra.y); v[2 * k + 1] = fma(rb.x, xd, rb.y);
+                            }
+                            if (!one_fma) {
+#pragma unroll
+                                for (int k = 0; k < N; k++) {
+                                    const double2 rc = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k0 + k] & KADDR))[2];
+                                    v[2 * k] += rc.x; v[2 * k + 1] += rc.y;
+                                }
+                            }
+                        }
+                    };
+                    typedef std::integral_constant<int, 2> two_t;
+                    typedef std::integral_constant<int, STEP> step_t;
                     const bool safe = flag_spans && __ballot(((best[0] | best[1] | best[2] | best[3]) & 1) != 0) == 0ull;      // wave-uniform
                     if (safe) {
 #pragma unroll
@@ -790,14 +838,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                             if (kk == 2 && c0 + 128 >= W) { px[p][2] = px[p][3] = 0u; continue; }
                             double v[4];
                             int r[4];
-#pragma unroll
-                            for (int k = kk; k < kk + 2; k++) {
-                                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KADDR));
-                                const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                                const double xd = xd0 + (double)(k * 64);
-                                v[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
-                                v[2 * (k - kk) + 1] = fma(m1.y, xd, m2.x) + m2.y;
-                            }
+                            coords(two_t{}, kk, v);
                             round_half_x4(v, r);
 #pragma unroll
                             for (int k = kk; k < kk + 2; k++)
@@ -810,16 +851,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                         // stores would be dropped by the range check anyway; wave-uniform test) -- a 2170-pixel row has 2 dead pieces in 36
                         if (STEP == 2 && kk == 2 && c0 + 128 >= W) { px[p][2] = px[p][3] = 0u; continue; }
                         double h[2 * STEP], rd[2 * STEP];
-#pragma unroll
-                        for (int k = kk; k < kk + STEP; k++) {
-                            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k] & KADDR));
-                            const double2 m0 = mrec[0], m1 = mrec[1], m2 = mrec[2];
-                            const double xd = xd0 + (double)(k * 64);
-                            // :1383-1384  (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times an integer
-                            // below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit: one instruction instead of two.
-                            h[2 * (k - kk)]     = fma(m0.x, xd, m0.y) + m1.x;
-                            h[2 * (k - kk) + 1] = fma(m1.y, xd, m2.x) + m2.y;
-                        }
+                        coords(step_t{}, kk, h);
                         if constexpr (STEP == 4) round_x8(h, rd); else round_x4(h, rd);
 #pragma unroll
                         for (int k = kk; k < kk + STEP; k++) {

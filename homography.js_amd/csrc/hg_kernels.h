@@ -58,6 +58,8 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     float *fwd;                     // F x n_tris x 6
     float *inv;                     // F x n_tris x kInvStride
     int32_t *status;                // F
+    int32_t *two_round;             // F: == gen when k_tri_setup met a triangle (with rows) of the frame whose :1383 sums are not exact (affine_fusable, hg_math.h);
+    int32_t gen;                    //    any other value: the row kernel may use one fma per coordinate for the whole frame.  gen: this step's number (never reset: no clearing pass)
     int32_t *host_flag;             // page-locked, device-visible word set to 1 whenever a kernel flags a frame (nullptr: none): lets hg_sync skip reading the status ring
     int32_t n_frames;
     int32_t max_obj_h;              // max over frames (grid size)

@@ -261,6 +261,45 @@ HG_HD void apply_affine(const double *m, double x, double y, double &ox, double 
     ox = (m[0] * x) + (m[2] * y) + m[4];
     oy = (m[1] * x) + (m[3] * y) + m[5];
 }
+// When may (m0*x) + (m2*y) + m4 of :1383-1384 be computed as ONE fma(m0, x, c) with c = (m2*y) + m4 ?
+// The reference rounds twice: RN(RN(m0 x + m2 y) + m4) (both products are exact in fp64: an f32 value times an integer below 2^28).
+// If (i) m0 x + m2 y is exactly representable, the reference's result is RN(m0 x + m2 y + m4); if (ii) m2 y + m4 is exactly representable,
+// fma(m0, x, c) is RN(m0 x + m2 y + m4) as well: the same bits.  Both sums are integer multiples of 2^g (g = the smallest unit in the last
+// place of the f32 operands involved; x, y are integers) and smaller in magnitude than 2^(top + 1): representable whenever
+// top + 1 <= 53 + g.  lx, ly: |x| <= 2^lx, |y| <= 2^ly for every pixel of the frame (bit lengths of the window's extreme coordinates).
+// Conservative (never says yes wrongly); non-finite entries say no.  Zero entries contribute nothing to either sum.
+HG_HD bool affine_row_fusable(float m0, float m2, float m4, int lx, int ly)
+{
+    union { float f; uint32_t u; } a, b, d;
+    a.f = m0; b.f = m2; d.f = m4;
+    const int ea = (int)((a.u >> 23) & 0xff), eb = (int)((b.u >> 23) & 0xff), ed = (int)((d.u >> 23) & 0xff);
+    if (ea == 255 || eb == 255 || ed == 255) return false;
+    const bool za = (a.u << 1) == 0, zb = (b.u << 1) == 0, zd = (d.u << 1) == 0;
+    // f32 v = k * 2^(E - 150), |k| < 2^24, |v| < 2^(E - 126), with E = max(biased exponent, 1)
+    const int Ea = ea ? ea : 1, Eb = eb ? eb : 1, Ed = ed ? ed : 1;
+    const int big = 1 << 20;
+    const int ua = za ? big : Ea - 150, ub = zb ? big : Eb - 150, ud = zd ? big : Ed - 150;
+    const int ta = za ? -big : Ea - 126 + lx, tb = zb ? -big : Eb - 126 + ly, td = zd ? -big : Ed - 126;
+    const int g1 = ua < ub ? ua : ub, top1 = ta > tb ? ta : tb;       // (i)  m0 x + m2 y
+    const int g2 = ub < ud ? ub : ud, top2 = tb > td ? tb : td;       // (ii) m2 y + m4
+    return top1 + 1 <= 53 + g1 && top2 + 1 <= 53 + g2;               // (an all-zero sum: -big + 1 <= 53 + big)
+}
+// number of bits of the largest |coordinate| of a window [off, off + n): |x| <= 2^bits
+HG_HD int coord_bits(int off, int n)
+{
+    int64_t a = off < 0 ? -(int64_t)off : off, b = (int64_t)off + n;
+    if (b < 0) b = -b;
+    uint64_t m = (uint64_t)(a > b ? a : b);
+    int bits = 0;
+    while (m) { bits++; m >>= 1; }
+    return bits;
+}
+// both rows of an inverse affine matrix [m0 m1 m2 m3 m4 m5] (sx = m0 x + m2 y + m4, sy = m1 x + m3 y + m5)
+HG_HD bool affine_fusable(const float *inv, int lx, int ly)
+{
+    return affine_row_fusable(inv[0], inv[2], inv[4], lx, ly) && affine_row_fusable(inv[1], inv[3], inv[5], lx, ly);
+}
+
 // applyProjectiveTransformToPoint :1401-1404 (the denominator is evaluated twice in JS; same value both times)
 HG_HD void apply_projective(const double *m, double x, double y, double &ox, double &oy)
 {

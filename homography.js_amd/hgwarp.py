@@ -38,7 +38,7 @@ EXPORTS = [
     "hg_warp_forward_piecewise_device", "hg_warp_forward_piecewise_batch_device",
     "hg_solve_affine_triangles", "hg_warp_inverse_piecewise_state", "hg_warp_forward_piecewise_state",
     "hg_upload_on_copy_stream", "hg_fence_copies",
-    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_piecewise_self", "hg_last_piecewise_flag", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_layout_walks", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_piecewise_self", "hg_last_piecewise_flag", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_layout_walks", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range", "hg_affine_one_fma_form",
 ]
 
 
@@ -110,7 +110,7 @@ def lib():
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
         "hg_last_piecewise_kernel": (i, [vp]), "hg_last_piecewise_self": (i, [vp]), "hg_last_piecewise_flag": (i, [vp]), "hg_last_forward_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]), "hg_layout_walks": (C.c_long, [vp]), "hg_xcc_count": (i, [vp]),
         "hg_selftest_division": (i, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
-        "hg_projective_plain_range": (i, [f64p, Geom]), "hg_forward_tiles_admissible": (i, [i, f64p, i, i, Geom]),
+        "hg_projective_plain_range": (i, [f64p, Geom]), "hg_affine_one_fma_form": (i, [f32p, Geom]), "hg_forward_tiles_admissible": (i, [i, f64p, i, i, Geom]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
         "hg_kernel_ms_stats": (i, [vp, f64p, C.POINTER(i)]),
         "hg_warp_forward_geometric": (i, [vp, i, f64p, Geom, u8p]),
@@ -212,6 +212,12 @@ def projective_plain_range(m, geom):
     """True if the projective kernel may use its shared-reciprocal division for this frame (host-side range proof)."""
     a = np.ascontiguousarray(m, np.float64)
     return bool(lib().hg_projective_plain_range(a.ctypes.data_as(C.POINTER(C.c_double)), Geom(*[int(v) for v in geom])))
+
+
+def affine_one_fma_form(inv, geom):
+    """1 where the piecewise row kernel may evaluate an inverse matrix's two sums with one fma each (hg_affine_one_fma_form)."""
+    a = np.ascontiguousarray(inv, np.float32)
+    return bool(lib().hg_affine_one_fma_form(a.ctypes.data_as(C.POINTER(C.c_float)), Geom(*[int(v) for v in geom])))
 
 
 def forward_tiles_admissible(kind, m, w, h, geom):

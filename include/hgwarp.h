@@ -385,6 +385,11 @@ int hg_xcc_count(const hg_ctx *ctx);
  * projective matrix m[8] keeps numerators and denominator in the plain range (entries 0 or in [2^-100, 2^100], coordinates
  * below 2^28, denominator of one sign and in [2^-100, 2^130] at the four corners), else 0 (-> IEEE divides in the kernel). */
 int hg_projective_plain_range(const double *m, hg_geom geom);
+/* Host-side proof obligation of the piecewise row kernel's one-fma form (no GPU needed): 1 if, for every integer pixel (x, y) of the window
+ * `geom`, (m0*x) + (m2*y) + m4 and (m1*x) + (m3*y) + m5 of applyAffineTransformToPoint :1382-1385 -- inv[6] = an inverse matrix, f32 values --
+ * round at most once, so that fma(m0, x, (m2*y) + m4) has the same bits (both partial sums exactly representable; hg_math.h
+ * affine_fusable); else 0 (-> the kernel keeps the two roundings).  k_tri_setup evaluates the same predicate per (frame, triangle). */
+int hg_affine_one_fma_form(const float inv[6], hg_geom geom);
 /* Self-test of the projective kernels' shared-reciprocal division against IEEE division on `samples` pseudo-random
  * operand triples drawn from the range the host admits it for; *mismatches must come back 0. */
 int hg_selftest_division(hg_ctx *ctx, uint64_t samples, uint64_t seed, uint64_t *mismatches);

@@ -244,6 +244,50 @@ def test_projective_plain_range_classification():
     assert HG.projective_plain_range(ident, (0, 0, 0, 0))                                          # empty window: nothing to divide
 
 
+def test_one_fma_form_is_admitted_only_where_it_has_the_reference_bits():
+    """hg_affine_one_fma_form (the predicate k_tri_setup applies per triangle): wherever it says yes, fma(m0, x, (m2*y) + m4) -- evaluated
+    here in exact rational arithmetic, rounded once -- equals the reference's ((m0*x) + (m2*y)) + m4 (two roundings, plain doubles) for
+    pixels of the window, incl. its corners; it says yes for ordinary meshes (C3's matrices, face-mesh-like matrices) and no for non-finite
+    entries, shears 2^-40 of the scale, and windows at 2^24."""
+    from fractions import Fraction
+    rng = np.random.default_rng(11)
+
+    def reference(m0, m2, m4, x, y):
+        return ((float(m0) * x) + (float(m2) * y)) + float(m4)          # :1383: products exact in doubles, two rounded sums
+
+    def one_fma(m0, m2, m4, x, y):
+        c = (float(m2) * y) + float(m4)                                  # the record's A
+        return float(Fraction(float(m0)) * x + Fraction(c))              # fma = the exact sum rounded once (Fraction -> float rounds to nearest even)
+
+    yes = 0
+    for trial in range(3000):
+        kind = trial % 6
+        m = rng.standard_normal(6).astype(np.float32)
+        if kind == 1: m *= np.float32(2.0) ** rng.integers(-30, 12, 6).astype(np.float32)   # wildly different magnitudes
+        if kind == 2: m[[0, 3]] = 1; m[[1, 2]] *= np.float32(2.0 ** -int(rng.integers(0, 45)))
+        if kind == 3: m[rng.integers(0, 6)] = 0
+        if kind == 4: m[4:] *= 4000
+        if kind == 5: m = np.array([1, rng.normal() * 0.2, 0, 1, 0, rng.normal() * 200], np.float32)      # C3-like
+        g = (int(rng.integers(-50, 50)), int(rng.integers(-50, 50)), int(rng.integers(1, 8192)), int(rng.integers(1, 4500)))
+        if not HG.affine_one_fma_form(m, g):
+            continue
+        yes += 1
+        xs = [g[0], g[0] + g[2] - 1] + [int(v) for v in rng.integers(g[0], g[0] + g[2], 6)]
+        ys = [g[1], g[1] + g[3] - 1] + [int(v) for v in rng.integers(g[1], g[1] + g[3], 6)]
+        for x in xs:
+            for y in ys:
+                assert one_fma(m[0], m[2], m[4], x, y) == reference(m[0], m[2], m[4], x, y), (m, g, x, y)
+                assert one_fma(m[1], m[3], m[5], x, y) == reference(m[1], m[3], m[5], x, y), (m, g, x, y)
+    assert yes > 1200                                                    # the predicate is not vacuous
+    g4k = (0, 1, 3840, 2239)
+    assert HG.affine_one_fma_form(np.array([1, 0.0756, -0.0, 1, -0.0, -40.0], np.float32), g4k)
+    assert HG.affine_one_fma_form(np.array([0.97, 0.11, -0.08, 1.04, 35.5, -12.25], np.float32), g4k)
+    assert not HG.affine_one_fma_form(np.array([1, 0, 2.0 ** -40, 1, 0, 0], np.float32), g4k)        # m0 x + m2 y needs 12 + 40 + 24 bits
+    assert not HG.affine_one_fma_form(np.array([1, 0, np.nan, 1, 0, 0], np.float32), g4k)
+    assert not HG.affine_one_fma_form(np.array([np.inf, 0, 0, 1, 0, 0], np.float32), g4k)
+    assert HG.affine_one_fma_form(np.zeros(6, np.float32), g4k)                                        # all sums are 0
+
+
 def test_forward_tile_admission_bounds():
     """Host-side admission of the tile-binned forward kernel (hg_forward_tiles_admissible): ordinary matrices pass with a trusted
     inverse; anything that could put a source pixel far outside the window, a projective denominator near zero, huge or

@@ -701,6 +701,56 @@ def test_one_source_per_frame(ctx):
         ctx.free(d_src)
 
 
+def test_frame_sets_mixing_one_fma_and_two_rounding_frames(ctx):
+    """k_pw_rows<SELF> evaluates a frame's coordinates with one fma where k_tri_setup found the sums of every triangle of the frame exact
+    (hg_affine_one_fma_form) and with the reference's two roundings otherwise -- per frame, decided on the device at every step.
+    Frame set: pure translations and ordinary deformations (every sum exact) next to frames in which a few vertices are moved by one ulp
+    (shears of 2^-23: far too small against the unit scale for exact sums).  Every frame against the oracle, with the self-span kernel
+    forced (min_row_groups = 0) and under the default policy, safe spans on and off; then the same buffers again with the frames in another
+    order (a frame index changes kind from one step to the next)."""
+    W = H = 256
+    img = G.lcg_image(W, H, 77)
+    sp, tris = WL.grid_points(W, H, 4, 4), WL.grid_triangles(4, 4)
+    base = (sp.reshape(-1, 2) + np.array([3, 2], np.float32)).astype(np.float32)
+    frames = []
+    for f in range(8):
+        d = base.copy()
+        if f in (1, 2, 4, 7):
+            for v in ((6 + f) % 25, (12 + 2 * f) % 25, 18):                # vertices nudged by one unit in the last place
+                d[v, f % 2] = np.nextafter(d[v, f % 2], np.float32(1e9), dtype=np.float32)
+        if f in (3, 4): d[7] += np.float32(0.375)                           # + an ordinary deformation
+        if f == 5: d[:, 0] = (d[:, 0] * np.float32(1.25)).astype(np.float32)
+        frames.append(d.ravel())
+    geoms = [WL.piecewise_geom(d) for d in frames]
+    ms = WL.src_min(sp)
+    kinds = []
+    for f in range(8):
+        fwd = HG.solve_affine_triangles(sp, frames[f], tris).reshape(-1, 6)
+        kinds.append(all(HG.affine_one_fma_form(HG.invert_affine(m), geoms[f]) for m in fwd))
+    assert kinds == [True, False, False, True, False, True, True, False], kinds
+    with HG.Context(0) as c:
+        c.set_image(img); c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+        for order in (list(range(8)), [1, 0, 3, 2, 7, 6, 5, 4]):
+            fr = [frames[i] for i in order]; gm = [geoms[i] for i in order]
+            offs, total = HG.pack_offsets(gm)
+            want = [O.warp_inverse_piecewise(sp, fr[f], tris, img, ms[0], ms[1], *gm[f]) for f in range(8)]
+            d_out = c.alloc(total)
+            try:
+                for mrg in (0, -1):
+                    for safe in (1, 0, -1):
+                        if mrg >= 0: c.set_option("min_row_groups", mrg)
+                        c.set_option("safe_spans", safe)
+                        c.piecewise_set_frames(np.concatenate(fr), gm, offs)
+                        for step in range(2):                               # (resident points: the second step re-derives the per-frame choice)
+                            c.warp_inverse_piecewise_frames_device(d_out); c.sync()
+                            for f in range(8):
+                                g = gm[f]
+                                assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), (order, mrg, safe, step, f)
+                        if mrg == 0: assert c.last_piecewise_self() != 0
+            finally:
+                c.free(d_out)
+
+
 def test_geometric_frame_sets_of_uneven_frames_on_their_own_sources(ctx):
     """k_geo_fast's XCD bands rotate with the frame when every frame reads its own source: frame sets whose frames differ in size by two
     orders of magnitude (rows past a frame's end, bands a small frame does not reach), affine and projective, with each rotation setting."""
