@@ -334,6 +334,7 @@ PwFrames frames_of(const hg_ctx *c)
     // alternating order, off -> on: C3 (1.5 spans per 256-pixel window) 0.562 -> 0.525 ms; C4 (4.5: one flag per span piece in the prologue, few
     // windows wholly inside flagged spans) 0.217 -> 0.220.  Hence by the host's spans-per-window estimate; option "safe_spans" forces either.
     f.safe_spans = c->opt_safe_spans >= 0 ? c->opt_safe_spans : (c->pw_spans_per_window < 3.0 ? 1 : 0);
+    f.safe_spans_patch = c->opt_safe_spans >= 0 ? c->opt_safe_spans : 1;
     f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 || c->pw_self ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
     f.patch_blocks = c->opt_phase > 0 ? c->opt_phase : 8;    // (k_pw_patch: measured best in both source layouts, hg_k_patch.hip)
     return f;

@@ -64,6 +64,11 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     const int W = fd.obj_w;
     const int nbins = (W + 63) >> 6;
     const int nrows = min(kPatchRows, fd.obj_h - r0);
+    // (the source window, also for the prologue's span flags)
+    const double bx_lo0 = (double)mesh.min_src_x + 0.5, bx_hi0 = (double)mesh.W + (double)mesh.min_src_x + 0.5;
+    const double by_lo0 = (double)mesh.min_src_y + 0.5, by_hi0 = (double)mesh.H + (double)mesh.min_src_y + 0.5;
+    const HiBounds hb0 = make_hi_bounds(bx_lo0, bx_hi0, by_lo0, by_hi0);
+    const bool flag_spans = SELF && fr.safe_spans_patch != 0;       // (uniform; host option)
     const float *__restrict__ ginv0 = fr.inv + (size_t)f * mesh.n_tris * kInvStride;     // this frame's inverse matrices (tap array)
     int cnts[kPatchRows], cmax = 0;
     bool bad1;
@@ -125,9 +130,9 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             if (c >= nc) continue;
             const int tn = s_cand_tn[c], t = tn & 0xffff, n = (int)((uint32_t)tn >> 16), ylo = s_cand_y[c];
             if (n >= 0xffff) { s_fail = 1; continue; }      // (absurd reach: the map path takes the frame)
+            const float4 ma = *reinterpret_cast<const float4 *>(ginv0 + (size_t)t * kInvStride);
+            const float2 mb = *reinterpret_cast<const float2 *>(ginv0 + (size_t)t * kInvStride + 4);
             if (jj == 0) {
-                const float4 ma = *reinterpret_cast<const float4 *>(ginv0 + (size_t)t * kInvStride);
-                const float2 mb = *reinterpret_cast<const float2 *>(ginv0 + (size_t)t * kInvStride + 4);
                 double2 *mrec = reinterpret_cast<double2 *>(s_rec + c * 6);
                 mrec[0] = make_double2((double)ma.x, (double)ma.z);    // m0, m2
                 mrec[1] = make_double2((double)mb.x, (double)ma.y);    // m4, m1
@@ -171,7 +176,20 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
                     const int slot = atomicAdd(&s_rowcnt[row], 1);
                     if (slot >= CAPR - 1) continue;         // (counted: the check below fails the group)
                     s_lohi[row * CAPR + slot] = (uint32_t)lo | ((uint32_t)hi << 16);
-                    s_key[row * CAPR + slot] = (t << kKeyShift) | (c * 48);
+                    // bit 0 "unsafe" (record offsets are multiples of 48): clear only when BOTH end pixels of the piece pass the source bounds
+                    // test :1047, evaluated exactly as the pixel body evaluates them -- then every pixel between them passes (k_pw_rows)
+                    int unsafe = 1;
+                    if (flag_spans) {
+                        const double yr = (double)(r + fd.y_off), xa = (double)(lo + fd.x_off), xb = (double)(hi - 1 + fd.x_off);
+                        const double cy0 = (double)ma.z * yr, cy1 = (double)ma.w * yr;
+                        double h[4] = { fma((double)ma.x, xa, cy0) + (double)mb.x, fma((double)ma.y, xa, cy1) + (double)mb.y,
+                                        fma((double)ma.x, xb, cy0) + (double)mb.x, fma((double)ma.y, xb, cy1) + (double)mb.y }, rd[4];
+                        round_x4(h, rd);
+                        const bool ia = HIB ? hi_inb(hb0, h[0], h[1]) : (bool)((int)(h[0] >= bx_lo0) & (int)(h[0] < bx_hi0) & (int)(h[1] >= by_lo0) & (int)(h[1] < by_hi0));
+                        const bool ib = HIB ? hi_inb(hb0, h[2], h[3]) : (bool)((int)(h[2] >= bx_lo0) & (int)(h[2] < bx_hi0) & (int)(h[3] >= by_lo0) & (int)(h[3] < by_hi0));
+                        unsafe = (ia && ib) ? 0 : 1;
+                    }
+                    s_key[row * CAPR + slot] = (t << kKeyShift) | (c * 48) | unsafe;
                 }
             }
         }
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     n_mine = 0;
     if (!GLOBALREC && !bad1) for (int e = threadIdx.x; e < kPatchRows * CAPR; e += 256) {
         const int bucket = my_bucket[n_mine++];
-        if (bucket >= 0) s_key[e] = (s_key[e] << kKeyShift) | (int)(((s_hash[bucket] & 0xffffu) - 1u) * 48u);
+        if (bucket >= 0) s_key[e] = (s_key[e] << kKeyShift) | (int)(((s_hash[bucket] & 0xffffu) - 1u) * 48u) | 1;
     }
     if (!GLOBALREC) __syncthreads();
     }
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     const double by_lo = (double)mesh.min_src_y + 0.5, by_hi = (double)mesh.H + (double)mesh.min_src_y + 0.5;
     const HiBounds hb = make_hi_bounds(bx_lo, bx_hi, by_lo, by_hi);      // HIB: :1047 on the high dwords of h (hg_dev.h)
     const int pitch4 = mesh.W * 4;
-    const int nan_key = GLOBALREC ? -1 : ((int)0x80000000u | (RECS * 48));
+    const int nan_key = GLOBALREC ? -1 : ((int)0x80000000u | (RECS * 48) | 1);      // ("no triangle" is unsafe: its pixels must come out as offset 0xffffffff)
     const int row_base = rr * CAPR;
     const int my_cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
     uint32_t *tile = s_tile + wave * (kPatchRows * kPatchTilePitch);
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
                 const double nanq = best[k] < 0 ? NAN : 0.0;     // no triangle: every coordinate becomes NaN and fails :1047
                 m0 = a.x; m1 = a.y; m2 = a.z; m3 = a.w; m4 = (double)b.x + nanq; m5 = (double)b.y + nanq;
             } else {
-                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_rec) + (best[k] & kKeyOffMask));
+                const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_rec) + (best[k] & (kKeyOffMask & ~15)));
                 const double2 m02 = mrec[0], m41 = mrec[1], m35 = mrec[2];
                 m0 = m02.x; m2 = m02.y; m4 = m41.x; m1 = m41.y; m3 = m35.x; m5 = m35.y;
             }
@@ -326,6 +344,14 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             // :1383-1384  (m0*x) + (m2*y) + m4: m2*y rounded on its own, m0*x exact in fp64 (see k_pw_rows)
             h[2 * k]     = fma(m0, xd, m2 * y) + m4;
             h[2 * k + 1] = fma(m1, xd, m3 * y) + m5;
+        }
+        // every pixel of the block resolved to a span whose ends are inside the source window: no bounds test, Math.round with one add (k_pw_rows)
+        if (flag_spans && __ballot(((best[0] | best[1] | best[2] | best[3]) & 1) != 0) == 0ull) {
+            int r[8];
+            round_half_x4(h, r); round_half_x4(h + 4, r + 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, (uint32_t)(__mul24(r[2 * k + 1], pitch4) + (r[2 * k] << 2)), 0, 0);
+            return;
         }
         round_x8(h, rd);
 #pragma unroll
