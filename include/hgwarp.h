@@ -372,6 +372,7 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "safe_spans" (default -1 = rows of fewer than 3 spans per 256-pixel window; 1 / 0 force / forbid): k_pw_rows flags every span whose two end
  *           pixels pass the source bounds test :1047 (then every pixel between them does: the affine coordinates are monotone along a row) and
  *           runs windows made only of such spans without the per-pixel test, Math.round with one add per coordinate;
+ *           k_pw_patch<SELF> does the same per 64-pixel x 4-row block (on unless the option says 0);
  *   "tile" (default -1 = whenever every frame reads its own source and k_pw_patch would evaluate its own spans; 1 = with a shared
  *           source too; 0 never): k_pw_tile instead of k_pw_patch -- 8 x 2048-pixel tiles, gathers in 8-pixel runs along the source
  *           rows; a tile beyond its limits (96 spans per row and tile, 128 triangle pieces) flags its frame, hg_sync
