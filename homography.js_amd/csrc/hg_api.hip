@@ -73,6 +73,8 @@ extern "C" void hg_destroy(hg_ctx *c)
     for (int i = 0; i < hg_ctx::kEvRing; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_event) (void)hipEventDestroy(c->copy_event);
+    if (c->down_stream) { (void)hipStreamSynchronize(c->down_stream); (void)hipStreamDestroy(c->down_stream); }
+    if (c->down_event) (void)hipEventDestroy(c->down_event);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -152,6 +154,29 @@ extern "C" int hg_fence_copies(hg_ctx *c)
     if (!c->copy_event) HIP_TRY(c, hipEventCreateWithFlags(&c->copy_event, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->copy_event, c->copy_stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_event, 0));
+    return HG_OK;
+}
+
+// D2H on the context's DOWNLOAD stream, ordered behind everything issued on the warp stream so far -- and nothing issued later: frame f
+// comes down while frame f + 1 is warped (and while image f + 2 goes up on the copy stream).  Purely stream-ordered like
+// hg_enqueue_copy_to_host: a frame the fused run only flagged is rewritten by a later hg_sync (hg_redone_frames tells) and must be
+// downloaded again.  hg_fence_downloads: the host waits for the download stream (hg_sync does not).
+extern "C" int hg_download_behind_warps(hg_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HG_TRY(bind(c));
+    if (!dst || !src) return fail(c, HG_ERR_INVALID, "NULL pointer");
+    if (!c->down_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+    if (!c->down_event) HIP_TRY(c, hipEventCreateWithFlags(&c->down_event, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->down_event, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->down_stream, c->down_event, 0));
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->down_stream));
+    return HG_OK;
+}
+
+extern "C" int hg_fence_downloads(hg_ctx *c)
+{
+    HG_TRY(bind(c));
+    if (c->down_stream) HIP_TRY(c, hipStreamSynchronize(c->down_stream));
     return HG_OK;
 }
 

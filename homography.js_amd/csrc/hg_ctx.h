@@ -26,6 +26,8 @@ struct hg_ctx {
     bool own_stream = false;
     hipStream_t copy_stream = nullptr;                         // hg_upload_on_copy_stream: uploads that overlap the warp stream's work
     hipEvent_t copy_event = nullptr;                           // hg_fence_copies
+    hipStream_t down_stream = nullptr;                         // hg_download_behind_warps: D2H copies that overlap the warp stream's later work
+    hipEvent_t down_event = nullptr;
     std::string err;
     int deferred = HG_OK;
 

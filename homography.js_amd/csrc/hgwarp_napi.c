@@ -745,6 +745,17 @@ static napi_value fn_get_tri_map(napi_env env, napi_callback_info info)
     return r;
 }
 
+/* redoneFrames(ctx): frames the fused kernels flagged and hg_sync redid through the map so far (hg_redone_frames; tests) */
+static napi_value fn_redone_frames(napi_env env, napi_callback_info info)
+{
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    handle_t *h = get_handle(env, a[0]); if (!h) return NULL;
+    napi_value out;
+    NAPI_OK(napi_create_double(env, (double)hg_redone_frames(h->ctx), &out));
+    return out;
+}
+
 static napi_value fn_get_matrices(napi_env env, napi_callback_info info)
 {
     napi_value a[2];
@@ -909,17 +920,30 @@ static napi_value run_batch(napi_env env, handle_t *h, const batch_job *job, con
             if (rc == HG_OK) { if (h->d_imgs) hg_device_free(h->ctx, h->d_imgs); h->d_imgs = q; h->d_imgs_cap = stride * n_img; }
             else if (q) hg_device_free(h->ctx, q);
         }
+        /* Three streams: image f + 1 goes up (copy stream) and frame f - 1 comes down (download stream) while frame f is warped; the host
+         * only ever waits for warps.  A frame comes down unsettled: if the settlement that precedes the next image binding (or the final
+         * hg_sync) redid it -- hg_redone_frames moved --, it comes down again. */
         if (rc == HG_OK) rc = hg_upload_on_copy_stream(h->ctx, h->d_imgs, src[0], bytes);
-        for (int f = 0; f < F && rc == HG_OK; f++) {
+        long redone = hg_redone_frames(h->ctx);
+        for (int f = 0; f <= F && rc == HG_OK; f++) {
+            if (f < F) rc = hg_set_images_device(h->ctx, (uint8_t *)h->d_imgs + stride * ((uint32_t)f % n_img), iw, ih, 1, stride);   /* (settles frame f - 1) */
+            else rc = hg_sync(h->ctx);
+            if (rc == HG_OK && f > 0) {
+                const long now = hg_redone_frames(h->ctx);
+                const size_t ppx = (g[f - 1].obj_w > 0 && g[f - 1].obj_h > 0) ? (size_t)g[f - 1].obj_w * g[f - 1].obj_h : 0;
+                if (now != redone && ppx) rc = hg_download_behind_warps(h->ctx, own ? outs[f - 1] : base + offs[f - 1], d_out + offs[f - 1], ppx * 4);
+                redone = now;
+            }
+            if (f == F || rc != HG_OK) break;
             const size_t px = (g[f].obj_w > 0 && g[f].obj_h > 0) ? (size_t)g[f].obj_w * g[f].obj_h : 0;
-            rc = hg_set_images_device(h->ctx, (uint8_t *)h->d_imgs + stride * ((uint32_t)f % n_img), iw, ih, 1, stride);   /* (settles frame f - 1) */
-            if (rc == HG_OK) rc = hg_fence_copies(h->ctx);                                  /* the warp stream waits for image f */
+            rc = hg_fence_copies(h->ctx);                                                   /* the warp stream waits for image f */
             if (rc == HG_OK) rc = job_launch(h, job, g, offs, f, 1, h->d_batch);
-            if (rc == HG_OK && px) rc = hg_copy_to_host_async(h->ctx, own ? outs[f] : base + offs[f], d_out + offs[f], px * 4);
+            if (rc == HG_OK && px) rc = hg_download_behind_warps(h->ctx, own ? outs[f] : base + offs[f], d_out + offs[f], px * 4);
             if (rc == HG_OK && (uint32_t)(f + 1) < n_img && f + 1 < F)                      /* ... and image f + 1 goes up meanwhile */
                 rc = hg_upload_on_copy_stream(h->ctx, (uint8_t *)h->d_imgs + stride * (uint32_t)(f + 1), src[f + 1], bytes);
         }
         free(src);
+        { const int rcd = hg_fence_downloads(h->ctx); if (rc == HG_OK) rc = rcd; }
     }
     const int rc2 = hg_sync(h->ctx);
     if (rc == HG_OK) rc = rc2;
@@ -1211,7 +1235,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "releaseBatch", fn_release_batch }, { "pinnedBuffer", fn_pinned_buffer },
         { "solveAffineTriangles", fn_solve_affine_triangles }, { "warpInversePiecewiseState", fn_warp_inverse_piecewise_state },
         { "warpForwardPiecewiseState", fn_warp_forward_piecewise_state },
-        { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },
+        { "release", fn_release }, { "setPinnedLimit", fn_set_pinned_limit }, { "poolStats", fn_pool_stats }, { "redoneFrames", fn_redone_frames }, { "_poolTestFrames", fn_pool_test_frames }, { "poolPressure", fn_pool_pressure }, { "poolCollected", fn_pool_collected },
         { "multiCreate", fn_multi_create }, { "multiDestroy", fn_multi_destroy }, { "multiSetImage", fn_multi_set_image },
         { "multiSetMesh", fn_multi_set_mesh }, { "multiWarpBatch", fn_multi_warp_batch }, { "multiWarpGeometricBatch", fn_multi_warp_geometric_batch },
     };

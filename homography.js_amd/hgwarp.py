@@ -37,7 +37,7 @@ EXPORTS = [
     "hg_warp_forward_geometric", "hg_warp_forward_piecewise", "hg_warp_forward_geometric_device", "hg_warp_forward_geometric_batch_device",
     "hg_warp_forward_piecewise_device", "hg_warp_forward_piecewise_batch_device",
     "hg_solve_affine_triangles", "hg_warp_inverse_piecewise_state", "hg_warp_forward_piecewise_state",
-    "hg_upload_on_copy_stream", "hg_fence_copies",
+    "hg_upload_on_copy_stream", "hg_fence_copies", "hg_download_behind_warps", "hg_fence_downloads",
     "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_piecewise_self", "hg_last_piecewise_flag", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_layout_walks", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range", "hg_affine_one_fma_form",
 ]
 
@@ -119,7 +119,7 @@ def lib():
         "hg_warp_forward_geometric_batch_device": (i, [vp, i, f64p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
         "hg_warp_forward_piecewise_device": (i, [vp, f32p, i, i, Geom, vp]),
         "hg_warp_forward_piecewise_batch_device": (i, [vp, f32p, i, i, C.POINTER(Geom), C.POINTER(sz), i, vp]),
-        "hg_upload_on_copy_stream": (i, [vp, vp, vp, sz]), "hg_fence_copies": (i, [vp]),
+        "hg_upload_on_copy_stream": (i, [vp, vp, vp, sz]), "hg_fence_copies": (i, [vp]), "hg_download_behind_warps": (i, [vp, vp, vp, sz]), "hg_fence_downloads": (i, [vp]),
         "hg_solve_affine_triangles": (i, [f32p, f32p, i, C.POINTER(C.c_uint32), i, f32p]),
         "hg_warp_inverse_piecewise_state": (i, [vp, f32p, i, C.POINTER(TriMapDef), i, i, Geom, u8p]),
         "hg_warp_forward_piecewise_state": (i, [vp, f32p, i, C.POINTER(TriMapDef), i, i, i, i, Geom, u8p]),
@@ -309,6 +309,14 @@ class Context:
         out = np.empty(int(nbytes), np.uint8)
         self._c(lib().hg_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr + offset), int(nbytes)))
         return out
+
+    def download_behind_warps(self, out, dptr, offset=0):
+        """D2H into the uint8 array `out` on the context's download stream, ordered behind the warps issued so far (hg_download_behind_warps);
+        `out` must stay alive until fence_downloads()."""
+        self._c(lib().hg_download_behind_warps(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr + offset), int(out.nbytes)))
+
+    def fence_downloads(self):
+        self._c(lib().hg_fence_downloads(self._h))
 
     def to_device(self, dptr, arr, offset=0):
         a = np.ascontiguousarray(arr)

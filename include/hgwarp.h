@@ -93,6 +93,12 @@ int hg_enqueue_copy_to_host(hg_ctx *ctx, void *dst_host, const void *src_device,
  * uploads queued so far.  (The video loop `for (f) warp(image_f)`, README.md:121-137, through js/Homography.mjs warpBatch({images}).) */
 int hg_upload_on_copy_stream(hg_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 int hg_fence_copies(hg_ctx *ctx);
+/* Device -> host on the context's DOWNLOAD stream (a third stream owned by the ctx), ordered behind the warps issued so far and nothing
+ * issued later: frame f comes down while frame f + 1 is warped and image f + 2 goes up.  Stream-ordered like hg_enqueue_copy_to_host (a
+ * frame a fused run flagged is rewritten by the next hg_sync -- hg_redone_frames tells -- and is then downloaded again by the caller).
+ * hg_fence_downloads: the host waits for the downloads queued so far (hg_sync does not wait for them). */
+int hg_download_behind_warps(hg_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+int hg_fence_downloads(hg_ctx *ctx);
 /* Everything queued on the ctx stream after this call waits for hip_event (a hipEvent_t recorded on any stream of any device):
  * orders warps behind the caller's own uploads / peer copies without blocking the host. */
 int hg_stream_wait_event(hg_ctx *ctx, void *hip_event);

@@ -701,6 +701,48 @@ def test_one_source_per_frame(ctx):
         ctx.free(d_src)
 
 
+def test_download_stream_protocol_with_a_flagged_frame(ctx):
+    """hg_download_behind_warps / hg_fence_downloads, used the way the Node addon pipelines warpBatch({images}): frame f's pixels go down a
+    third stream right behind its warp, UNSETTLED, while the host binds image f + 1 (which settles frame f) and warps it.  Frame 2 has a
+    NaN vertex: the fused kernel only flags it, the settlement redoes it through the map -- hg_redone_frames moves -- and the frame is
+    downloaded again.  Every frame equals the oracle."""
+    W, H, nx, ny, F = 288, 180, 9, 6, 5
+    imgs = [G.lcg_image(W, H, 500 + k) for k in range(F)]
+    sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+    frames = [WL.sin_dst(sp, 4.0 + f, 8 + (f % 4)) for f in range(F)]
+    frames[2] = frames[2].copy(); frames[2][4] = np.nan            # (an x coordinate: its triangles keep their rows and are irregular)
+    geoms = [WL.piecewise_geom(frames[0])] * F                           # (one window for all: the NaN frame has none of its own)
+    ms = WL.src_min(sp)
+    offs, total = HG.pack_offsets(geoms)
+    stride = W * H * 4
+    with HG.Context(0) as c:
+        d_src, d_out = c.alloc(stride * F), c.alloc(total)
+        outs = [np.zeros(geoms[f][2] * geoms[f][3] * 4, np.uint8) for f in range(F)]
+        try:
+            for k in range(F): c.to_device(d_src, imgs[k], k * stride)
+            c.set_image_device(d_src, W, H); c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
+            c.set_option("min_row_groups", 0)
+            redone = c.redone_frames()
+            for f in range(F + 1):
+                if f < F: c.set_image_device(d_src + f * stride, W, H)       # settles frame f - 1
+                else: c.sync()
+                if f > 0 and c.redone_frames() != redone:
+                    c.download_behind_warps(outs[f - 1], d_out, offs[f - 1]); redone = c.redone_frames()
+                if f == F: break
+                c.piecewise_set_frames(frames[f], [geoms[f]], [offs[f]])
+                c.warp_inverse_piecewise_frames_device(d_out)
+                c.download_behind_warps(outs[f], d_out, offs[f])
+            c.fence_downloads()
+            assert c.redone_frames() >= 1
+            for f in range(F):
+                g = geoms[f]
+                want = O.warp_inverse_piecewise(sp, frames[f], tris, imgs[f], ms[0], ms[1], *g)
+                assert np.array_equal(outs[f].reshape(g[3], g[2], 4), want), f
+        finally:
+            c.set_image(imgs[0])
+            c.free(d_out); c.free(d_src)
+
+
 def test_frame_sets_mixing_one_fma_and_two_rounding_frames(ctx):
     """k_pw_rows<SELF> evaluates a frame's coordinates with one fma where k_tri_setup found the sums of every triangle of the frame exact
     (hg_affine_one_fma_form) and with the reference's two roundings otherwise -- per frame, decided on the device at every step.
