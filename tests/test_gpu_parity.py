@@ -701,6 +701,45 @@ def test_one_source_per_frame(ctx):
         ctx.free(d_src)
 
 
+def test_one_fma_predicate_boundary_on_random_meshes(ctx):
+    """Random small meshes straddling hg_affine_one_fma_form's boundary: translations with vertices moved by 1-8 units in the last place
+    (shears of 2^-27 ... 2^-17 against the unit scale: exact sums on one side of the predicate, inexact on the other), random
+    stretches on top; 8 frames per set, the self-span kernel forced.  Every frame against the oracle; both kinds of frame must occur."""
+    rng = np.random.default_rng(20260929)
+    W, H = 96, 80
+    img = G.lcg_image(W, H, 5)
+    sp, tris = WL.grid_points(W, H, 4, 3), WL.grid_triangles(4, 3)
+    ms = WL.src_min(sp)
+    seen = set()
+    with HG.Context(0) as c:
+        c.set_image(img); c.piecewise_set_mesh(sp, tris, ms[0], ms[1]); c.set_option("min_row_groups", 0)
+        for trial in range(30):
+            frames = []
+            for f in range(8):
+                d = (sp.reshape(-1, 2) + rng.integers(0, 6, 2).astype(np.float32)).astype(np.float32)
+                if rng.random() < 0.3: d[:, 0] = (d[:, 0] * np.float32(rng.choice([1.25, 0.75, 1.5]))).astype(np.float32)
+                for _ in range(int(rng.integers(0, 4))):
+                    v, ax, n = int(rng.integers(0, d.shape[0])), int(rng.integers(0, 2)), int(rng.integers(1, 9))
+                    for _ in range(n): d[v, ax] = np.nextafter(d[v, ax], np.float32(1e9 if rng.random() < 0.5 else -1e9), dtype=np.float32)
+                frames.append(d.ravel())
+            geoms = [WL.piecewise_geom(d) for d in frames]
+            for f in range(8):
+                fwd = HG.solve_affine_triangles(sp, frames[f], tris).reshape(-1, 6)
+                seen.add(all(HG.affine_one_fma_form(HG.invert_affine(m), geoms[f]) for m in fwd))
+            offs, total = HG.pack_offsets(geoms)
+            d_out = c.alloc(total)
+            try:
+                c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
+                c.warp_inverse_piecewise_frames_device(d_out); c.sync()
+                for f in range(8):
+                    g = geoms[f]
+                    want = O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *g)
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want), (trial, f)
+            finally:
+                c.free(d_out)
+    assert seen == {True, False}
+
+
 def test_download_stream_protocol_with_a_flagged_frame(ctx):
     """hg_download_behind_warps / hg_fence_downloads, used the way the Node addon pipelines warpBatch({images}): frame f's pixels go down a
     third stream right behind its warp, UNSETTLED, while the host binds image f + 1 (which settles frame f) and warps it.  Frame 2 has a
