@@ -39,7 +39,7 @@ def main():
             else: c.set_image_device(img.data_ptr(), W, H)
             c.piecewise_set_mesh(sp, tris, msx, msy)
             c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
-            ctxs.append((c, stream)); outs.append(torch.empty(total, dtype=torch.uint8, device=dev))
+            ctxs.append((c, stream)); outs.append(torch.zeros(total, dtype=torch.uint8, device=dev))     # (zeros: the packing leaves padding between frames that no kernel writes)
         res = {"config": config, "F": F, "sources": src}
         for mode in ("one", "two", "one", "two"):
             n = 100
