@@ -52,6 +52,11 @@ PKG = os.path.join(ROOT, "homography.js_amd")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 # reference-generated goldens whose k-th warp is frame k of the config's sequence on rank 0 (tests/golden/gen_golden.mjs)
 GOLDEN_CASE = {"C3": "C3_batch_4k", "C2": "C2_projective_1080p", "C5": "C5_batch_8k", "C4": "C4_orbit_4k"}
+HBM_ACHIEVABLE_GBS = 6300.0    # what a streaming kernel reaches on this part (same guide); prices `write_floor_ms`
+# what `python bench.py` measures besides the headline: the other BASELINE.json configs on one GPU (frames per GPU per step), and -- with
+# --gpus N > 1 -- north_star's own sharded lines: C4 batch 512 and C5 batch 64, STRONG scaling, fan-out of the shared source priced in end_to_end
+DEFAULT_ALSO = "C4:64,C5:8,C2:64"
+DEFAULT_ALSO_STRONG = "C4:512:strong,C5:64:strong"
 
 
 def _load(name, path):
@@ -109,6 +114,23 @@ def launch_command(argv, n):
             "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--launch-dry-run"]
 
 
+def also_entries(args, world):
+    """[(config, frames or batch, "weak" | "strong")] measured after the headline.  --also given: exactly that list ('none' / '' = nothing).
+    Not given: the plain command (no workload-selecting flag) takes DEFAULT_ALSO, plus DEFAULT_ALSO_STRONG when it runs on more than one GPU."""
+    also = args.also
+    if also is None:
+        plain = (args.config == "C3" and args.frames == 64 and args.sources == "both" and args.points == "both" and args.scaling == "weak"
+                 and not args.batch and not args.no_verify)
+        also = (DEFAULT_ALSO + ("," + DEFAULT_ALSO_STRONG if world > 1 else "")) if plain else ""
+    out = []
+    for item in [a for a in also.split(",") if a and a != "none"]:
+        parts = item.split(":")
+        if parts[0] not in ("C2", "C3", "C4", "C5", "C5flat") or len(parts) > 3 or (len(parts) == 3 and parts[2] not in ("strong", "weak")):
+            raise SystemExit(f"bench.py: --also entry '{item}' is not CONFIG[:FRAMES[:strong]]")
+        out.append((parts[0], int(parts[1]) if len(parts) > 1 and parts[1] else args.frames, parts[2] if len(parts) == 3 else "weak"))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,8 +146,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the (untimed) output checks")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU-baseline sample (0 = auto, ~10-20 s)")
-    ap.add_argument("--also", default="", help="further configs measured in the same invocation, e.g. C4:64,C5:8 (config:frames per GPU per step); "
-                                               "each is reported under \"also\" with the fields of the headline line")
+    ap.add_argument("--also", default=None, help="further measurements in the same invocation, reported under \"also\" with the fields of the headline line: "
+                                                 "CONFIG:FRAMES (frames per GPU per step, weak) or CONFIG:BATCH:strong (a fixed batch over all GPUs, shared source, "
+                                                 "fan-out priced in end_to_end), comma-separated; 'none' = headline only.  Default (the plain command, no workload flag): "
+                                                 f"{DEFAULT_ALSO} and, with --gpus N > 1, {DEFAULT_ALSO_STRONG} (north_star's sharded configs)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --frames frames per GPU per step, per-GPU work fixed as N grows; strong: a FIXED batch of --batch frames "
                          "per step split over the N GPUs (north_star: 'batch = 512 / 64 frames sharded over 8 GPUs'), total work fixed")
@@ -172,11 +196,13 @@ def main():
     wl = _load("hg_workloads", os.path.join(PKG, "workloads.py"))
     env = dict(torch=torch, dist=dist, world=world, rank=rank, local_rank=local_rank, dev=dev, n_devices=n_devices, hgdist=hgdist, hg=hg, wl=wl)
     line, ok = measure(args, args.config, args.frames, env, primary=True)
-    # --also C4:64,C5:8: the other sharded configs of BASELINE.json in the SAME invocation (one multi-GPU lease yields every curve);
-    # each is a complete measurement (own context, own checks), attached under "also" with the same fields as the headline
-    for item in [a for a in (args.also or "").split(",") if a]:
-        name, _, fr = item.partition(":")
-        extra, ok_x = measure(args, name, int(fr) if fr else args.frames, env, primary=False)
+    # "also": the other configs of BASELINE.json in the SAME invocation (one lease yields every driver-timed line); each is a complete
+    # measurement (own context, own checks) with the fields of the headline.  The plain command takes the default list.
+    for name, fr, sc in also_entries(args, world):
+        if sc == "strong":
+            extra, ok_x = measure(args, name, fr, env, primary=False, scaling="strong", batch=fr, sources="shared", points="resident")
+        else:
+            extra, ok_x = measure(args, name, fr, env, primary=False, scaling="weak")
         ok = ok and ok_x
         if rank == 0:
             line.setdefault("also", []).append(extra)
@@ -187,14 +213,19 @@ def main():
     return 0 if (ok or args.no_verify) else 3
 
 
-def measure(args, config, F, env, primary=True):
-    """One complete measurement of `config` with F frames per GPU per step: inputs -> HBM, timed regions, untimed checks, CPU baseline
-    (headline only).  Returns (the JSON line as a dict -- meaningful on rank 0 --, verified)."""
+def measure(args, config, F, env, primary=True, scaling=None, batch=None, sources=None, points=None):
+    """One complete measurement of `config` with F frames per GPU per step (scaling "strong": a fixed batch over all GPUs): inputs -> HBM,
+    timed regions, untimed checks, CPU baseline (headline only).  scaling / batch / sources / points default to the command line's.
+    Returns (the JSON line as a dict -- meaningful on rank 0 --, verified)."""
+    scaling = scaling or args.scaling
+    sources = sources or args.sources
+    points = points or args.points
+    batch_arg = args.batch if batch is None else batch
     torch, dist, world, rank, local_rank, dev = env["torch"], env["dist"], env["world"], env["rank"], env["local_rank"], env["dev"]
     n_devices, hgdist, hg, wl = env["n_devices"], env["hgdist"], env["hg"], env["wl"]
     cfg = wl.CONFIGS[config]
     W, H = cfg["W"], cfg["H"]
-    do_shared, do_distinct = args.sources in ("both", "shared"), args.sources in ("both", "distinct")
+    do_shared, do_distinct = sources in ("both", "shared"), sources in ("both", "distinct")
 
     # ---------------------------------------------------------------- inputs -> HBM (untimed)
     img_t = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
@@ -207,8 +238,8 @@ def measure(args, config, F, env, primary=True):
         ctx.set_image_device(img_t.data_ptr(), W, H)         # (N > 1: attached below, once the broadcast has delivered it)
 
     piecewise = cfg["kind"] in ("piecewise", "face")
-    batch = (args.batch or (512 if config == "C4" else 64)) if args.scaling == "strong" else F * world
-    frame_ids = hgdist.job_frame_ids(args.scaling, rank, world, F, batch)     # different ranks get different frames of the same sequence
+    batch = (batch_arg or (512 if config == "C4" else 64)) if scaling == "strong" else F * world
+    frame_ids = hgdist.job_frame_ids(scaling, rank, world, F, batch)     # different ranks get different frames of the same sequence
     F = len(frame_ids)                                       # (strong scaling: block sizes differ by at most one between ranks)
     if F == 0:
         raise SystemExit(f"bench.py: --batch {batch} leaves rank {rank} of {world} without a frame")
@@ -234,7 +265,7 @@ def measure(args, config, F, env, primary=True):
         ctx.piecewise_set_frames(np.concatenate(frames), geoms, offs)
         run_resident = ctx.warp_inverse_piecewise_frames_device
         workload = (f"{config}: {W}x{H} RGBA piecewise-affine, {mesh_txt} "
-                    f"({tris.size // 3} triangles), " + (f"{batch} frames/step over {world} GPU(s)" if args.scaling == "strong" else f"{F} frames/GPU/step"))
+                    f"({tris.size // 3} triangles), " + (f"{batch} frames/step over {world} GPU(s)" if scaling == "strong" else f"{F} frames/GPU/step"))
     else:
         s4 = wl.corners(W, H)
         d4s = [wl.projective_dst(W, H, 0.0125 * (i % 10)) for i in frame_ids]
@@ -250,12 +281,12 @@ def measure(args, config, F, env, primary=True):
         solve_txt = ", 8x8 DLT solve per frame on the device inside the step"
         run_resident = ctx.warp_inverse_geometric_frames_device
         workload = (f"{config}: {W}x{H} RGBA projective, 4 corner points, " +
-                    (f"{batch} frames/step over {world} GPU(s)" if args.scaling == "strong" else f"{F} frames/GPU/step") + solve_txt)
+                    (f"{batch} frames/step over {world} GPU(s)" if scaling == "strong" else f"{F} frames/GPU/step") + solve_txt)
 
     run = run_resident
     # --points fresh: a ring of R point sets (the config's own sequence shifted by k frames), one uploaded per timed step
     fresh_sets = None
-    if piecewise and args.points in ("both", "fresh") and args.sources != "distinct":
+    if piecewise and points in ("both", "fresh") and sources != "distinct":
         R = 8
         fresh_sets = []
         for k in range(R):
@@ -267,7 +298,7 @@ def measure(args, config, F, env, primary=True):
             o_k, t_k = hg.pack_offsets(g_k)
             fresh_sets.append({"frames": fr_k, "geoms": g_k, "offs": o_k, "total": t_k, "args": ctx.frame_set_args(np.concatenate(fr_k), g_k, o_k)})
         total = max([total] + [fs["total"] for fs in fresh_sets])
-    elif not piecewise and args.points in ("both", "fresh") and args.sources != "distinct":
+    elif not piecewise and points in ("both", "fresh") and sources != "distinct":
         fresh_sets = []                                      # projective: the corner sets of the sequence shifted by k frames
         for k in range(8):
             d_k = [wl.projective_dst(W, H, 0.0125 * ((i + k) % 10)) for i in frame_ids]
@@ -377,12 +408,21 @@ def measure(args, config, F, env, primary=True):
     def roofline_block(k_ms, launches, sources, elapsed_s):
         achieved = algo_bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = _pmc_traffic(config, F, sources)
+        # fabric_frac: the bytes that really crossed the memory fabric (PMC pass of the same workload, incl. Infinity-Cache hits) per launch /
+        # THIS run's kernel time / peak -- a fraction that cannot exceed 1, next to the algorithmic `frac` that can when frames share a source;
+        # write_floor_ms: the output alone (4 * sum N_out, written exactly once) at the ~6.3 TB/s a streaming kernel reaches on this part
+        write_bytes = float(sum(4 * no for no in n_out))
         return {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "step_frac": step_frac(elapsed_s),
                 "step_ms": round(elapsed_s * 1e3 / args.steps, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "fabric_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and k_ms > 0 else None,
+                "write_floor_ms": round(write_bytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3, 5),
+                "kernel_ms_over_write_floor": round(k_ms / (write_bytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3), 3) if write_bytes > 0 else None,
                 "kernel_ms": round(k_ms, 5), "launches_timed": launches, "algorithmic_bytes_per_launch": int(algo_bytes_per_launch),
                 "note": "achieved = (4*N_out + 4*N_hit summed over the frames of one launch) / mean hipEvent duration of that kernel; "
-                        "step_frac = the same bytes / wall time per step (all kernels of the step, boundaries, launch gaps) / peak"}
+                        "step_frac = the same bytes / wall time per step (all kernels of the step, boundaries, launch gaps) / peak; "
+                        "fabric_frac = `traffic` (measured fabric bytes per launch, from the committed PMC pass) / kernel_ms / peak (<= 1 by construction); "
+                        "write_floor_ms = 4 * sum N_out / 6.3 TB/s (the output stream alone at the achievable rate)"}
 
     verified, checks = True, []
 
@@ -592,10 +632,15 @@ def measure(args, config, F, env, primary=True):
     e2e_ms, e2e_value = hgdist.end_to_end(ms_per_step, broadcast_ms, px_all)
     line = {"metric": "Mpixels/s warped (piecewise-affine, 4K RGBA)" if config == "C3" else f"Mpixels/s warped ({config})",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8 pixels / f64 coordinates", "data": "synthetic",
             "config": {"workload": workload + (" on a shared source" if primary_src == "shared" else ", one source per frame"),
-                       "frames_per_gpu_per_step": F if args.scaling == "weak" else None, "frames_per_step_all_gpus": batch, "point_sets": pts_txt,
+                       "frames_per_gpu_per_step": F if scaling == "weak" else None, "frames_per_step_all_gpus": batch, "point_sets": pts_txt,
+                       "value_is": ("WEAK scaling: every GPU warps its own %d frames per step, so `value` grows ~N x by construction; the one-off fan-out of the shared source is "
+                                    "EXCLUDED (inputs resident) and priced in end_to_end; north_star's fixed-batch lines are the \"scaling\": \"strong\" entries under `also`" % F)
+                                   if scaling == "weak" else
+                                   ("STRONG scaling: a fixed batch of %d frames per step split over the GPUs; `value` excludes the one-off fan-out of the shared source, "
+                                    "end_to_end includes it" % batch),
                        "rccl_world": world, "ranks": ranks,
                        "source_fanout": None if world == 1 else f"rank 0 -> {world} ranks: dist.scatter of 1/{world} slices + all_gather_into_tensor over RCCL (every xGMI link carries 1/{world} of the image)",
                        "end_to_end": {"ms_per_batch_incl_broadcast": round(e2e_ms, 4), "value_mpixels_per_s_incl_broadcast": round(e2e_value, 1),

@@ -231,3 +231,27 @@ def test_bench_self_launch_command():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-dry-run"], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, WORLD_SIZE="8", RANK="0", LOCAL_RANK="0"))
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["launch"] is None
+
+
+def test_bench_default_also_entries():
+    """What the driver's one command records: `python bench.py [--gpus N --steps K --warmup W]` measures the headline AND the other
+    BASELINE.json configs; with N > 1 also north_star's fixed-batch (strong) lines.  Any workload-selecting flag means "exactly this"."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hg_bench", os.path.join(ROOT, "bench.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+
+    def ns(**kw):
+        base = dict(config="C3", frames=64, sources="both", points="both", scaling="weak", batch=0, no_verify=False, also=None)
+        base.update(kw)
+        return argparse.Namespace(**base)
+    assert B.also_entries(ns(), 1) == [("C4", 64, "weak"), ("C5", 8, "weak"), ("C2", 64, "weak")]
+    assert B.also_entries(ns(), 8) == [("C4", 64, "weak"), ("C5", 8, "weak"), ("C2", 64, "weak"), ("C4", 512, "strong"), ("C5", 64, "strong")]
+    for flag in (dict(config="C4"), dict(frames=8), dict(sources="shared"), dict(points="resident"), dict(scaling="strong"), dict(batch=64), dict(no_verify=True)):
+        assert B.also_entries(ns(**flag), 8) == [], flag
+    assert B.also_entries(ns(also="none"), 8) == [] and B.also_entries(ns(also=""), 1) == []
+    assert B.also_entries(ns(also="C4:32,C5:64:strong", frames=16), 2) == [("C4", 32, "weak"), ("C5", 64, "strong")]
+    assert B.also_entries(ns(also="C2", frames=16), 1) == [("C2", 16, "weak")]
+    with pytest.raises(SystemExit):
+        B.also_entries(ns(also="C9:4"), 1)

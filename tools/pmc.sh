@@ -4,7 +4,7 @@
 # counters never return -- each ran into its timeout.  Only SQ_*/GRBM_* and FETCH_SIZE / WRITE_SIZE passes are usable here.
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_$1; mkdir -p $out
-B="python bench.py --no-cpu-baseline --steps 3 --warmup 1"
+B="python bench.py --no-cpu-baseline --also none --steps 3 --warmup 1"
 timeout 240 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $out/p1 -o p -- $B > $out/p1.log 2>&1
 timeout 240 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $out/p2 -o p -- $B > $out/p2.log 2>&1
 timeout 240 rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM -d $out/p3 -o p -- $B > $out/p3.log 2>&1

@@ -7,7 +7,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python bench.py --no-cpu-baseline "$@" > $out/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/trace -o t -- python bench.py --no-cpu-baseline --also none "$@" > $out/bench_trace.log 2>&1
 P="--steps 3 --warmup 1"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU -d $out/pmc1 -o p -- python bench.py --no-cpu-baseline $P > $out/bench_pmc1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d $out/pmc2 -o p -- python bench.py --no-cpu-baseline $P > $out/bench_pmc2.log 2>&1

@@ -27,12 +27,24 @@ for db in sorted(glob.glob(os.path.join(out, "trace", "*.db"))):
         print(f"{calls:7d} {total/1e3 if total > 1e6 else total:12.1f} {avg/1e3 if avg > 1e5 else avg:10.2f} {pct:6.2f}  {name[:110]}")
     print("   (units as reported by rocprofv3's top_kernels view)")
     try:
-        rows = con.execute("select kernel_name, count(*), avg(end-start), min(end-start), max(end-start) from kernels where kernel_name like '%hg::%' group by kernel_name").fetchall()
+        rows = con.execute("select name, count(*), avg(end-start), min(end-start), max(end-start) from kernels where name like '%hg::%' group by name").fetchall()
         print("== per-dispatch durations of the hg kernels (ns)")
         for r in rows:
             print(f"  {r[0][:70]:70s} n={r[1]:4d} avg={r[2]:12.0f} min={r[3]:12.0f} max={r[4]:12.0f}")
     except Exception as e:  # schema differs between rocprof versions
         print("  (kernels view unavailable:", e, ")")
+    # the plain `python bench.py` measures several configs in one process: the same kernel name then covers launches of different
+    # workloads -- told apart by their grid (workgroups = grid_x / workgroup_x; C3 x 64 frames: 35 840 row groups, C4: 19 968, ...)
+    for col in ("name", "kernel_name"):
+        try:
+            rows = con.execute(f"select {col}, grid_x / workgroup_x, count(*), avg(end-start), min(end-start), max(end-start) from kernels "
+                               f"where {col} like '%hg::%' group by {col}, grid_x / workgroup_x having count(*) >= 5 order by sum(end-start) desc limit 24").fetchall()
+        except Exception:
+            continue
+        print("== the same by launch shape (kernel, workgroups per launch; ns)")
+        for r in rows:
+            print(f"  {r[0][:70]:70s} wgs={r[1]:7d} n={r[2]:4d} avg={r[3]:12.0f} min={r[4]:12.0f} max={r[5]:12.0f}")
+        break
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
