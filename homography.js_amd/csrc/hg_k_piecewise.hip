@@ -5,12 +5,6 @@
 #include "hg_dev.h"
 #include <type_traits>
 
-#ifndef HG_ROWS_REUSE_UNSAFE
-#define HG_ROWS_REUSE_UNSAFE 1
-#endif
-#ifndef HG_ROWS_REUSE
-#define HG_ROWS_REUSE 0
-#endif
 namespace hg {
 
 // ------------------------------------------------------------------------------------------------ k_tri_setup
@@ -759,10 +753,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         const bool in_regs = cnt <= 64;                     // wave-uniform
         int lo_r = 0x7fffffff, hi_r = 0, key_r = 0;
         if (in_regs && lane < cnt) { lo_r = s_lo[base + lane]; hi_r = s_hi[base + lane]; key_r = s_key[base + lane]; }
-#if HG_ROWS_REUSE
-        int cur_key = -1;                                   // (no key: real keys are >= 0, the "no triangle" key has bit 31 and a record offset)
-        double2 cur_a = make_double2(0.0, 0.0), cur_b = cur_a;
-#endif
         for (int wb = w0; wb < nwin; wb += wstep * PH) {
             uint32_t px[PH][4];
             bool empty[PH];                                 // wave-uniform
@@ -812,7 +802,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     // :1383-1384 for pixels k0 .. k0 + N - 1 of the window: (m0*x) + (m2*y) + m4.  m0*x is exact in fp64 (24-bit f32 significand times
                     // an integer below 2^24), so fma(m0, x, m2*y) == RN((m0*x) + (m2*y)) bit for bit; a one_fma frame's records already hold
                     // A = (m2*y) + m4 in that place and nothing is added (the branch is uniform for the workgroup)
-                    auto coords = [&](auto n_tag, int k0, double *v, auto reuse_tag) {
+                    auto coords = [&](auto n_tag, int k0, double *v) {
                         constexpr int N = decltype(n_tag)::value;
                         if constexpr (SELF == 0) {          // (row lists: always the long form)
 #pragma unroll
@@ -823,36 +813,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                                 v[2 * k] = fma(ra.x, xd, ra.y) + rc.x; v[2 * k + 1] = fma(rb.x, xd, rb.y) + rc.y;
                             }
                         } else {
-#if HG_ROWS_REUSE
-                            if (decltype(reuse_tag)::value && one_fma) {
-#pragma unroll
-                                for (int k = 0; k < N; k++) {
-                                    const int bk = best[k0 + k];
-                                    const int sk = __builtin_amdgcn_readfirstlane(bk);
-                                    const double xd = xd0 + (double)((k0 + k) * 64);
-                                    if (__ballot(bk != sk) == 0ull) {        // the 64 pixels of this piece share one span: its record is read once per run of such pieces
-                                        if (sk != cur_key) {
-                                            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (sk & KADDR));
-#if HG_ROWS_REUSE == 2
-                                            const double2 ta = mrec[0], tb = mrec[1];
-                                            cur_a = make_double2(sgpr_f64(ta.x), sgpr_f64(ta.y)); cur_b = make_double2(sgpr_f64(tb.x), sgpr_f64(tb.y)); cur_key = sk;
-#elif HG_ROWS_REUSE == 3
-                                            const double2 ta = mrec[0], tb = mrec[1];
-                                            cur_a = make_double2(sgpr_f64(ta.x), ta.y); cur_b = make_double2(sgpr_f64(tb.x), tb.y); cur_key = sk;
-#else
-                                            cur_a = mrec[0]; cur_b = mrec[1]; cur_key = sk;
-#endif
-                                        }
-                                        v[2 * k] = fma(cur_a.x, xd, cur_a.y); v[2 * k + 1] = fma(cur_b.x, xd, cur_b.y);
-                                    } else {
-                                        const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (bk & KADDR));
-                                        const double2 ra = mrec[0], rb = mrec[1];
-                                        v[2 * k] = fma(ra.x, xd, ra.y); v[2 * k + 1] = fma(rb.x, xd, rb.y);
-                                    }
-                                }
-                                return;
-                            }
-#endif
 #pragma unroll
                             for (int k = 0; k < N; k++) {
                                 const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (best[k0 + k] & KADDR));
@@ -878,7 +838,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                             if (kk == 2 && c0 + 128 >= W) { px[p][2] = px[p][3] = 0u; continue; }
                             double v[4];
                             int r[4];
-                            coords(two_t{}, kk, v, std::true_type{});
+                            coords(two_t{}, kk, v);
                             round_half_x4(v, r);
 #pragma unroll
                             for (int k = kk; k < kk + 2; k++)
@@ -891,7 +851,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                         // stores would be dropped by the range check anyway; wave-uniform test) -- a 2170-pixel row has 2 dead pieces in 36
                         if (STEP == 2 && kk == 2 && c0 + 128 >= W) { px[p][2] = px[p][3] = 0u; continue; }
                         double h[2 * STEP], rd[2 * STEP];
-                        coords(step_t{}, kk, h, std::integral_constant<bool, (HG_ROWS_REUSE_UNSAFE != 0)>{});
+                        coords(step_t{}, kk, h);
                         if constexpr (STEP == 4) round_x8(h, rd); else round_x4(h, rd);
 #pragma unroll
                         for (int k = kk; k < kk + STEP; k++) {

@@ -16,6 +16,9 @@ namespace hg {
 // else.  The taller workgroup is affordable because it is NARROW: spans are kept only where they overlap the tile's columns,
 // candidates only for triangles that reach the tile in rows AND columns.
 // Timing experiments that led here: EXPERIMENTS.md R4.3.
+#ifndef HG_TILE_NE
+#define HG_TILE_NE 0
+#endif
 #ifndef HG_TILE_PB
 #define HG_TILE_PB 4
 #endif
@@ -295,6 +298,60 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
         sl = fminf(fmaxf(sl, -1.f), 1.f);
         return (int)rintf(sl * (float)c);
     };
+#if HG_TILE_NE
+    // Blocks NO span of the tile reaches (a third of C4's: the window around a face mesh) are zeros: they take two 16-byte stores per
+    // lane instead of the whole pixel body.  Every wave derives the same mask of non-empty blocks from the bin counts (lane b: block b,
+    // one ballot; no list in LDS, no barrier) and walks its share -- the wave-th, wave + 4-th, ... set bit -- with scalar instructions only.
+    static_assert(kTileBlocks <= 64, "one mask bit per 64-column block");
+    unsigned long long m_ne;
+    {
+        int any = 0;
+        if (lane < nblk) {
+#pragma unroll
+            for (int r = 0; r < kTileRows; r++) any |= s_bincnt[lane * kTileRows + r];
+        }
+        m_ne = __ballot(any != 0);
+    }
+    {
+        unsigned long long m_e = ~m_ne & (nblk >= 64 ? ~0ull : ((1ull << nblk) - 1ull));
+        const bool vec = (W & 3) == 0 && ((fd.out_off + (uint64_t)r0 * W * 4) & 15) == 0;        // (wave-uniform)
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        const v4u zero4 = { 0u, 0u, 0u, 0u };
+        for (int i = 0; m_e; i++) {
+            const int blk = __builtin_amdgcn_readfirstlane(__ffsll((long long)m_e) - 1);
+            m_e &= m_e - 1;
+            if ((i & 3) != wave) continue;
+            const int xs0 = t0 + (blk << 6);
+            if (vec && xs0 + 64 <= W) {                      // lane l: row l >> 4 (and + 4), columns 4 (l & 15) .. + 3
+                const int rw = lane >> 4, xs = xs0 + ((lane & 15) << 2);
+                __builtin_amdgcn_raw_buffer_store_b128(zero4, dst, rw < nrows ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
+                __builtin_amdgcn_raw_buffer_store_b128(zero4, dst, rw + 4 < nrows ? (uint32_t)((rw + 4) * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
+            } else {
+                const int xs = xs0 + lane;
+#pragma unroll
+                for (int rw = 0; rw < kTileRows; rw++)
+                    __builtin_amdgcn_raw_buffer_store_b32(0u, dst, (xs < W && rw < nrows) ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
+            }
+        }
+    }
+    // this wave's non-empty blocks; kTilePB of them in flight before the first is transposed and stored
+    unsigned long long m = m_ne;
+    for (int i = 0; i < wave && m; i++) m &= m - 1;
+    while (m) {
+        uint32_t px[kTilePB][8];
+        int blks[kTilePB];
+        uint32_t skp = 0;                                    // the blocks' skews, 4 bits each: only (q + sk) mod 8 is ever used
+#pragma unroll
+        for (int b = 0; b < kTilePB; b++) {
+            blks[b] = m ? __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1) : -1;
+            m &= m - 1; m &= m - 1; m &= m - 1; m &= m - 1;          // (x & (x - 1) of 0 is 0)
+        }
+#pragma unroll
+        for (int b = 0; b < kTilePB; b++) if (blks[b] >= 0) { const int sk = block_skew(blks[b]) & 7; skp |= (uint32_t)sk << (4 * b); resolve_gather(blks[b], sk, px[b]); }
+#pragma unroll
+        for (int b = 0; b < kTilePB; b++) if (blks[b] >= 0) transpose_store(blks[b], (int)((skp >> (4 * b)) & 7u), px[b]);
+    }
+#else
     // this wave's blocks: wave, wave + 4, ...; kTilePB of them in flight before the first is transposed and stored
     for (int blk = wave; blk < nblk; blk += 4 * kTilePB) {
         uint32_t px[kTilePB][8];
@@ -304,6 +361,7 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
 #pragma unroll
         for (int b = 0; b < kTilePB; b++) if (blk + 4 * b < nblk) transpose_store(blk + 4 * b, sk[b], px[b]);
     }
+#endif
 }
 
 void launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream)

@@ -51,6 +51,22 @@ def test_random_call_sequences_against_the_live_reference():
 
 
 @needs_js
+@pytest.mark.skipif(not os.path.exists("/root/reference/Homography.js"), reason="the live reference exists only in the build container")
+@pytest.mark.parametrize("solve", ["reference", "addon"])
+def test_reference_class_patched_over_the_addon(solve):
+    """INTEGRATION.md section B, executed: the REFERENCE's own class with its four private loops replaced by addon calls exactly as
+    homography.js_amd/js/reference_patch.mjs prints them (reference-state forms included), over the mock addon.  Every golden script (4K /
+    8K included) gives the bytes the reference recorded, and 250 random call sequences give, op by op, the exception, state, path and
+    bytes of the UNPATCHED reference.  The fast calls and the state forms must both have been exercised."""
+    args = ["250", "11"] if solve == "reference" else ["250", "5", "--skip-big", "--own-solve"]
+    rc, res = _node("ref_patched_over_addon.mjs", *args, timeout=900)
+    assert res["failures"] == [] and rc == 0
+    g, q = res["golden"], res["sequences"]
+    assert g["cases"] >= (144 if solve == "reference" else 130) and g["warps"] >= 310 and g["staleStateWarps"] >= 40 and g["expectedThrows"] >= 30 and g["stateCalls"] >= 30
+    assert q["sequences"] == 250 and q["warps"] >= 800 and q["stateCalls"] >= 50 and q["fastCalls"] >= 500
+
+
+@needs_js
 def test_host_side_javascript():
     rc, res = _node("test_host.mjs")
     assert res["failures"] == [] and rc == 0

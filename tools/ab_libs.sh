@@ -20,7 +20,7 @@ for line in open(sys.argv[1]):
     lib, _, js = line.partition(" ")
     try: d = json.loads(js)
     except Exception: print(line.rstrip()); continue
-    key = (d["config"], d["sources"], " ".join(f"{k}={v}" for k, v in d.items() if k not in ("config", "F", "sources", "kernel", "kernel_ms", "step_ms", "same_bytes", "redone")), d["kernel"][:40])
+    key = (d["config"], d["sources"], " ".join(f"{k}={v}" for k, v in d.items() if k not in ("config", "F", "sources", "kernel", "kernel_ms", "step_ms", "same_bytes", "redone")), str(d["kernel"])[:40])
     rows.setdefault(key, collections.OrderedDict()).setdefault(lib, []).append((d["kernel_ms"], d["step_ms"], d["same_bytes"], d["redone"]))
 for key, libs in rows.items():
     print(*key)
