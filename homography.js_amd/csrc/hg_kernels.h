@@ -133,6 +133,7 @@ constexpr int kPatchMaxRowSpansDense = 480;
 void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream);
 // Sheared meshes (self-span path only): tiles of 8 rows x <= 2048 columns whose gathers follow the source rows (hg_k_tile.hip).
 void launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream);
+void launch_pw_tile_p(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, int n_cus, hipStream_t stream);   // persistent, wave-specialised form
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
 // the pixel loop :1042-1056 reading the map.

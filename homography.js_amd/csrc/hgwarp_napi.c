@@ -782,7 +782,16 @@ static napi_value fn_get_matrices(napi_env env, napi_callback_info info)
  * arrays.  `ownFrames` (optional argument) = the old behaviour: every frame its own pooled buffer with a GC-bound life time.
  * With per-frame sources ({images}: the video loop warp(image_f), README.md:121-137) the pass is pipelined frame by frame:
  * H2D(f + 1) on the context's copy stream runs while D2H(f) travels the other way on the warp stream. */
-static void slab_finalize(napi_env env, void *data, void *hint) { (void)env; (void)hint; if (data) hg_host_free(data); }
+static void slab_finalize(napi_env env, void *data, void *hint)
+{
+    const size_t bytes = hint ? *(size_t *)hint : 0;          /* (the hint is the slab's size: what was added to V8's external-memory counter and to the pinned total) */
+    free(hint);
+    if (data) hg_host_free(data);
+    pool_t *P = NULL;
+    if (!bytes || napi_get_instance_data(env, (void **)&P) != napi_ok || !P) return;        /* (the env is going away) */
+    P->pin_bytes -= bytes < P->pin_bytes ? bytes : P->pin_bytes;
+    int64_t adj; napi_adjust_external_memory(env, -(int64_t)bytes, &adj);
+}
 
 static void slab_drop(napi_env env, slab_t *sl, int detach)
 {
@@ -794,15 +803,24 @@ static void slab_drop(napi_env env, slab_t *sl, int detach)
 }
 
 /* JS array of F Uint8ClampedArray views, frame f at byte offs[f] of slab `slot` (grown to `total` bytes if needed) */
-static napi_value slab_frames(napi_env env, handle_t *h, int slot, const hg_geom *g, const size_t *offs, int F, size_t total, uint8_t **base)
+/* The slab is page-locked memory like the pooled frames and counts against the same cap (setPinnedLimit): when it does not fit -- or the
+ * cap is 0, or the allocation fails -- *fallback is set, NULL is returned WITHOUT a pending exception, and the batch gets own frames. */
+static napi_value slab_frames(napi_env env, handle_t *h, int slot, const hg_geom *g, const size_t *offs, int F, size_t total, uint8_t **base, int *fallback)
 {
     slab_t *sl = &h->slab[slot];
+    *fallback = 0;
     if (total > sl->cap || !sl->ab) {
+        pool_t *P = pool_of(env); if (!P) return NULL;
         slab_drop(env, sl, 0);
         const size_t want = total + total / 8 + 4096;
+        for (int i = 0; i < P->npins && P->pin_bytes + want > P->pin_limit; i++) if (P->pins[i].ptr && !P->pins[i].in_use) pin_drop(P, i);   /* idle pooled frames make room */
+        if (P->pin_limit == 0 || P->pin_bytes + want > P->pin_limit) { P->stat_fallback++; *fallback = 1; return NULL; }
         void *p = NULL; napi_value ab;
-        if (hg_host_alloc(want, &p) != HG_OK) return throw_str(env, "hgwarp: cannot allocate the page-locked frame slab of this batch");
-        if (napi_create_external_arraybuffer(env, p, want, slab_finalize, NULL, &ab) != napi_ok) { hg_host_free(p); return throw_str(env, "hgwarp: cannot wrap the frame slab"); }
+        size_t *hint = (size_t *)malloc(sizeof *hint);
+        if (!hint || hg_host_alloc(want, &p) != HG_OK) { free(hint); P->stat_fallback++; *fallback = 1; return NULL; }
+        *hint = want;
+        if (napi_create_external_arraybuffer(env, p, want, slab_finalize, hint, &ab) != napi_ok) { hg_host_free(p); free(hint); return throw_str(env, "hgwarp: cannot wrap the frame slab"); }
+        P->pin_bytes += want;                                 /* (slab_finalize takes both back) */
         int64_t adj; napi_adjust_external_memory(env, (int64_t)want, &adj);
         if (napi_create_reference(env, ab, 1, &sl->ab) != napi_ok) return throw_str(env, "hgwarp: cannot keep the frame slab");
         sl->ptr = p; sl->cap = want;
@@ -880,8 +898,13 @@ static napi_value run_batch(napi_env env, handle_t *h, const batch_job *job, con
     napi_value arr = NULL;
     uint8_t *base = NULL;
     uint8_t **outs = NULL;
-    if (!own) { arr = slab_frames(env, h, slot, g, offs, F, total, &base); if (!arr) { free(offs); return NULL; } }
-    else {
+    if (!own) {
+        int fallback = 0;
+        arr = slab_frames(env, h, slot, g, offs, F, total, &base, &fallback);
+        if (!arr && !fallback) { free(offs); return NULL; }
+        if (!arr) own = true;                                 /* no room under the pinned cap (or no page-locked memory): own frames, as without the option */
+    }
+    if (own) {
         outs = (uint8_t **)calloc((size_t)F, sizeof *outs);
         if (!outs || napi_create_array_with_length(env, F, &arr) != napi_ok) { free(offs); free(outs); return throw_str(env, "hgwarp: out of memory (frames)"); }
         for (int f = 0; f < F; f++) {
@@ -933,7 +956,7 @@ static napi_value run_batch(napi_env env, handle_t *h, const batch_job *job, con
                 const size_t ppx = (g[f - 1].obj_w > 0 && g[f - 1].obj_h > 0) ? (size_t)g[f - 1].obj_w * g[f - 1].obj_h : 0;
                 if (now != redone && ppx) rc = hg_download_behind_warps(h->ctx, own ? outs[f - 1] : base + offs[f - 1], d_out + offs[f - 1], ppx * 4);
                 redone = now;
-            }
+            } else if (rc == HG_OK) redone = hg_redone_frames(h->ctx);      /* f == 0: that binding settled runs queued BEFORE this batch; their redos are not frame 0's */
             if (f == F || rc != HG_OK) break;
             const size_t px = (g[f].obj_w > 0 && g[f].obj_h > 0) ? (size_t)g[f].obj_w * g[f].obj_h : 0;
             rc = hg_fence_copies(h->ctx);                                                   /* the warp stream waits for image f */

@@ -192,17 +192,36 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
     ok(threw, 'unknown device id must throw a string');
     mh.close();
 }
-{   // life time of batch frames: views of ONE page-locked buffer owned by the instance, reused by the next warpBatch() on it, released at
-    // once by frames.release(); {ownFrames: true} gives every frame a buffer of its own.  Nothing waits for the garbage collector: a loop
-    // of batches that never yields never falls back to plain V8 arrays.
+{   // life time of batch frames.  Default: every frame owns its buffer (the reference's loop returns independent frames; a caller may
+    // accumulate them across calls).  Opt-in {reuseBatchOutput: true}: views of ONE page-locked buffer owned by the instance, reused by the
+    // next warpBatch() on it, released at once by frames.release(); nothing then waits for the garbage collector: a loop of batches that
+    // never yields never falls back to plain V8 arrays.  The slab counts against setPinnedLimit and falls back to own frames beyond it.
     const bh = new Homography('piecewiseaffine');
     bh.setSourcePoints(src, lcgImage(W, H, 21), W, H, false);
+    {   // the default: frames accumulated across calls stay what they were
+        const keep = [];
+        keep.push(...bh.warpBatch(sets.slice(0, 3), { inverse: true }));
+        const shas = keep.map((o) => sha(o.data));
+        keep.push(...bh.warpBatch([sets[2], sets[1], sets[0]], { inverse: true }));
+        ok(new Set(keep.map((o) => o.data.buffer)).size === 6, 'by default every frame of a batch owns its buffer');
+        ok(keep.slice(0, 3).every((o, f) => sha(o.data) === shas[f]) && sha(keep[3].data) === shas[2] && sha(keep[5].data) === shas[0], 'frames kept across warpBatch() calls are not overwritten');
+        const inst = new Homography('piecewiseaffine', undefined, undefined, { reuseBatchOutput: true });
+        inst.setSourcePoints(src, lcgImage(W, H, 21), W, H, false);
+        const v = inst.warpBatch(sets.slice(0, 3), { inverse: true });
+        ok(new Set(v.map((o) => o.data.buffer)).size === 1 && v.every((o, f) => sha(o.data) === shas[f]), 'the constructor option turns the shared buffer on for the instance');
+        ok(new Set(inst.warpBatch(sets.slice(0, 3), { inverse: true, reuseBatchOutput: false }).map((o) => o.data.buffer)).size === 3, '... and a call can turn it off');
+        const lim = Homography.setPinnedLimit(0);                   // no page-locked memory allowed: the batch silently gets own frames
+        const fb = inst.warpBatch(sets.slice(0, 3), { inverse: true });
+        ok(new Set(fb.map((o) => o.data.buffer)).size === 3 && fb.every((o, f) => sha(o.data) === shas[f]), 'setPinnedLimit(0): own frames, same bytes');
+        Homography.setPinnedLimit(2 * 2 ** 30);
+        inst.close();
+    }
     const before = Homography.poolStats();
-    const b1 = bh.warpBatch(sets.slice(0, 3), { inverse: true });
+    const b1 = bh.warpBatch(sets.slice(0, 3), { inverse: true, reuseBatchOutput: true });
     const want1 = b1.map((o) => sha(o.data));
     ok(new Set(b1.map((o) => o.data.buffer)).size === 1, 'the frames of a batch are views of one buffer');
     ok(typeof b1.release === 'function' && Object.keys(b1).length === 3, 'release() is a non-enumerable method of the returned array');
-    const b2 = bh.warpBatch([sets[2], sets[1], sets[0]], { inverse: true });                  // (a batch that fits the buffer as it stands)
+    const b2 = bh.warpBatch([sets[2], sets[1], sets[0]], { inverse: true, reuseBatchOutput: true });                  // (a batch that fits the buffer as it stands)
     ok(b2[0].data.buffer === b1[0].data.buffer, 'the next batch reuses the buffer');
     ok(sha(b2[0].data) === want1[2] && sha(b2[2].data) === want1[0], 'the next batch holds its own frames');
     ok(sha(b1[0].data.subarray(0, 4096)) === sha(b2[0].data.subarray(0, 4096)), 'the previous batch now shows the new frames (documented life time)');
@@ -210,20 +229,20 @@ ok(o1.width === 400 && o1.height === 200 && sha(o1.data) === sha(o2.data), 'proj
         const ims = [lcgImage(W, H, 61), lcgImage(W, H, 62), lcgImage(W, H, 63)];
         const pinned = ims.map((im) => { const p = Homography.pinnedImage(W, H); p.data.set(im.data); return p; });
         const wantI = bh.warpBatch(sets.slice(0, 3), { inverse: true, images: ims, ownFrames: true }).map((o) => sha(o.data));
-        ok(bh.warpBatch(sets.slice(0, 3), { inverse: true, images: pinned }).every((o, f) => sha(o.data) === wantI[f]), 'pinned sources give the same frames');
+        ok(bh.warpBatch(sets.slice(0, 3), { inverse: true, images: pinned, reuseBatchOutput: true }).every((o, f) => sha(o.data) === wantI[f]), 'pinned sources give the same frames');
         ok(wantI[0] !== want1[0], 'per-frame sources should differ from the instance image');
     }
     const own = bh.warpBatch(sets.slice(0, 3), { inverse: true, ownFrames: true });
     ok(new Set(own.map((o) => o.data.buffer)).size === 3 && own.every((o, f) => sha(o.data) === want1[f]), 'ownFrames: one buffer per frame, same bytes');
-    bh.warpBatch(sets.slice(2, 5), { inverse: true });
+    bh.warpBatch(sets.slice(2, 5), { inverse: true, reuseBatchOutput: true });
     ok(own.every((o, f) => sha(o.data) === want1[f]), 'ownFrames survive later batches');
-    for (let it = 0; it < 40; it++) bh.warpBatch(sets, { inverse: true });                    // 200 frames of ~0.7 MB .. without yielding
+    for (let it = 0; it < 40; it++) bh.warpBatch(sets, { inverse: true, reuseBatchOutput: true });                    // 200 frames of ~0.7 MB .. without yielding
     const after = Homography.poolStats();
     ok(after.fallbackToV8 === before.fallbackToV8, `a loop of batches must not fall back to V8 arrays (${JSON.stringify(after)})`);
-    const b3 = bh.warpBatch(sets.slice(0, 2), { inverse: true });
+    const b3 = bh.warpBatch(sets.slice(0, 2), { inverse: true, reuseBatchOutput: true });
     b3.release();
     ok(b3.every((o) => o.data.length === 0), 'release() empties the frames');
-    ok(bh.warpBatch(sets.slice(0, 3), { inverse: true }).every((o, f) => sha(o.data) === want1[f]), 'a batch after release() gets a fresh buffer');
+    ok(bh.warpBatch(sets.slice(0, 3), { inverse: true, reuseBatchOutput: true }).every((o, f) => sha(o.data) === want1[f]), 'a batch after release() gets a fresh buffer');
     bh.close();
 }
 {   // frames of 1 MiB and more come from the page-locked pool as external ArrayBuffers; release() returns one at once

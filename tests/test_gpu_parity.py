@@ -27,6 +27,7 @@ LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds":
            "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0, "self_spans": 1, "safe_spans": 0},
            "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16, "self_spans": 0, "xcc_rotate": 1, "tri_group": 0},
            "tile": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 1, "xcc_rotate": 1},
+           "tile_p": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 2, "xcc_rotate": 0},
            "rows8": {"min_row_groups": 0, "patch": 0, "self_spans": 1, "rows8": 1, "safe_spans": 1}}
 
 
