@@ -34,7 +34,6 @@ static int create_common(int device_id, void *stream, bool own, hg_ctx **out)
         return fail(nullptr, HG_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + "; libhgwarp is built for gfx950 (MI355X) only");
     hg_ctx *c = new hg_ctx();
     c->device = device_id;
-    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     {   // XCC count of this device / partition (8 on an unpartitioned MI355X): the warp kernels map block ids to per-XCD row bands
         // with it (speed only -- any value gives the same pixels).  Not a power of two or unknown: no banding.
         int nx = 0;
@@ -220,6 +219,7 @@ extern "C" int hg_copy_to_device(hg_ctx *c, void *dst, const void *src, size_t b
 }
 
 extern "C" int hg_last_piecewise_kernel(hg_ctx *c) { return c ? c->pw_last_kernel : 0; }
+extern "C" int hg_last_piecewise_variant(hg_ctx *c) { return c ? c->pw_last_variant : 0; }
 extern "C" int hg_last_forward_kernel(hg_ctx *c) { return c ? c->fwd_last_kernel : 0; }
 
 extern "C" int hg_last_piecewise_self(hg_ctx *c) { return c && c->pw_self ? 1 : 0; }
@@ -238,7 +238,7 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "hi_bounds")) c->opt_hi_bounds = value != 0;
     else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
     else if (!std::strcmp(key, "compact")) c->opt_compact = value < 0 ? -1 : (value ? 1 : 0);
-    else if (!std::strcmp(key, "tile")) { c->opt_tile = value < 0 ? -1 : (value >= 2 ? 2 : (value ? 1 : 0)); c->pw_tile_disabled = false; }
+    else if (!std::strcmp(key, "tile")) { c->opt_tile = value < 0 ? -1 : (value ? 1 : 0); c->pw_tile_disabled = false; }
     else if (!std::strcmp(key, "self_spans")) { c->opt_self = value < 0 ? -1 : (value ? 1 : 0); c->pw_self_disabled = false; }
     else if (!std::strcmp(key, "tri_group")) c->opt_tri_group = value < 0 ? -1 : (value >= 64 ? 64 : (value ? 16 : 0));
     else if (!std::strcmp(key, "safe_spans")) c->opt_safe_spans = value < 0 ? -1 : (value ? 1 : 0);

@@ -421,8 +421,12 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         // per frame, alternating order, patch -> tile (EXPERIMENTS.md R4.7): C5 0.5915 -> 0.5093 ms, its mesh at 3/4, 1/2, 1/4 of the shear
         // 0.5345 -> 0.4737, 0.486 -> 0.4528, 0.437 -> 0.429; C3 0.8155 -> 0.816, C4 0.332 -> 0.330, 40x40 / 64x36 grids 0.870 -> 0.868, 0.975 ->
         // 0.950.  With a shared source it is a toss-up (C5 0.4009 -> 0.3975, 64x36 grid 0.848 -> 0.830, 40x40 grid 0.734 -> 0.747): k_pw_patch stays.
-        c->pw_tile = self_patch && !c->pw_tile_disabled && mw >= 512 && (c->opt_tile >= 0 ? c->opt_tile >= 1 : c->n_imgs > 1);
-        c->pw_tile_persist = c->pw_tile && c->opt_tile == 2;
+        // Round 6 (R6.4): with the block slopes evaluated once per tile the tile kernel also wins on a SHARED source where the mesh is steeply
+        // sheared or packs more than two spans into a 64-pixel block, k_pw_patch -> k_pw_tile: C5 (shear 0.39) 0.395 -> 0.378 ms, 64x36 grid
+        // (128 spans per 3840-pixel row) 0.834 -> 0.783; not elsewhere: 40x40 grid 0.721 -> 0.703 but 24x24 0.642 -> 0.638, C5's mesh at 3/8
+        // and 1/8 of its shear 0.353 -> 0.352 and 0.331 -> 0.338, 20x60 tall cells 0.631 -> 0.636.
+        const bool tile_shared = c->pw_shear >= 0.3 || (int64_t)c->pw_cover * 64 >= (int64_t)2 * mw;
+        c->pw_tile = self_patch && !c->pw_tile_disabled && mw >= 512 && (c->opt_tile >= 0 ? c->opt_tile == 1 : (c->n_imgs > 1 || tile_shared));
         c->pw_bands = (self_patch && c->n_tris > 256) || (self_rows && c->n_tris > 1024);
         if (c->pw_bands && (std::max(max_h, 1) + 63) / 64 > 2048) {      // (kBandMax; frames taller than 131 072 rows)
             c->pw_bands = false; c->pw_self_patch = false;
@@ -494,15 +498,13 @@ static void run_warp(hg_ctx *c, uint8_t *d_out, int16_t *map_out)
         for (const FrameDesc &d : c->pw_frames) mw = std::max(mw, d.obj_w);
         c->pw_last_kernel = 5;
         c->pw_used_patch = false;                            // (a flagged tile run disables k_pw_tile for the mesh, not k_pw_patch)
-        if (c->pw_tile_persist) launch_pw_tile_p(mesh_of(c), frames_of(c), rows_of(c), d_out, mw, c->status_next, c->n_cus, c->stream);
-        else launch_pw_tile(mesh_of(c), frames_of(c), rows_of(c), d_out, mw, c->status_next, c->stream);
-        c->rows_clean = true;
+        c->pw_last_variant = launch_pw_tile(mesh_of(c), frames_of(c), rows_of(c), d_out, mw, c->status_next, c->stream); c->rows_clean = true;
     }
-    else if (patch)      { launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
+    else if (patch)      { c->pw_last_variant = launch_pw_patch(mesh_of(c), frames_of(c), rows_of(c), d_out, c->status_next, global_records, c->stream); c->rows_clean = true; }
     else if (c->pw_fast) {
-        launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true;
+        c->pw_last_variant = launch_pw_rows(mesh_of(c), frames_of(c), rows_of(c), d_out, map_out, c->status_next, c->stream); c->rows_clean = true;
     }
-    else            launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream);
+    else          { launch_pw_fused(mesh_of(c), frames_of(c), d_out, map_out, c->stream); c->pw_last_variant = 600000; }
 }
 
 static int check_pw_state(hg_ctx *c)

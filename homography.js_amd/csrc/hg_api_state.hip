@@ -133,7 +133,6 @@ extern "C" int hg_warp_forward_piecewise_state(hg_ctx *c, const float *fwd_mats,
 {
     size_t bytes = 0;
     HG_TRY(state_common(c, fwd_mats, n_mats, geom, out_host, &bytes));
-    if (bytes == 0) return HG_OK;
     const int64_t bw = (int64_t)max_src_x - msx, bh = (int64_t)max_src_y - msy;       // the loops :955-956
     if (bw > 0 && bh > 0) {
         if (bw * bh >= ((int64_t)1 << 31)) return fail(c, HG_ERR_INVALID, "the source-point bounding box has 2^31 pixels or more: the forward path ranks source pixels in 32 bits");
@@ -143,6 +142,10 @@ extern "C" int hg_warp_forward_piecewise_state(hg_ctx *c, const float *fwd_mats,
     HG_TRY(build_state_map(c, map, cells));
     const size_t own = (map->width > 0 && map->height > 0) ? (size_t)map->width * map->height : 0;
     HG_TRY(check_state_ids(c, std::min(own, cells), n_mats));
+    // A blank output window (:440) does not stop the reference's loop: it still walks the source bounding box, reads the held map and
+    // throws at a cell that names a missing matrix -- hence the check above runs first; with every id in range the loop's stores all
+    // miss the empty array and nothing is left to do.
+    if (bytes == 0) return HG_OK;
     const size_t T = (size_t)std::max(n_mats, 1);
     HG_TRY(ensure(c, c->d_st_mats, c->st_mats_cap, T * kInvStride));
     HG_TRY(ensure(c, c->d_out_tmp, c->out_tmp_cap, bytes));

@@ -85,7 +85,6 @@ struct hg_ctx {
     int32_t pw_last_flag = 0;                                  // status word of the last frame a fused run flagged (bits 4..: which limit, see k_pw_patch<SELF>)
     long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
     int opt_min_row_groups = 1152, opt_patch = -1, opt_phase = -1, opt_geo_nw = 8;   // hg_set_option()
-    int n_cus = 256;                                           // compute units of the device (grid of the persistent tile kernel)
     int xcc_log2 = 3;                                          // log2(XCCs of the device): hipDeviceAttributeNumberOfXccs at hg_create, option "xcc"
     int opt_lds_pad = -1;                                       // KB of dynamic LDS padding per k_pw_rows workgroup (occupancy experiments)
     int opt_hi_bounds = 1;                                     // 0: fp64 bounds compares instead of the high-dword form (hg_dev.h)
@@ -131,8 +130,8 @@ struct hg_ctx {
     bool pw_self_patch = false;                                // ... through k_pw_patch (dense / sheared meshes, one source per frame)
     bool pw_tile = false;                                      // ... through k_pw_tile (8-row x <= 2048-column tiles whose gathers follow the source rows)
     bool pw_tile_disabled = false;                             // a tile exceeded its limits once: k_pw_patch for this mesh
-    int opt_tile = -1;                                         // option "tile": 1 / 2 whenever k_pw_patch<SELF> would run (2: the persistent form k_pw_tile_p), 0 never, -1 by policy
-    bool pw_tile_persist = false;                              // this frame set runs k_pw_tile_p instead of k_pw_tile
+    int pw_last_variant = 0;                                   // variant code of the last piecewise warp kernel launched (launch_pw_rows; hg_last_piecewise_variant)
+    int opt_tile = -1;                                         // option "tile": 1 whenever k_pw_patch<SELF> would run, 0 never, -1 by policy
     bool pw_bands = false;                                     // ... with candidate bands (meshes too large for every workgroup to scan)
     int4 *d_bands = nullptr; size_t bands_cap = 0;             // F x n_bands x band_cap entries (hg_kernels.h)
     int band_cap = 0, n_bands = 0;

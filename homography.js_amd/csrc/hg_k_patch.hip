@@ -397,21 +397,23 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     }
 }
 
-void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream)
+int launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream)
 {
-    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
+    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return 0;
+    int code = 0;                                            // (variant code: see launch_pw_rows)
     const int nx = 1 << fr.xcc_log2;
     const int gpx = ((fr.max_obj_h + kPatchRows - 1) / kPatchRows + nx - 1) / nx;
     const dim3 grid((unsigned)gpx * (unsigned)nx * (unsigned)fr.n_frames);
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-#define HG_PATCH(G, HB, PBV, SF) hipLaunchKernelGGL((k_pw_patch<G, HB, PBV, SF>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, status_next)
+#define HG_PATCH(G, HB, PBV, SF) do { code = ((G) ? 800000 : 400000) + (PBV) * 1000 + ((HB) ? 10 : 0) + ((SF) ? 1 : 0); \
+        hipLaunchKernelGGL((k_pw_patch<G, HB, PBV, SF>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, status_next); } while (0)
     if (fr.self_spans && !global_records) {                  // own spans (k_tri_setup in front, no row lists)
         if (!hib) HG_PATCH(false, false, 1, true);
         else if (fr.patch_blocks >= 8) HG_PATCH(false, true, 8, true);
         else if (fr.patch_blocks >= 4) HG_PATCH(false, true, 4, true);
         else if (fr.patch_blocks >= 2) HG_PATCH(false, true, 2, true);
         else HG_PATCH(false, true, 1, true);
-        return;
+        return code;
     }
     if (global_records) { if (hib) HG_PATCH(true, true, 1, false); else HG_PATCH(true, false, 1, false); }
     else if (!hib) HG_PATCH(false, false, 1, false);
@@ -420,6 +422,7 @@ void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl,
     else if (fr.patch_blocks >= 2) HG_PATCH(false, true, 2, false);
     else HG_PATCH(false, true, 1, false);
 #undef HG_PATCH
+    return code;
 }
 
 } // namespace hg

@@ -1005,9 +1005,13 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
     else            hipLaunchKernelGGL((k_tri_spans<false>), grid, block, 0, stream, mesh, fr, rl);
 }
 
-void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
+// Returns the variant code of the instantiation it launched (hg_last_piecewise_variant; tools/census.py): kind * 100000 + (512-slot rows) * 10000 +
+// windows-or-blocks per phase * 1000 + (8-byte entries) * 100 + (bounds on the high dwords) * 10 + self-span form; kind 1 k_pw_rows, 2 k_pw_rows8,
+// 3 k_pw_rows_s80, 4 k_pw_patch, 5 k_pw_tile, 6 k_pw_fused, 8 k_pw_patch with global records; + 50 for a parity-tap (map) instantiation.
+int launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
 {
-    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return;
+    if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return 0;
+    int code = 0;
     const bool rows8 = fr.self_spans == 1 && fr.rows8 && fr.row_group == kRowGroup && !map_out;
     const int rg = rows8 ? 8 : (fr.row_group == kRowGroup ? kRowGroup : 1);
     const int nx = 1 << fr.xcc_log2;                                            // XCCs of this device (partition mode), hg_create
@@ -1018,49 +1022,51 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
     const dim3 block(256);
     const size_t pad = (size_t)fr.lds_pad_kb * 1024;
-#define HG_ROWS(CAP, MAPF, PHV, CMP, HB, SF) hipLaunchKernelGGL((k_pw_rows<CAP, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next)
+#define HG_ROWS(CAP, MAPF, PHV, CMP, HB, SF) do { code = 100000 + ((CAP) > kRowSpanCapFast ? 10000 : 0) + (PHV) * 1000 + ((CMP) ? 100 : 0) + ((HB) ? 10 : 0) + (int)(SF) + ((MAPF) ? 50 : 0); \
+        hipLaunchKernelGGL((k_pw_rows<CAP, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); } while (0)
 #define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true, 0); else HG_ROWS(CAP, false, 1, CMP, false, 0); } while (0)
     if (rows8) {
         if (hib) hipLaunchKernelGGL((k_pw_rows8<4, true>), grid, dim3(512), pad, stream, mesh, fr, rl, out, rpx, status_next);
         else     hipLaunchKernelGGL((k_pw_rows8<1, false>), grid, dim3(512), pad, stream, mesh, fr, rl, out, rpx, status_next);
-        return;
+        return 200000 + (hib ? 4011 : 1001);
     }
     if (fr.self_spans) {                                     // spans evaluated by the row workgroups themselves (sparse meshes: CAP 256, no row lists, k_tri_setup in front)
-        if (map_out) { HG_ROWS(kRowSpanCapFast, true, 1, false, false, 1); return; }
-        if (!hib) { HG_ROWS(kRowSpanCapFast, false, 1, false, false, 1); return; }
-        if (fr.self_spans == 2) { HG_ROWS(kRowSpanCapFast, false, 2, false, true, 2); return; }      // small frame sets: the short-latency prologue
+        if (map_out) { HG_ROWS(kRowSpanCapFast, true, 1, false, false, 1); return code; }
+        if (!hib) { HG_ROWS(kRowSpanCapFast, false, 1, false, false, 1); return code; }
+        if (fr.self_spans == 2) { HG_ROWS(kRowSpanCapFast, false, 2, false, true, 2); return code; }      // small frame sets: the short-latency prologue
         switch (fr.phase) {
         case 4:  HG_ROWS(kRowSpanCapFast, false, 4, false, true, 1); break;
         case 2:
-            if (fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, false, 2, false, true, 1>), grid, block, pad, stream,
-                                                mesh, fr, rl, out, map_out, rpx, rg, status_next);
+            if (fr.sgpr_cap) { code = 302011; hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, false, 2, false, true, 1>), grid, block, pad, stream,
+                                                mesh, fr, rl, out, map_out, rpx, rg, status_next); }
             else HG_ROWS(kRowSpanCapFast, false, 2, false, true, 1);
             break;
         default: HG_ROWS(kRowSpanCapFast, false, 1, false, true, 1); break;
         }
-        return;
+        return code;
     }
     if (rl.cap > kRowSpanCapFast) {                          // very dense meshes: 512 LDS slots per row (32 KB), one row per workgroup
         if (rl.compact) { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, true, false, false); else HG_ROWS_B(kRowSpanCapDense, 1, true); }
         else            { if (map_out) HG_ROWS(kRowSpanCapDense, true, 1, false, false, false); else HG_ROWS_B(kRowSpanCapDense, 1, false); }
-        return;
+        return code;
     }
-    if (map_out) { if (rl.compact) HG_ROWS(kRowSpanCapFast, true, 1, true, false, false); else HG_ROWS(kRowSpanCapFast, true, 1, false, false, false); return; }
+    if (map_out) { if (rl.compact) HG_ROWS(kRowSpanCapFast, true, 1, true, false, false); else HG_ROWS(kRowSpanCapFast, true, 1, false, false, false); return code; }
     if (rl.compact) {                                        // dense rows: 8-byte entries
         if (fr.phase >= 2) HG_ROWS_B(kRowSpanCapFast, 2, true); else HG_ROWS_B(kRowSpanCapFast, 1, true);     // (no 4-window instantiation here)
-        return;
+        return code;
     }
     switch (fr.phase) {
     case 4:  HG_ROWS_B(kRowSpanCapFast, 4, false); break;
     case 2:
-        if (hib && fr.sgpr_cap) hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, false, 2, false, true, false>), grid, block, pad, stream,
-                                                   mesh, fr, rl, out, map_out, rpx, rg, status_next);
+        if (hib && fr.sgpr_cap) { code = 302010; hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, false, 2, false, true, false>), grid, block, pad, stream,
+                                                   mesh, fr, rl, out, map_out, rpx, rg, status_next); }
         else HG_ROWS_B(kRowSpanCapFast, 2, false);
         break;
     default: HG_ROWS_B(kRowSpanCapFast, 1, false); break;
     }
 #undef HG_ROWS_B
 #undef HG_ROWS
+    return code;
 }
 
 } // namespace hg

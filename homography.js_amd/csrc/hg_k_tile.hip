@@ -15,25 +15,8 @@ namespace hg {
 // work: every pixel of the 64 x 8 block is visited exactly once whatever its value, and each pixel is computed exactly as everywhere
 // else.  The taller workgroup is affordable because it is NARROW: spans are kept only where they overlap the tile's columns,
 // candidates only for triangles that reach the tile in rows AND columns.
-// Timing experiments that led here: EXPERIMENTS.md R4.3.
-#ifndef HG_TILE_XSTEP
-#define HG_TILE_XSTEP 1
-#endif
-#ifndef HG_TILE_SOFF
-#define HG_TILE_SOFF 0
-#endif
-#ifndef HG_TILE_WPE6
-#define HG_TILE_WPE6 0
-#endif
-#ifndef HG_TILE_PAD
-#define HG_TILE_PAD 0
-#endif
-#ifndef HG_TP_EXP
-#define HG_TP_EXP 0
-#endif
-#ifndef HG_TILE_NE
-#define HG_TILE_NE 0
-#endif
+// Timing experiments that led here: EXPERIMENTS.md R4.3, R4.7; the persistent, wave-specialised form of this kernel was built in round 6
+// and is slower (R6.3: git show 5f4414b:homography.js_amd/csrc/hg_k_tile.hip).
 #ifndef HG_TILE_PB
 #define HG_TILE_PB 4
 #endif
@@ -45,9 +28,6 @@ constexpr int kTileRows = 8, kTileCols = HG_TILE_COLS, kTileBlocks = kTileCols /
               kTileSpanPitch = kTileCap + 8;         // words between the rows' span blocks: 8 mod 64, so the eight rows a wave looks up at once start 8 banks apart (96: 4-way conflicts)
 
 template <bool HIB>
-#if HG_TILE_WPE6
-__attribute__((amdgpu_waves_per_eu(6, 6)))
-#endif
 __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int groups_per_xcd, int col_tiles,
                                                  int tile_cols, int32_t *__restrict__ status_next)
 {
@@ -259,9 +239,7 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
             }
         }
         const double y = (double)(r0 + row + fd.y_off);
-#if HG_TILE_XSTEP
         const double xd0 = (double)(t0 + cb + c + fd.x_off);
-#endif
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             double h[8], rd[8];
@@ -269,22 +247,10 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
             for (int k = 0; k < 4; k++) {
                 const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_rec) + (best[4 * half + k] & kKeyOffMask));
                 const double2 m02 = mrec[0], m41 = mrec[1], m35 = mrec[2];
-                #if HG_TILE_XSTEP
                 const double xd = xd0 + (double)(8 * (4 * half + k));          // (integers far below 2^53: the fp64 add is exact; one instruction instead of an integer add and a conversion)
-#else
-                const double xd = (double)(t0 + cb + 8 * (4 * half + k) + c + fd.x_off);
-#endif
                 // :1383-1384  (m0*x) + (m2*y) + m4: m2*y rounded on its own, m0*x exact in fp64 (see k_pw_rows)
                 h[2 * k]     = fma(m02.x, xd, m02.y * y) + m41.x;
                 h[2 * k + 1] = fma(m41.y, xd, m35.x * y) + m35.y;
-#if HG_TILE_PAD
-                {   // timing only (EXPERIMENTS.md R6.3): HG_TILE_PAD dependent fp64 fma per pixel that cannot be removed and never change a result
-                    double d = xd;
-#pragma unroll
-                    for (int i = 0; i < HG_TILE_PAD; i++) d = fma(d, y, m02.x);
-                    if (d == 0.123456789) h[2 * k] = d;
-                }
-#endif
             }
             round_x8(h, rd);
 #pragma unroll
@@ -304,24 +270,12 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the row's byte offset travels in the instruction's scalar offset, the lane's column (or, past the row end, an offset no buffer
-        // holds) in the vector offset: two vector instructions per block instead of two per row; rows past the frame's end are skipped by
-        // a scalar test (whether the hardware's range check sees the scalar offset does not matter this way)
         const int xs = t0 + (blk << 6) + lane;
-#if HG_TILE_SOFF
-        const uint32_t vo = xs < W ? (uint32_t)xs * 4u : 0x80000000u;
-#pragma unroll
-        for (int rw = 0; rw < kTileRows; rw++) {
-            const uint32_t v = tile[rw * kTilePitch + lane];
-            if (rw < nrows) __builtin_amdgcn_raw_buffer_store_b32(v, dst, vo, rw * W * 4, kStoreNT);
-        }
-#else
 #pragma unroll
         for (int rw = 0; rw < kTileRows; rw++) {
             const uint32_t v = tile[rw * kTilePitch + lane];
             __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && rw < nrows) ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
         }
-#endif
         __builtin_amdgcn_wave_barrier();
     };
     // The run direction of a block: along the source row of the triangle under its centre (row 4, column 32): dy = -(m1 / m3) dx.  An
@@ -343,69 +297,15 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
         if (!(sl == sl) || best < 0) sl = 0.f;
         return fminf(fmaxf(sl, -1.f), 1.f);
     };
-    // ... evaluated ONCE per tile: lane l of a wave takes that wave's l-th block (wave + 4 l), the block loop reads the slope back with
-    // v_readlane.  (Every lane used to evaluate every block's slope: ~40 vector instructions per 8 pixels for a number that is the same
-    // in all 64 lanes; the kernel runs on its vector port -- EXPERIMENTS.md R6.3.)
+    // ... evaluated ONCE per tile: lane l of a wave takes that wave's l-th block (wave + 4 l) and leaves the slope in LDS.  (Every lane used
+    // to evaluate every block's slope: ~40 vector instructions per 8 pixels for a number that is the same in all 64 lanes, and with a
+    // shared source this kernel runs on its vector port -- EXPERIMENTS.md R6.4.)
     static_assert(kTileBlocks <= 4 * 64, "one lane per block of the wave");
     if (wave + 4 * lane < nblk) s_slope[wave + 4 * lane] = block_slope(wave + 4 * lane);      // (kept in LDS: a register held across the block loop cost a wave per SIMD)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     auto block_skew = [&](int blk) -> int { return (int)rintf(s_slope[blk] * (float)c); };
-#if HG_TILE_NE
-    // Blocks NO span of the tile reaches (a third of C4's: the window around a face mesh) are zeros: they take two 16-byte stores per
-    // lane instead of the whole pixel body.  Every wave derives the same mask of non-empty blocks from the bin counts (lane b: block b,
-    // one ballot; no list in LDS, no barrier) and walks its share -- the wave-th, wave + 4-th, ... set bit -- with scalar instructions only.
-    static_assert(kTileBlocks <= 64, "one mask bit per 64-column block");
-    unsigned long long m_ne;
-    {
-        int any = 0;
-        if (lane < nblk) {
-#pragma unroll
-            for (int r = 0; r < kTileRows; r++) any |= s_bincnt[lane * kTileRows + r];
-        }
-        m_ne = __ballot(any != 0);
-    }
-    {
-        unsigned long long m_e = ~m_ne & (nblk >= 64 ? ~0ull : ((1ull << nblk) - 1ull));
-        const bool vec = (W & 3) == 0 && ((fd.out_off + (uint64_t)r0 * W * 4) & 15) == 0;        // (wave-uniform)
-        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-        const v4u zero4 = { 0u, 0u, 0u, 0u };
-        for (int i = 0; m_e; i++) {
-            const int blk = __builtin_amdgcn_readfirstlane(__ffsll((long long)m_e) - 1);
-            m_e &= m_e - 1;
-            if ((i & 3) != wave) continue;
-            const int xs0 = t0 + (blk << 6);
-            if (vec && xs0 + 64 <= W) {                      // lane l: row l >> 4 (and + 4), columns 4 (l & 15) .. + 3
-                const int rw = lane >> 4, xs = xs0 + ((lane & 15) << 2);
-                __builtin_amdgcn_raw_buffer_store_b128(zero4, dst, rw < nrows ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
-                __builtin_amdgcn_raw_buffer_store_b128(zero4, dst, rw + 4 < nrows ? (uint32_t)((rw + 4) * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
-            } else {
-                const int xs = xs0 + lane;
-#pragma unroll
-                for (int rw = 0; rw < kTileRows; rw++)
-                    __builtin_amdgcn_raw_buffer_store_b32(0u, dst, (xs < W && rw < nrows) ? (uint32_t)(rw * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
-            }
-        }
-    }
-    // this wave's non-empty blocks; kTilePB of them in flight before the first is transposed and stored
-    unsigned long long m = m_ne;
-    for (int i = 0; i < wave && m; i++) m &= m - 1;
-    while (m) {
-        uint32_t px[kTilePB][8];
-        int blks[kTilePB];
-        uint32_t skp = 0;                                    // the blocks' skews, 4 bits each: only (q + sk) mod 8 is ever used
-#pragma unroll
-        for (int b = 0; b < kTilePB; b++) {
-            blks[b] = m ? __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1) : -1;
-            m &= m - 1; m &= m - 1; m &= m - 1; m &= m - 1;          // (x & (x - 1) of 0 is 0)
-        }
-#pragma unroll
-        for (int b = 0; b < kTilePB; b++) if (blks[b] >= 0) { const int sk = block_skew(blks[b]) & 7; skp |= (uint32_t)sk << (4 * b); resolve_gather(blks[b], sk, px[b]); }
-#pragma unroll
-        for (int b = 0; b < kTilePB; b++) if (blks[b] >= 0) transpose_store(blks[b], (int)((skp >> (4 * b)) & 7u), px[b]);
-    }
-#else
     // this wave's blocks: wave, wave + 4, ...; kTilePB of them in flight before the first is transposed and stored
     for (int blk = wave; blk < nblk; blk += 4 * kTilePB) {
         uint32_t px[kTilePB][8];
@@ -415,408 +315,11 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
 #pragma unroll
         for (int b = 0; b < kTilePB; b++) if (blk + 4 * b < nblk) transpose_store(blk + 4 * b, sk[b], px[b]);
     }
-#endif
 }
 
-// ------------------------------------------------------------------------------------------------ k_pw_tile_p (round 6)
-// The same tiles, the same pixels, as a PERSISTENT, WAVE-SPECIALISED kernel: the grid is (workgroups that fit the chip) and a workgroup
-// walks the tiles of its XCD band `slot, slot + slots, ...` (the order the one-shot grid would have given that XCD).  Wave 5 is the
-// PROLOGUE wave: while waves 0-4 resolve / gather / transpose / store tile n out of one LDS bin set, it runs tile n + 1's candidate scan,
-// predictXLimits and span filing (:1111-1197 through span_cells' lean form, exactly as k_pw_tile) into the OTHER set; one s_barrier per
-// tile.  What this buys over k_pw_tile: the prologue's dependent chain (two L2 round trips, three IEEE divisions per candidate row, LDS
-// atomics) leaves the critical path of the pixel waves, a workgroup slot is never 3/4 empty behind its slowest wave's tail, and 12-35
-// thousand workgroup launches become ~1000.  What it costs: two bin sets in LDS (4 workgroups of 6 waves per CU instead of 6 of 4; the
-// transpose goes through a 4-row tile in two halves to pay for that), 112 instead of 128 triangle pieces per tile.
-// Flag -> redo contract and :1042-1056 semantics unchanged.  EXPERIMENTS.md R6.3.
-#ifndef HG_TP_BODY
-#define HG_TP_BODY 5
-#endif
-#ifndef HG_TP_PB
-#define HG_TP_PB 3
-#endif
-#ifndef HG_TP_PER_CU
-#define HG_TP_PER_CU 4
-#endif
-#ifndef HG_TP_WPE
-#define HG_TP_WPE 6
-#endif
-constexpr int kTPBody = HG_TP_BODY, kTPWaves = kTPBody + 1, kTPThreads = 64 * kTPWaves, kTPRecs = 112, kTPPB = HG_TP_PB, kTPPerCU = HG_TP_PER_CU;
-struct TileBuf {
-    double rec[(kTPRecs + 1) * 6];                           // {m0, m2, m4, m1, m3, m5} per candidate entry; last = NaN record
-    uint32_t lohi[kTileRows * kTileSpanPitch];
-    int key[kTileRows * kTileSpanPitch];
-    int bincnt[kTileBlocks * kTileRows];
-    uint8_t bin[kTileBlocks * kTileRows * kTileBinSlots];
-    int rowcnt[kTileRows];
-    int fail;                                                // 0: run the tile; -1: nothing to do (outside the frame); else the flag bits
-    int pad[3];
-};
-
-// All parameters travel as ONE struct and are re-read from the kernarg segment (scalar loads through a pointer the compiler cannot see
-// through) at the head of every tile: held in SGPRs across the persistent loop they cost 46 spilled SGPRs and 18 VGPRs of scratch.
-struct TPArgs { PwMesh mesh; PwFrames fr; RowLists rl; uint8_t *out; int32_t *status_next; int groups_per_xcd, col_tiles, tile_cols, n_bi; };
-typedef const TPArgs __attribute__((address_space(4))) *TPArgsP;
-__device__ __forceinline__ TPArgsP tp_args()
+int launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream)
 {
-    TPArgsP a = (TPArgsP)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(a));
-    return a;
-}
-
-template <class S> __device__ __forceinline__ S tp_load(const S __attribute__((address_space(4))) *p)
-{
-    S v;
-    __builtin_memcpy(&v, (const void __attribute__((address_space(4))) *)p, sizeof(S));
-    return v;
-}
-
-template <bool HIB>
-__global__ __launch_bounds__(kTPThreads) __attribute__((amdgpu_waves_per_eu(HG_TP_WPE, HG_TP_WPE))) void k_pw_tile_p(TPArgs args_by_value)
-{
-    __shared__ __align__(16) TileBuf s_buf[2];
-    __shared__ int s_cand_tn[kTileCands], s_cand_y[kTileCands];
-    __shared__ uint32_t s_tile[kTPBody * 4 * kTilePitch];
-
-    (void)args_by_value;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int xcc_log2, n_bi;
-    {
-        TPArgsP A = tp_args();
-        xcc_log2 = A->fr.xcc_log2; n_bi = A->n_bi;
-        int32_t *status_next = A->status_next;
-        const int nf = A->fr.n_frames;
-        if (blockIdx.x == 0 && status_next) for (int i = threadIdx.x; i < nf; i += kTPThreads) status_next[i] = 0;   // (see k_pw_rows)
-    }
-    const int xmask = (1 << xcc_log2) - 1;
-    const int xcd = blockIdx.x & xmask, slot = blockIdx.x >> xcc_log2, slots = gridDim.x >> xcc_log2;
-
-    auto decode = [&](TPArgsP A, int bi, int &f, int &r0, int &t0, int &tile_cols) {
-        const int groups_per_xcd = A->groups_per_xcd, col_tiles = A->col_tiles;
-        const int per_frame = groups_per_xcd * col_tiles;
-        tile_cols = A->tile_cols;
-        f = bi / per_frame;
-        const int rem = bi - f * per_frame;
-        const int band = (xcd + (A->fr.xcc_rotate ? f : 0)) & xmask;
-        const int g_in = rem / col_tiles, ct = rem - g_in * col_tiles;
-        r0 = (band * groups_per_xcd + g_in) * kTileRows; t0 = ct * tile_cols;
-    };
-
-    // ---------------------------------------------------------------- the prologue of one tile, by ONE wave (no workgroup barrier inside)
-    auto prologue = [&](TileBuf &B, int bi) {
-        TPArgsP A = tp_args();
-        int f, r0, t0, tile_cols;
-        decode(A, bi, f, r0, t0, tile_cols);
-        const PwFrames fr = tp_load(&A->fr);
-        const RowLists rl = tp_load(&A->rl);
-        const int T = A->mesh.n_tris;
-        const FrameDesc fd = fr.frames[f];
-        if (t0 == 0 && lane < kTileRows && r0 + lane < rl.row_stride) rl.cnt_clear[(size_t)f * rl.row_stride + r0 + lane] = 0;   // (ping-pong, see k_pw_rows)
-        if (r0 >= fd.obj_h || fd.obj_w <= 0 || t0 >= fd.obj_w) { if (lane == 0) B.fail = -1; return; }
-        const int W = fd.obj_w;
-        const int nrows = min(kTileRows, fd.obj_h - r0), ncols = min(tile_cols, W - t0);
-        for (int i = lane; i < kTileBlocks * kTileRows; i += 64) B.bincnt[i] = 0;
-        if (lane < kTileRows) B.rowcnt[lane] = 0;
-        if (lane < 3) reinterpret_cast<double2 *>(B.rec + kTPRecs * 6)[lane] = make_double2(NAN, NAN);
-        // (1) candidates (see k_pw_tile): the count lives in a scalar register, no LDS atomic
-        const int g_lo = r0 + fd.y_off, g_hi = r0 + nrows - 1 + fd.y_off;
-        int n_src = T;
-        const int4 *__restrict__ bent = nullptr;
-        if (fr.band_ent) {
-            const int bandi = r0 >> fr.band_rows_log2;
-            n_src = min(fr.band_cnt[(size_t)f * fr.band_stride + bandi], fr.band_cap);
-            bent = fr.band_ent + ((size_t)f * fr.n_bands + bandi) * fr.band_cap * 2;
-        }
-        const TriRange *__restrict__ trir = fr.trir + (size_t)f * T;
-        const int2 *__restrict__ trix = fr.trix + (size_t)f * T;
-        int nc = 0;
-        for (int i0 = 0; i0 < n_src; i0 += 64) {
-            const int i = i0 + lane;
-            int t = i, xlo = 0, xhi = -1;
-            TriRange tr = TriRange{0, 0, 0, 0};
-            if (i < n_src) {
-                if (bent) {
-                    const int4 e = bent[2 * i], x = bent[2 * i + 1];
-                    t = e.x; tr.y_min = e.y; tr.y_end = e.z; tr.a = (int16_t)(e.w & 0xffff); tr.b = e.w >> 16; xlo = x.x; xhi = x.y;
-                } else { tr = trir[i]; const int2 x = trix[i]; xlo = x.x; xhi = x.y; }
-            }
-            bool cols = false;
-            if (xhi >= xlo) {
-                if (xhi - xlo + 1 >= W) cols = true;
-                else {
-                    int cl = xlo % W; if (cl < 0) cl += W;
-                    const int ch = cl + (xhi - xlo);
-                    cols = (cl < t0 + ncols && ch >= t0) || (cl - W < t0 + ncols && ch - W >= t0);
-                }
-            }
-            int ylo0 = max(g_lo - tr.a, tr.y_min), n0 = min(g_hi - tr.b, tr.y_end - 1) - ylo0 + 1;
-            int ylo1 = max(g_lo - tr.a - fd.obj_h, tr.y_min), n1 = min(g_hi - tr.b - fd.obj_h, tr.y_end - 1) - ylo1 + 1;
-            if (!cols) { n0 = 0; n1 = 0; }
-            const unsigned long long m0 = __ballot(n0 > 0), m1 = __ballot(n1 > 0);
-            if ((m0 | m1) == 0ull) continue;
-            const unsigned long long m0b = __ballot(n0 > kTileRows), m1b = __ballot(n1 > kTileRows);
-            const int c0 = __popcll(m0), c0b = __popcll(m0b), c1 = __popcll(m1), c1b = __popcll(m1b);
-            const int base = nc;
-            nc += c0 + c0b + c1 + c1b;
-            auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-            auto file = [&](int at, int y0, int n) { if (at < kTileCands) { s_cand_tn[at] = t | (min(n, 0xffff) << 16); s_cand_y[at] = y0; } };
-            if (n0 > 0) file(base + below(m0), ylo0, min(n0, kTileRows));
-            if (n0 > kTileRows) file(base + c0 + below(m0b), ylo0 + kTileRows, n0 - kTileRows);
-            if (m1) {
-                if (n1 > 0) file(base + c0 + c0b + below(m1), ylo1, min(n1, kTileRows));
-                if (n1 > kTileRows) file(base + c0 + c0b + c1 + below(m1b), ylo1 + kTileRows, n1 - kTileRows);
-            }
-        }
-        int fail = nc > kTPRecs ? (1 | (nc << 8)) : 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // (2) spans: 8 lanes per candidate entry, one source row each
-        const float *__restrict__ ginv = fr.inv + (size_t)f * T * kInvStride;
-        const double flen = (double)((int64_t)W * fd.obj_h), fW = (double)W;
-        const Seg *__restrict__ gseg = fr.segs + (size_t)f * T * 3;
-        if (fail == 0) for (int c0 = 0; c0 < nc; c0 += 8) {
-            const int c = c0 + (lane >> 3), jj = lane & 7;
-            if (c >= nc) continue;
-            const int tn = s_cand_tn[c], t = tn & 0xffff, n = (int)((uint32_t)tn >> 16), ylo = s_cand_y[c];
-            if (n >= 0xffff) { fail = 1; continue; }
-            if (jj == 0) {
-                const float4 ma = *reinterpret_cast<const float4 *>(ginv + (size_t)t * kInvStride);
-                const float2 mb = *reinterpret_cast<const float2 *>(ginv + (size_t)t * kInvStride + 4);
-                double2 *mrec = reinterpret_cast<double2 *>(B.rec + c * 6);
-                mrec[0] = make_double2((double)ma.x, (double)ma.z);    // m0, m2
-                mrec[1] = make_double2((double)mb.x, (double)ma.y);    // m4, m1
-                mrec[2] = make_double2((double)ma.w, (double)mb.y);    // m3, m5
-            }
-            const Seg *__restrict__ sg = gseg + (size_t)t * 3;
-            for (int j = jj; j < n; j += 8) {
-                const int ys = ylo + j;
-                const double y = (double)ys;
-                double mn = INFINITY, mx = -INFINITY;
-                const Seg q0 = sg[0], q1 = sg[1], q2 = sg[2];
-                auto edge = [&](const Seg &q) {
-                    const double x = q.m == INFINITY ? q.b : (y - q.b) / q.m;
-                    const bool use = (y >= q.minY) & (y <= q.maxY) & !(q.m == 0.0);
-                    mn = (use & (x < mn)) ? x : mn;
-                    mx = (use & (x > mx)) ? x : mx;
-                };
-                edge(q0); edge(q1); edge(q2);
-                const double base = (y - (double)fd.y_off) * fW;
-                double rk = floor(mn); rk += (mn - rk >= 0.5) ? 1.0 : 0.0;
-                double rf = floor(mx); rf += (mx - rf >= 0.5) ? 1.0 : 0.0;
-                double vk = trunc(base + rk), vf = trunc(base + rf);
-                vk = vk < 0.0 ? flen + vk : vk; vf = vf < 0.0 ? flen + vf : vf;
-                const int k = (int)fmin(fmax(vk, 0.0), flen), fin = (int)fmin(fmax(vf, 0.0), flen);
-                if (k >= fin) continue;
-                int r = ys - fd.y_off;
-                if (r < 0) r += fd.obj_h;
-                if ((unsigned)r >= (unsigned)fd.obj_h || (unsigned)(k - r * W) >= (unsigned)W) r = k / W;
-                if (r < r0) r = r0;
-                for (; r < r0 + nrows; r++) {
-                    const int rb = r * W;
-                    if (rb >= fin) break;
-                    const int lo = max(max(k - rb, 0), t0) - t0, hi = min(min(fin - rb, W), t0 + ncols) - t0;
-                    if (lo >= hi) continue;
-                    const int row = r - r0;
-                    const int sl = atomicAdd(&B.rowcnt[row], 1);
-                    if (sl >= kTileCap) continue;             // (counted: the check below fails the tile)
-                    B.lohi[row * kTileSpanPitch + sl] = (uint32_t)lo | ((uint32_t)hi << 16);
-                    B.key[row * kTileSpanPitch + sl] = (t << kKeyShift) | (c * 48);
-                    for (int b = lo >> 6; b <= (hi - 1) >> 6; b++) {
-                        const int pos = atomicAdd(&B.bincnt[b * kTileRows + row], 1);
-                        if (pos < kTileBinSlots) B.bin[(b * kTileRows + row) * kTileBinSlots + pos] = (uint8_t)sl;
-                    }
-                }
-            }
-        }
-        fail = __any(fail == 1) ? 1 : fail;                 // (a lane that met an absurd candidate entry)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // (3) limits
-#pragma unroll
-        for (int r = 0; r < kTileRows; r++) { const int cnt = B.rowcnt[r]; if (cnt > kTileCap && fail == 0) fail = 2 | (cnt << 8); }
-        if (lane == 0) {
-            if (fail) flag_frame(fr, f, FRAME_LDS_OVERFLOW | (fail << 4));      // the host redoes the frame through the materialised map
-            B.fail = fail;
-        }
-    };
-
-    // ---------------------------------------------------------------- the pixels of one tile, by the five pixel waves
-    auto body = [&](const TileBuf &B, int bi) {
-        if (B.fail != 0) return;
-        TPArgsP A = tp_args();
-        int f, r0, t0, tile_cols;
-        decode(A, bi, f, r0, t0, tile_cols);
-        const PwMesh mesh = tp_load(&A->mesh);
-        const PwFrames fr = tp_load(&A->fr);
-        uint8_t *__restrict__ out = A->out;
-        const FrameDesc fd = fr.frames[f];
-        const int W = fd.obj_w;
-        const int nrows = min(kTileRows, fd.obj_h - r0), ncols = min(tile_cols, W - t0), nblk = (ncols + 63) >> 6;
-        const int c = lane & 7, q = lane >> 3;
-        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 0, mesh.W * mesh.H * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r0 * W * 4, 0, nrows * W * 4, 0x00020000);
-        const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
-        const double by_lo = (double)mesh.min_src_y + 0.5, by_hi = (double)mesh.H + (double)mesh.min_src_y + 0.5;
-        const HiBounds hb = make_hi_bounds(bx_lo, bx_hi, by_lo, by_hi);
-        const int pitch4 = mesh.W * 4;
-        const int nan_key = (int)0x80000000u | (kTPRecs * 48);
-        uint32_t *tile = s_tile + wave * (4 * kTilePitch);
-
-        auto resolve_gather = [&](int blk, int sk, uint32_t px[8]) {
-            const int cb = blk << 6;
-            const int row = (q + sk) & (kTileRows - 1);
-            int best[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) best[k] = nan_key;
-            {
-                const int bidx = blk * kTileRows + row;
-                const int nb = B.bincnt[bidx];
-                const uint8_t *bin = B.bin + bidx * kTileBinSlots;
-                const int row_base = row * kTileSpanPitch;
-                if (!__any(nb > kTileBinSlots)) {
-                    for (int p = 0; __any(p < nb); p++) {
-                        int lo = 0, len = 0, key = 0;
-                        if (p < nb) {
-                            const int e = row_base + bin[p];
-                            const uint32_t lh = B.lohi[e];
-                            lo = (int)(lh & 0xffffu); len = (int)(lh >> 16) - lo; key = B.key[e];
-                        }
-                        const int d = cb + c - lo;
-                        span_max4d(best, d, d + 8, d + 16, d + 24, len, key);
-                        span_max4d(best + 4, d + 32, d + 40, d + 48, d + 56, len, key);
-                    }
-                } else {
-                    const int my_cnt = B.rowcnt[row];
-                    for (int i = 0; __any(i < my_cnt); i++) {
-                        int lo = 0, len = 0, key = 0;
-                        if (i < my_cnt) {
-                            const uint32_t lh = B.lohi[row_base + i];
-                            lo = (int)(lh & 0xffffu); len = (int)(lh >> 16) - lo; key = B.key[row_base + i];
-                        }
-                        const int d = cb + c - lo;
-                        span_max4d(best, d, d + 8, d + 16, d + 24, len, key);
-                        span_max4d(best + 4, d + 32, d + 40, d + 48, d + 56, len, key);
-                    }
-                }
-            }
-            const double y = (double)(r0 + row + fd.y_off);
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                double h[8], rd[8];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(B.rec) + (best[4 * half + k] & kKeyOffMask));
-                    const double2 m02 = mrec[0], m41 = mrec[1], m35 = mrec[2];
-                    const double xd = (double)(t0 + cb + 8 * (4 * half + k) + c + fd.x_off);
-                    h[2 * k]     = fma(m02.x, xd, m02.y * y) + m41.x;          // :1383-1384 (see k_pw_tile)
-                    h[2 * k + 1] = fma(m41.y, xd, m35.x * y) + m35.y;
-                }
-                round_x8(h, rd);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const bool inb = HIB ? hi_inb(hb, h[2 * k], h[2 * k + 1])
-                                         : (bool)((int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi));   // :1047 (NaN fails)
-                    const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
-                    px[4 * half + k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
-                }
-            }
-        };
-        // 64 x 8 transpose in two halves through this wave's 4-row LDS tile (wave-synchronous), 4 stores of 256 contiguous bytes per half
-        auto transpose_store = [&](int blk, int sk, const uint32_t px[8]) {
-            const int row = (q + sk) & (kTileRows - 1);
-            const int xs = t0 + (blk << 6) + lane;
-#pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                if ((row >> 2) == hf) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) tile[(row & 3) * kTilePitch + 8 * k + c] = px[k];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int rw = 0; rw < 4; rw++) {
-                    const uint32_t v = tile[rw * kTilePitch + lane];
-                    const int ro = 4 * hf + rw;
-                    __builtin_amdgcn_raw_buffer_store_b32(v, dst, (xs < W && ro < nrows) ? (uint32_t)(ro * W + xs) * 4u : 0xffffffffu, 0, kStoreNT);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        };
-        auto block_skew = [&](int blk) -> int {
-            int best = nan_key;
-            const int cb = blk << 6;
-            const int bidx = blk * kTileRows + (kTileRows / 2);
-            const int nb = min(B.bincnt[bidx], kTileBinSlots);
-            for (int p = 0; p < nb; p++) {
-                const int e = (kTileRows / 2) * kTileSpanPitch + B.bin[bidx * kTileBinSlots + p];
-                const uint32_t lh = B.lohi[e];
-                const int lo = (int)(lh & 0xffffu), len = (int)(lh >> 16) - lo;
-                if ((unsigned)(cb + 32 - lo) < (unsigned)len) best = max(best, B.key[e]);
-            }
-            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(B.rec) + (best & kKeyOffMask));
-            const float m1 = (float)mrec[1].y, m3 = (float)mrec[2].x;
-            float sl = -m1 / m3;
-            if (!(sl == sl) || best < 0) sl = 0.f;
-            sl = fminf(fmaxf(sl, -1.f), 1.f);
-            return (int)rintf(sl * (float)c);
-        };
-        for (int blk = wave; blk < nblk; blk += kTPBody * kTPPB) {
-            uint32_t px[kTPPB][8];
-            int sk[kTPPB];
-#pragma unroll
-            for (int b = 0; b < kTPPB; b++) if (blk + kTPBody * b < nblk) { sk[b] = block_skew(blk + kTPBody * b); resolve_gather(blk + kTPBody * b, sk[b], px[b]); }
-#pragma unroll
-            for (int b = 0; b < kTPPB; b++) if (blk + kTPBody * b < nblk) transpose_store(blk + kTPBody * b, sk[b], px[b]);
-        }
-    };
-
-    // Two loops, one per role, meeting at one s_barrier per tile: after barrier n the pixel waves own bin set n & 1 (tile n), the prologue
-    // wave the other one (tile n + 1).  (Written as two loops so that each role's registers are allocated on their own.)
-    if (wave == kTPBody) {
-        for (int n = -1; ; n++) {
-            const int bi = slot + n * slots, nbi = bi + slots;
-            if (n >= 0 && bi >= n_bi) break;
-#if HG_TP_EXP == 2
-            if (nbi < n_bi && n < 1) prologue(s_buf[(n + 1) & 1], nbi);      // (timing only: later tiles reuse the first two tiles' bins)
-#else
-            if (nbi < n_bi) prologue(s_buf[(n + 1) & 1], nbi);
-#endif
-            __syncthreads();
-        }
-    } else {
-        for (int n = -1; ; n++) {
-            const int bi = slot + n * slots;
-            if (n >= 0 && bi >= n_bi) break;
-#if HG_TP_EXP != 1
-            if (n >= 0) body(s_buf[n & 1], bi);                              // (HG_TP_EXP == 1, timing only: the prologue wave alone)
-#endif
-            __syncthreads();
-        }
-    }
-}
-
-void launch_pw_tile_p(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, int n_cus, hipStream_t stream)
-{
-    if (fr.n_frames <= 0 || fr.max_obj_h <= 0 || max_obj_w <= 0) return;
-    const int nx = 1 << fr.xcc_log2;
-    const int gpx = ((fr.max_obj_h + kTileRows - 1) / kTileRows + nx - 1) / nx;
-    const int cts = (max_obj_w + kTileCols - 1) / kTileCols;
-    const int tile_cols = (((max_obj_w + cts - 1) / cts) + 63) & ~63;
-    const int64_t n_bi = (int64_t)gpx * cts * fr.n_frames;                       // tiles per XCD band
-    const int slots = (int)std::min<int64_t>(n_bi, std::max(1, (std::max(n_cus, nx) / nx) * kTPPerCU));
-    const dim3 grid((unsigned)slots * (unsigned)nx);
-    const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-    const TPArgs args{ mesh, fr, rl, out, status_next, gpx, cts, tile_cols, (int)n_bi };
-    if (hib) hipLaunchKernelGGL((k_pw_tile_p<true>), grid, dim3(kTPThreads), 0, stream, args);
-    else     hipLaunchKernelGGL((k_pw_tile_p<false>), grid, dim3(kTPThreads), 0, stream, args);
-}
-
-void launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream)
-{
-    if (fr.n_frames <= 0 || fr.max_obj_h <= 0 || max_obj_w <= 0) return;
+    if (fr.n_frames <= 0 || fr.max_obj_h <= 0 || max_obj_w <= 0) return 0;
     const int nx = 1 << fr.xcc_log2;
     const int gpx = ((fr.max_obj_h + kTileRows - 1) / kTileRows + nx - 1) / nx;
     const int cts = (max_obj_w + kTileCols - 1) / kTileCols;
@@ -825,6 +328,7 @@ void launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
     if (hib) hipLaunchKernelGGL((k_pw_tile<true>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, cts, tile_cols, status_next);
     else     hipLaunchKernelGGL((k_pw_tile<false>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, cts, tile_cols, status_next);
+    return 500000 + kTilePB * 1000 + (hib ? 11 : 1);         // (variant code: see launch_pw_rows)
 }
 
 } // namespace hg

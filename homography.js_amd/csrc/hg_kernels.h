@@ -122,7 +122,7 @@ void launch_pw_fused(const PwMesh &mesh, const PwFrames &fr, uint8_t *out, int16
 // Fast path (see hg_k_piecewise.hip): eligibility, span-list build (includes the per-triangle solves), row warp.
 bool pw_fast_ok(const PwMesh &mesh, int max_obj_w);
 void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, hipStream_t stream);
-void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream);
+int launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream);
 // Dense meshes (64..199 spans per row, obj_w <= 8192): 4 rows per workgroup, 16 x 4 pixel gather patches, one matrix record
 // per triangle of the group.  Same row lists, same status protocol as launch_pw_rows; no map tap.
 // (limits on the HOST ESTIMATES, which run ~10 % above the real counts the kernel enforces: 199 spans per row, 208 triangles
@@ -130,10 +130,9 @@ void launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
 constexpr int kPatchMaxW = 8192, kPatchMaxRowSpans = 215, kPatchMaxGroupTris = 225;
 // global_records: the variant for up to 511 spans per row whose pixels read their matrix from the tap array instead of LDS
 constexpr int kPatchMaxRowSpansDense = 480;
-void launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream);
+int launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream);
 // Sheared meshes (self-span path only): tiles of 8 rows x <= 2048 columns whose gathers follow the source rows (hg_k_tile.hip).
-void launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream);
-void launch_pw_tile_p(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, int n_cus, hipStream_t stream);   // persistent, wave-specialised form
+int launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then
 // the pixel loop :1042-1056 reading the map.

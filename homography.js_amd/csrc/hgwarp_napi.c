@@ -726,8 +726,10 @@ static napi_value fn_warp_forward_piecewise_state(napi_env env, napi_callback_in
     const size_t px = (g.obj_w > 0 && g.obj_h > 0) ? (size_t)g.obj_w * g.obj_h : 0;
     void *out; napi_value r = make_pixels(env, px * 4, NULL, 0, &out); if (!r) return NULL;
     hg_tri_map_def def = { p, (int)(np / 2), t, (int)(nt / 3), mw, mh, myo };
-    if (px) { int rc = hg_warp_forward_piecewise_state(h->ctx, m, (int)(nm / 6), &def, msx, msy, mxx, mxy, g, (uint8_t *)out);
-              if (rc != HG_OK) return throw_state(env, h->ctx, "hg_warp_forward_piecewise_state", rc); }
+    uint8_t none[4];                                          /* a blank window still gets the held map's ids checked (the reference's loop runs and may throw) */
+    if (!px) { g.x_off = g.y_off = g.obj_w = g.obj_h = 0; }
+    int rc = hg_warp_forward_piecewise_state(h->ctx, m, (int)(nm / 6), &def, msx, msy, mxx, mxy, g, px ? (uint8_t *)out : none);
+    if (rc != HG_OK) return throw_state(env, h->ctx, "hg_warp_forward_piecewise_state", rc);
     return r;
 }
 
@@ -809,8 +811,12 @@ static napi_value slab_frames(napi_env env, handle_t *h, int slot, const hg_geom
 {
     slab_t *sl = &h->slab[slot];
     *fallback = 0;
+    pool_t *P = pool_of(env); if (!P) return NULL;
+    if (sl->ab && (P->pin_limit == 0 || P->pin_bytes > P->pin_limit)) {      /* the cap was lowered since this slab was made: it goes (its views keep their memory until collected) */
+        slab_drop(env, sl, 0);
+        if (P->pin_limit == 0) { P->stat_fallback++; *fallback = 1; return NULL; }
+    }
     if (total > sl->cap || !sl->ab) {
-        pool_t *P = pool_of(env); if (!P) return NULL;
         slab_drop(env, sl, 0);
         const size_t want = total + total / 8 + 4096;
         for (int i = 0; i < P->npins && P->pin_bytes + want > P->pin_limit; i++) if (P->pins[i].ptr && !P->pins[i].in_use) pin_drop(P, i);   /* idle pooled frames make room */

@@ -38,7 +38,7 @@ EXPORTS = [
     "hg_warp_forward_piecewise_device", "hg_warp_forward_piecewise_batch_device",
     "hg_solve_affine_triangles", "hg_warp_inverse_piecewise_state", "hg_warp_forward_piecewise_state",
     "hg_upload_on_copy_stream", "hg_fence_copies", "hg_download_behind_warps", "hg_fence_downloads",
-    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_piecewise_self", "hg_last_piecewise_flag", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_layout_walks", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range", "hg_affine_one_fma_form",
+    "hg_set_timing", "hg_last_kernel_ms", "hg_kernel_ms_stats", "hg_last_piecewise_kernel", "hg_last_piecewise_variant", "hg_last_piecewise_self", "hg_last_piecewise_flag", "hg_last_forward_kernel", "hg_forward_tiles_admissible", "hg_redone_frames", "hg_layout_walks", "hg_set_option", "hg_xcc_count", "hg_selftest_division", "hg_projective_plain_range", "hg_affine_one_fma_form",
 ]
 
 
@@ -108,7 +108,7 @@ def lib():
         "hg_warp_inverse_piecewise_batch_device": (i, [vp, f32p, C.POINTER(Geom), C.POINTER(sz), i, vp]),
         "hg_get_tri_map": (i, [vp, C.POINTER(C.c_int16), sz]), "hg_get_tri_map_fused": (i, [vp, C.POINTER(C.c_int16), sz]),
         "hg_get_matrices": (i, [vp, f32p, f32p]), "hg_warp_inverse_piecewise_via_map": (i, [vp, u8p]),
-        "hg_last_piecewise_kernel": (i, [vp]), "hg_last_piecewise_self": (i, [vp]), "hg_last_piecewise_flag": (i, [vp]), "hg_last_forward_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]), "hg_layout_walks": (C.c_long, [vp]), "hg_xcc_count": (i, [vp]),
+        "hg_last_piecewise_kernel": (i, [vp]), "hg_last_piecewise_variant": (i, [vp]), "hg_last_piecewise_self": (i, [vp]), "hg_last_piecewise_flag": (i, [vp]), "hg_last_forward_kernel": (i, [vp]), "hg_set_option": (i, [vp, C.c_char_p, i]), "hg_redone_frames": (C.c_long, [vp]), "hg_layout_walks": (C.c_long, [vp]), "hg_xcc_count": (i, [vp]),
         "hg_selftest_division": (i, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
         "hg_projective_plain_range": (i, [f64p, Geom]), "hg_affine_one_fma_form": (i, [f32p, Geom]), "hg_forward_tiles_admissible": (i, [i, f64p, i, i, Geom]),
         "hg_set_timing": (i, [vp, i]), "hg_last_kernel_ms": (i, [vp, f32p]),
@@ -337,6 +337,11 @@ class Context:
     def last_piecewise_kernel(self):
         """0 none, 1 k_pw_rows (4-row groups), 2 k_pw_rows (1 row), 3 k_pw_patch, 4 k_pw_fused, 5 k_pw_tile."""
         return lib().hg_last_piecewise_kernel(self._h)
+
+    def last_piecewise_variant(self):
+        """Variant code of the instantiation that ran (include/hgwarp.h); 0 with an older library."""
+        L = lib()
+        return L.hg_last_piecewise_variant(self._h) if hasattr(L, "hg_last_piecewise_variant") else 0
 
     def last_piecewise_self(self):
         """1 if the row workgroups of the last fused run evaluated their own spans (no row lists), 0 if they read k_tri_spans' lists."""

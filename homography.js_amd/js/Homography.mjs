@@ -304,7 +304,7 @@ class Homography {
                 if (!this._mapIsCurrentForward()) this._snapshotForwardMap();
             } else if (!(this._mapIsCurrentForward() && this._matricesAreCurrent())) {
                 if (this._map === null) throw new TypeError("Cannot read property '0' of null");
-                if (!blank[f]) stale.push({ f, map: this._map, mats: this._snapshotMatrices() });
+                stale.push({ f, map: this._map, mats: this._snapshotMatrices(), blank: blank[f] });     // (a blank one too: its loop still reads the held map, :957-961)
                 blank[f] = blank[f] || null;                                                            // (null: neither blank nor batched)
             }
             if (blank[f] === true) continue;
@@ -357,7 +357,8 @@ class Homography {
             const datas = this._batchSources(images, (...src) => this._native.warpForwardPiecewiseBatch(this._ctx, pts, this._maxSrcX, this._maxSrcY, g, own, ...src));
             fwd.forEach((f, k) => { frames[f] = makeImageData(datas[k], g[4 * k + 2], g[4 * k + 3]); });
         }
-        for (const { f, map, mats } of stale) {                                                         // forward frames over a stale map: one by one, as they stand
+        for (const { f, map, mats, blank: isBlank } of stale) {                                         // forward frames over a stale map: one by one, as they stand
+            if (isBlank) { if (options.images) this._uploadSources([options.images[f % options.images.length]]); else this._uploadImage(); this._forwardOverHeldMap(mats, map, 0, 0, 0, 0); continue; }
             const [xo, yo, ow, oh] = geoms.subarray(4 * f, 4 * f + 4);
             makeRoomFor(this._native, ow * oh * 4, 1);
             if (options.images) this._uploadSources([options.images[f % options.images.length]]); else this._uploadImage();
@@ -701,7 +702,12 @@ class Homography {
         if (!usual && map === null) throw new TypeError("Cannot read property '0' of null");              // :957 on a null map
         if (this.repairStaleMap && !this._mapIsCurrentForward()) this._snapshotForwardMap();
         this._uploadImage();
-        if (!(ow * oh >= 1)) return new Uint8ClampedArray(0);
+        if (!(ow * oh >= 1)) {
+            // a blank window (:440) does not stop the reference's loop: it walks the source bbox over the held map and throws where a
+            // cell names a matrix that does not exist -- the stale state still gets that check
+            if (!usual) this._forwardOverHeldMap(mats, map, 0, 0, 0, 0);
+            return new Uint8ClampedArray(0);
+        }
         checkedLength(ow * oh * 4);
         makeRoomFor(this._native, ow * oh * 4, 1);
         if (!usual) {

@@ -314,8 +314,12 @@ int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, 
 
 /* Which kernel produced the last fused piecewise warp of this ctx (tests / profiling): 0 = none yet, 1 = k_pw_rows with
  * 4-row groups, 2 = k_pw_rows one row per workgroup, 3 = k_pw_patch (dense sheared meshes), 4 = k_pw_fused (general),
- * 5 = k_pw_tile (8-row tiles whose gathers follow the source rows: one source per frame). */
+ * 5 = k_pw_tile (8-row tiles whose gathers follow the source rows: one source per frame, steeply sheared or very dense meshes). */
 int hg_last_piecewise_kernel(hg_ctx *ctx);
+/* ... and which template instantiation of it (tools/census.py: the census of what the layout policy really picks): kind * 100000 +
+ * (512-slot rows) * 10000 + windows / blocks per phase * 1000 + (8-byte row entries) * 100 + (bounds on the high dwords) * 10 + self-span
+ * form; kind 1 k_pw_rows, 2 k_pw_rows8, 3 k_pw_rows_s80, 4 k_pw_patch, 5 k_pw_tile, 6 k_pw_fused, 8 k_pw_patch with records in global memory. */
+int hg_last_piecewise_variant(hg_ctx *ctx);
 /* 1 if that run's row workgroups evaluated their own spans (k_tri_setup + k_pw_rows<SELF>: no row lists, no slot atomics, option
  * "self_spans"), 0 if they read the per-output-row span lists of k_tri_spans. */
 int hg_last_piecewise_self(hg_ctx *ctx);

@@ -78,8 +78,25 @@ const errRepr = (e) => (typeof e === 'string' ? 'S:' + e : (e && e.constructor ?
     Mine.triangulate = (p) => triangulate(p);
     const failures = [];
     let ops = 0, warps = 0, stateCalls = 0, throwsSeen = 0;
-    for (let s = 0; s < nSeq; s++) {
-        const { images: specs, script } = makeScript(rng(seed0 * 7919 + s), { triangles: (src) => Array.from(triangulate(Float32Array.from(src.flat()))) });
+    // Fixed sequences in front of the random ones: corners the generator reaches too rarely.
+    //  (1) a forward frame with a BLANK window (destiny x all Infinity: a NaN width passes every test of :421, so warp() takes the forward loop) over a stale
+    //      inverse map that names more triangles than there are matrices: the reference's loop still walks the source bbox and throws.
+    //  (2) the same with every id in range: a 1 x 1 blank frame, no exception.
+    const FIXED = [];
+    {
+        const W = 48, Hh = 40, src = [], tri = [];
+        for (let j = 0; j <= 2; j++) for (let i = 0; i <= 3; i++) src.push([i * 16, j * 20]);
+        for (let j = 0; j < 2; j++) for (let i = 0; i < 3; i++) { const a = j * 4 + i; tri.push(a, a + 1, a + 4, a + 1, a + 5, a + 4); }
+        const scaled = (k) => src.map(([x, y]) => [x * k, y * k]);
+        const nan = src.map(([x, y]) => [Infinity, y]);              // max x = min x = Infinity: the window width is NaN, which passes every test of :421 and fails :440
+        const head = [['new', 'piecewiseaffine'], ['setSourcePoints', src, 'a', W, Hh, false], ['setTriangles', tri], ['setDestinyPoints', scaled(1.25), false], ['warp']];
+        FIXED.push({ images: { a: { w: W, h: Hh, seed: 77 } }, script: [...head, ['setTriangles', tri.slice(0, 3 * 8)], ['setDestinyPoints', nan, false], ['warp'], ['warp']] });
+        FIXED.push({ images: { a: { w: W, h: Hh, seed: 78 } }, script: [...head, ['setDestinyPoints', nan, false], ['warp'], ['setDestinyPoints', scaled(0.95), false], ['warp']] });
+        FIXED.push({ images: { a: { w: W, h: Hh, seed: 79 } }, script: [...head, ['setTriangles', tri.slice(0, 3 * 8)], ['warpBatch', [scaled(0.95), nan, scaled(0.9)], false]] });
+    }
+    for (let s = -FIXED.length; s < nSeq; s++) {
+        const { images: specs, script } = s < 0 ? FIXED[s + FIXED.length]
+                                                : makeScript(rng(seed0 * 7919 + s), { triangles: (src) => Array.from(triangulate(Float32Array.from(src.flat()))) });
         const mk = () => { const o = {}; for (const [k, v] of Object.entries(specs)) o[k] = lcgImage(v.w, v.h, v.seed); return o; };
         const A = makeRunner(ref.Homography, 'ref'), B = makeRunner(Mine, 'mine'), ia = mk(), ib = mk();
         for (let i = 0; i < script.length; i++) {

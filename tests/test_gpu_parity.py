@@ -27,7 +27,6 @@ LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds":
            "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0, "self_spans": 1, "safe_spans": 0},
            "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16, "self_spans": 0, "xcc_rotate": 1, "tri_group": 0},
            "tile": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 1, "xcc_rotate": 1},
-           "tile_p": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 2, "xcc_rotate": 0},
            "rows8": {"min_row_groups": 0, "patch": 0, "self_spans": 1, "rows8": 1, "safe_spans": 1}}
 
 
@@ -1314,7 +1313,7 @@ def test_general_path_between_two_banded_fast_path_sets():
         sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
         ms = WL.src_min(sp)
         c.set_image(img)
-        c.set_option("min_row_groups", 0); c.set_option("patch", 1); c.set_option("self_spans", 1)
+        c.set_option("min_row_groups", 0); c.set_option("patch", 1); c.set_option("self_spans", 1); c.set_option("tile", 0)    # (tile 0: this test is about k_pw_patch's bands)
 
         def step(F, scale, msx, msy, expect_self):
             frames = [(WL.sin_dst(sp, 5.0 + f, 8 + (f % 3)).reshape(-1, 2) * np.float32(scale)).astype(np.float32).ravel() for f in range(F)]
@@ -1631,16 +1630,17 @@ def test_queued_runs_settle_in_call_order():
 
 
 def test_dense_sheared_mesh_takes_the_patch_kernel():
-    """A mesh with ~150 spans per row and shear ~1 (C5's regime at a size the oracle does in a blink): the host picks
-    k_pw_patch (4-row groups, 2-D gather patches, one matrix record per triangle of the group), for a flat dense mesh too; a dense
+    """A mesh with ~150 spans per row and shear ~1 (C5's regime at a size the oracle does in a blink): the host picks the 2-D gather
+    kernels -- since round 6 k_pw_tile (8-row tiles, source-row-following runs) where the mesh is steeply sheared or packs more than two
+    spans into a 64-pixel block, k_pw_patch (4-row groups, one matrix record per triangle of the group) for a flat dense mesh; a dense
     mesh too narrow for its bins and a sparse mesh stay on k_pw_rows.  All bit-exact against the oracle, three frames with different windows per batch."""
     c = HG.Context(0)
     c.set_option("min_row_groups", 0)            # (these frame sets are small: without this they would all run one row per workgroup)
     try:
-        # (dense sheared -> k_pw_patch; dense flat -> k_pw_patch as well since round 4 (its self-span form needs no producer kernel);
+        # (dense sheared -> k_pw_tile (5; round 6, EXPERIMENTS.md R6.4: before that k_pw_patch); dense flat -> k_pw_patch since round 4 (its self-span form needs no producer kernel);
         #  dense rows too narrow for its bins -> k_pw_rows one row per workgroup; sparse -> 4-row groups; very dense, ~300 spans per
         #  row -> k_pw_patch in its global-record variant)
-        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 3), (3200, 150, 17, 3, 0.5, 3), (640, 150, 60, 3, 0.5, 2),
+        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 5), (3200, 150, 17, 3, 0.5, 3), (640, 150, 60, 3, 0.5, 2),
                                                (640, 150, 8, 3, 18.0, 1), (3000, 100, 110, 2, 5.0, 3)]:
             img = G.lcg_image(W, H, 31)
             sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
