@@ -303,7 +303,7 @@ PwFrames frames_of(const hg_ctx *c)
     f.max_obj_h = mh;
     f.row_group = c->pw_row_group;
     f.tri_threads = c->pw_tri_threads;
-    f.self_spans = c->pw_self ? (c->pw_small_set ? 2 : 1) : 0;       // (2: a launch that cannot fill the chip takes the short-latency prologue)
+    f.self_spans = c->pw_self ? 1 : 0;
     f.band_ent = nullptr; f.band_cnt = nullptr; f.band_stride = 0; f.n_bands = 0; f.band_cap = 0; f.band_rows_log2 = 6;
     if (c->pw_self && c->pw_bands && c->d_rowcnt) {
         const RowLists rl = rows_of(c);
@@ -323,7 +323,6 @@ PwFrames frames_of(const hg_ctx *c)
     // stay in that XCD's L2 from frame to frame), rotating with the frame otherwise (even load; measured in hg_k_piecewise.hip)
     f.xcc_rotate = c->opt_xcc_rotate >= 0 ? (c->opt_xcc_rotate != 0) : (c->n_imgs > 1 || c->pw_fill > 1.08);
     f.xcc_log2 = c->xcc_log2; f.no_hi_bounds = c->opt_hi_bounds ? 0 : 1;
-    f.rows8 = c->pw_rows8 ? 1 : 0;
     f.sgpr_cap = c->n_imgs <= 1;
     f.lds_pad_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : (c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0);
     f.lds_pad_patch_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : 0;
@@ -336,7 +335,6 @@ PwFrames frames_of(const hg_ctx *c)
     f.safe_spans = c->opt_safe_spans >= 0 ? c->opt_safe_spans : (c->pw_spans_per_window < 3.0 ? 1 : 0);
     f.safe_spans_patch = c->opt_safe_spans >= 0 ? c->opt_safe_spans : 1;
     f.phase = c->opt_phase > 0 ? c->opt_phase : (c->n_imgs > 1 || c->pw_self ? 4 : (c->pw_spans_per_window >= 3.0 ? 4 : 2));
-    f.patch_blocks = c->opt_phase > 0 ? c->opt_phase : 8;    // (k_pw_patch: measured best in both source layouts, hg_k_patch.hip)
     return f;
 }
 
@@ -413,10 +411,6 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         bool self_rows = self_ok && !want_patch && !compact && c->row_cap <= kRowSpanCapFast && (c->n_tris <= 1024 || (c->n_tris <= 8192 && c->pw_tri_rows_max > 0)) &&
                          (c->pw_row_group == 1 || c->pw_cover <= 56);
         c->pw_self_patch = self_patch;
-        // 8-row workgroups (k_pw_rows8: one candidate scan and one launch slot per eight rows).  Same box, order-controlled (EXPERIMENTS.md R4.10):
-        // shared source C3 0.574 -> 0.583 ms, C4 0.226 -> 0.227 -- a loss; one source per frame (where k_pw_tile does not take the set) C3
-        // 0.875 -> 0.839, C4 0.376 -> 0.339.  Hence only there, and only for small meshes.
-        c->pw_rows8 = self_rows && c->pw_row_group == kRowGroup && (c->opt_rows8 >= 0 ? c->opt_rows8 == 1 : (c->n_imgs > 1 && c->n_tris <= 256));
         // k_pw_tile instead of k_pw_patch<SELF> where every frame streams its own source (option "tile" forces either).  Same box, one source
         // per frame, alternating order, patch -> tile (EXPERIMENTS.md R4.7): C5 0.5915 -> 0.5093 ms, its mesh at 3/4, 1/2, 1/4 of the shear
         // 0.5345 -> 0.4737, 0.486 -> 0.4528, 0.437 -> 0.429; C3 0.8155 -> 0.816, C4 0.332 -> 0.330, 40x40 / 64x36 grids 0.870 -> 0.868, 0.975 ->
@@ -426,11 +420,16 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         // (128 spans per 3840-pixel row) 0.834 -> 0.783; not elsewhere: 40x40 grid 0.721 -> 0.703 but 24x24 0.642 -> 0.638, C5's mesh at 3/8
         // and 1/8 of its shear 0.353 -> 0.352 and 0.331 -> 0.338, 20x60 tall cells 0.631 -> 0.636.
         const bool tile_shared = c->pw_shear >= 0.3 || (int64_t)c->pw_cover * 64 >= (int64_t)2 * mw;
-        c->pw_tile = self_patch && !c->pw_tile_disabled && mw >= 512 && (c->opt_tile >= 0 ? c->opt_tile == 1 : (c->n_imgs > 1 || tile_shared));
+        // ... and, on a shared source, only where the host's estimate says a tile row holds its spans (a tile is at most 2048 columns of the row: the
+        // estimate -- an upper bound, it counts every piece of the densest row -- split evenly; the kernel checks the real counts and flags what does
+        // not fit, which is how one source per frame finds out: there the redo is paid once and the mesh goes back to k_pw_patch)
+        const int col_tiles = std::max(1, (mw + 2047) / 2048);
+        const bool tile_fits = (c->pw_cover + col_tiles - 1) / col_tiles <= kTileRowSpanCap;
+        c->pw_tile = self_patch && !c->pw_tile_disabled && mw >= 512 && (c->opt_tile >= 0 ? c->opt_tile == 1 : (c->n_imgs > 1 || (tile_shared && tile_fits)));
         c->pw_bands = (self_patch && c->n_tris > 256) || (self_rows && c->n_tris > 1024);
         if (c->pw_bands && (std::max(max_h, 1) + 63) / 64 > 2048) {      // (kBandMax; frames taller than 131 072 rows)
             c->pw_bands = false; c->pw_self_patch = false;
-            if (c->n_tris > 1024) { self_rows = false; c->pw_rows8 = false; }
+            if (c->n_tris > 1024) self_rows = false;
         }
         if (c->pw_bands) {
             // bands of 64 output rows; capacity from the tallest triangle of the frame set (host estimate; an overfull band flags its frame)
@@ -477,7 +476,7 @@ static int run_setup(hg_ctx *c, bool for_tap = false)
         // the general path has no row lists, no self-span prologue and no candidate bands: frames_of() must not hand k_tri_setup the
         // band buffers an earlier fast-path set was laid out for (sized for ITS frame count and height), and the next fast-path set
         // starts from freshly zeroed counters
-        c->pw_self = false; c->pw_bands = false; c->pw_self_patch = false; c->pw_tile = false; c->pw_rows8 = false; c->rows_clean = false;
+        c->pw_self = false; c->pw_bands = false; c->pw_self_patch = false; c->pw_tile = false; c->rows_clean = false;
         c->status_ptr = c->d_status;
         HIP_TRY(c, hipMemsetAsync(c->d_status, 0, sizeof(int32_t) * F, c->stream));
         launch_tri_setup(mesh_of(c), frames_of(c), c->stream);

@@ -126,7 +126,6 @@ struct hg_ctx {
     bool pw_small_set = false;                                 // fewer 4-row groups than "min_row_groups": one row per workgroup, short-latency prologues
     bool pw_self = false;                                      // the current step uses the self-span path
     bool pw_self_disabled = false;                             // a run on it flagged a frame (more candidates / spans than its LDS blocks hold): row lists for this mesh
-    bool pw_rows8 = false;                                     // ... with 8-row workgroups (k_pw_rows8)
     bool pw_self_patch = false;                                // ... through k_pw_patch (dense / sheared meshes, one source per frame)
     bool pw_tile = false;                                      // ... through k_pw_tile (8-row x <= 2048-column tiles whose gathers follow the source rows)
     bool pw_tile_disabled = false;                             // a tile exceeded its limits once: k_pw_patch for this mesh
@@ -140,7 +139,6 @@ struct hg_ctx {
     int opt_tri_group = -1;                                    // k_tri_spans_grouped: 16 / 64 triangles per workgroup, 0 never, -1 by mesh size
     int opt_upload_kernel = -1;                                // frame-set blocks up to 1 MB go up by k_upload (default) instead of hipMemcpyAsync (0)
     int opt_safe_spans = -1;                                   // option "safe_spans": span flags + bounds-test-free windows in k_pw_rows: 1 / 0, -1 by the spans-per-window estimate
-    int opt_rows8 = -1;                                        // k_pw_rows<SELF>: 8 rows per workgroup (1), 4 (0), -1 by policy
     // layout estimates of the last frame set, reused for the next set of the same shape (the kernels check the real counts)
     struct LayoutKey { int n = -1, n_tris = -1, max_w = -1, max_h = -1; uint64_t mesh_gen = 0; bool quick = false; } layout_key;
     uint64_t mesh_gen = 0; int layout_age = 0;

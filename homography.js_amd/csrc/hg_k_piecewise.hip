@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh m
 }
 
 
-template <int CAP, bool MAP, int PH, bool COMPACT, bool HIB, int SELF, int RG = kRowGroup>      // SELF: 0 row lists, 1 own spans, 2 the same with all three edges in flight (small frame sets); RG: rows per group in packed mode (8: k_pw_rows8, SELF only)
+template <int CAP, bool MAP, int PH, bool COMPACT, bool HIB, int SELF>      // SELF: 0 row lists, 1 own spans
 __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *__restrict__ out,
                                              int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
                                              int32_t *__restrict__ status_next)
@@ -483,8 +483,8 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
 
     __shared__ __align__(16) double s_m[CAP * 6];
     __shared__ int s_lo[CAP], s_hi[CAP], s_len[CAP], s_key[CAP];   // span start / end (window overlap test), length, key (KS)
+    constexpr int RG = kRowGroup;                            // rows per group in packed mode
     static_assert(CAP >= 64 * RG, "packed mode gives each of the RG rows a 64-slot block");
-    static_assert(RG == kRowGroup || (RG == 8 && SELF == 1), "8-row groups exist for the self-span path only");
     constexpr int KS = CAP * 48 <= (1 << kKeyShift) ? kKeyShift : kKeyShift + 1, KMASK = (1 << KS) - 1;   // id << KS | record offset | unsafe
     static_assert(CAP * 48 <= (1 << KS) && KS <= 15, "record offsets must fit below the 15-bit id");
     // Record offsets are multiples of 48: the low four bits of a key are free.  Bit 0 = "unsafe": 0 only when BOTH end pixels of the
@@ -610,7 +610,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         // Candidate entries carry up to `chunk` source rows (4 for 4-row groups, 1 for one-row groups: one lane per row below); a
         // triangle that reaches more rows -- window borders, spans spilling over the row end (x-offset quirk) -- files a second entry
         // for the rest, whose lanes loop if that is still more than `chunk` (a - b > 1: triangles wider than the map; rare).
-        const int chunk_log2 = packed ? (RG == 8 ? 3 : 2) : 0, chunk = 1 << chunk_log2;
+        const int chunk_log2 = packed ? 2 : 0, chunk = 1 << chunk_log2;
         // (meshes beyond 1024 triangles: not the whole mesh but the entries k_tri_setup filed under this group's 64-row band, as in k_pw_patch<SELF>)
         int n_src = T;
         const int4 *__restrict__ bent = nullptr;
@@ -673,16 +673,11 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                     mn = (use & (x < mn)) ? x : mn;
                     mx = (use & (x > mx)) ? x : mx;
                 };
-                if constexpr (SELF == 2) {                  // small frame sets: one round trip for all three edge equations (72 VGPRs, which
-                    const Seg q0 = sg[0], q1 = sg[1], q2 = sg[2];       // a launch that does not fill the chip can afford)
-                    edge(q0); edge(q1); edge(q2);
-                } else {
-                    // one edge at a time: with all three in flight the prologue would need 14 registers more than the pixel loop does
-                    // (72 instead of 56-58: 7 waves per SIMD instead of 8).  The three dependent round trips this costs are NOT what the
-                    // prologue's time is made of (EXPERIMENTS.md R4.8: forming the edges from the vertices in one round trip changed nothing)
+                // one edge at a time: with all three in flight the prologue would need 14 registers more than the pixel loop does
+                // (72 instead of 56-58: 7 waves per SIMD instead of 8).  The three dependent round trips this costs are NOT what the
+                // prologue's time is made of (EXPERIMENTS.md R4.8: forming the edges from the vertices in one round trip changed nothing)
 #pragma unroll 1
-                    for (int e = 0; e < 3; e++) edge(sg[e]);
-                }
+                for (int e = 0; e < 3; e++) edge(sg[e]);
                 // the two flat fill() indices :1124 = (y - yOffset) * W + Math.round(x) under TypedArray.fill's index rules: NaN -> 0,
                 // trunc, negative counts from the end, clamp to [0, len] (js_fill_index, hg_math.h; maxNum / minNum absorb the NaN)
                 const double base = (y - (double)fd.y_off) * fW;
@@ -920,14 +915,6 @@ __global__ __launch_bounds__(256) void k_pw_rows(PwMesh mesh, PwFrames fr, RowLi
     pw_rows_body<CAP, MAP, PH, COMPACT, HIB, SELF>(mesh, fr, rl, out, map_out, groups_per_xcd, rows_per_group, status_next);
 }
 
-// 8-row groups of the self-span path (512 threads, wave j walks row r0 + j): one candidate scan and one launch slot per EIGHT rows -- the
-// prologue is issue time the pixel loop cannot hide (EXPERIMENTS.md R4.8), and its scan / launch share halves.  Same body, RG = 8.
-template <int PH, bool HIB>
-__global__ __launch_bounds__(512) void k_pw_rows8(PwMesh mesh, PwFrames fr, RowLists rl, uint8_t *__restrict__ out, int groups_per_xcd, int32_t *__restrict__ status_next)
-{
-    pw_rows_body<kRowSpanCapDense, false, PH, false, HIB, 1, 8>(mesh, fr, rl, out, nullptr, groups_per_xcd, 8, status_next);
-}
-
 // The same kernel held to 80 SGPRs.  A 256-thread workgroup puts one wave on each SIMD and a SIMD has 800 SGPRs, allocated in
 // granules of 16 (+16): the 89-104 the compiler takes by itself admit 7 (or 6) workgroups per CU although VGPRs and LDS allow
 // 8; capped, ~20 scalars move into VGPR lanes and 8 workgroups fit.  Measured on one box (round 3): with a shared,
@@ -1006,14 +993,13 @@ void launch_tri_spans(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl
 }
 
 // Returns the variant code of the instantiation it launched (hg_last_piecewise_variant; tools/census.py): kind * 100000 + (512-slot rows) * 10000 +
-// windows-or-blocks per phase * 1000 + (8-byte entries) * 100 + (bounds on the high dwords) * 10 + self-span form; kind 1 k_pw_rows, 2 k_pw_rows8,
+// windows-or-blocks per phase * 1000 + (8-byte entries) * 100 + (bounds on the high dwords) * 10 + self-span form; kind 1 k_pw_rows,
 // 3 k_pw_rows_s80, 4 k_pw_patch, 5 k_pw_tile, 6 k_pw_fused, 8 k_pw_patch with global records; + 50 for a parity-tap (map) instantiation.
 int launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int16_t *map_out, int32_t *status_next, hipStream_t stream)
 {
     if (fr.n_frames <= 0 || fr.max_obj_h <= 0) return 0;
     int code = 0;
-    const bool rows8 = fr.self_spans == 1 && fr.rows8 && fr.row_group == kRowGroup && !map_out;
-    const int rg = rows8 ? 8 : (fr.row_group == kRowGroup ? kRowGroup : 1);
+    const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
     const int nx = 1 << fr.xcc_log2;                                            // XCCs of this device (partition mode), hg_create
     const int rpx = ((fr.max_obj_h + rg - 1) / rg + nx - 1) / nx;               // row groups per XCD band
     dim3 grid((unsigned)rpx * (unsigned)nx * (unsigned)fr.n_frames);
@@ -1025,24 +1011,12 @@ int launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, u
 #define HG_ROWS(CAP, MAPF, PHV, CMP, HB, SF) do { code = 100000 + ((CAP) > kRowSpanCapFast ? 10000 : 0) + (PHV) * 1000 + ((CMP) ? 100 : 0) + ((HB) ? 10 : 0) + (int)(SF) + ((MAPF) ? 50 : 0); \
         hipLaunchKernelGGL((k_pw_rows<CAP, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); } while (0)
 #define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true, 0); else HG_ROWS(CAP, false, 1, CMP, false, 0); } while (0)
-    if (rows8) {
-        if (hib) hipLaunchKernelGGL((k_pw_rows8<4, true>), grid, dim3(512), pad, stream, mesh, fr, rl, out, rpx, status_next);
-        else     hipLaunchKernelGGL((k_pw_rows8<1, false>), grid, dim3(512), pad, stream, mesh, fr, rl, out, rpx, status_next);
-        return 200000 + (hib ? 4011 : 1001);
-    }
     if (fr.self_spans) {                                     // spans evaluated by the row workgroups themselves (sparse meshes: CAP 256, no row lists, k_tri_setup in front)
-        if (map_out) { HG_ROWS(kRowSpanCapFast, true, 1, false, false, 1); return code; }
-        if (!hib) { HG_ROWS(kRowSpanCapFast, false, 1, false, false, 1); return code; }
-        if (fr.self_spans == 2) { HG_ROWS(kRowSpanCapFast, false, 2, false, true, 2); return code; }      // small frame sets: the short-latency prologue
-        switch (fr.phase) {
-        case 4:  HG_ROWS(kRowSpanCapFast, false, 4, false, true, 1); break;
-        case 2:
-            if (fr.sgpr_cap) { code = 302011; hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, false, 2, false, true, 1>), grid, block, pad, stream,
-                                                mesh, fr, rl, out, map_out, rpx, rg, status_next); }
-            else HG_ROWS(kRowSpanCapFast, false, 2, false, true, 1);
-            break;
-        default: HG_ROWS(kRowSpanCapFast, false, 1, false, true, 1); break;
-        }
+        // ONE depth: 4 windows per phase (R4.10: a wash to a slight gain over 2 for every self-span set; the census of round 6 found the
+        // 1- / 2-window, the 80-SGPR and the three-edges-in-flight instantiations never picked: deleted, EXPERIMENTS.md R6.6)
+        if (map_out) HG_ROWS(kRowSpanCapFast, true, 1, false, false, 1);
+        else if (!hib) HG_ROWS(kRowSpanCapFast, false, 1, false, false, 1);
+        else HG_ROWS(kRowSpanCapFast, false, 4, false, true, 1);
         return code;
     }
     if (rl.cap > kRowSpanCapFast) {                          // very dense meshes: 512 LDS slots per row (32 KB), one row per workgroup

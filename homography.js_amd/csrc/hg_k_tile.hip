@@ -23,7 +23,7 @@ namespace hg {
 #ifndef HG_TILE_COLS
 #define HG_TILE_COLS 2048
 #endif
-constexpr int kTileRows = 8, kTileCols = HG_TILE_COLS, kTileBlocks = kTileCols / 64, kTileCap = 96, kTileRecs = 128, kTileCands = 192,
+constexpr int kTileRows = 8, kTileCols = HG_TILE_COLS, kTileBlocks = kTileCols / 64, kTileCap = kTileRowSpanCap, kTileRecs = 128, kTileCands = 192,
               kTileBinSlots = 8, kTilePitch = 72, kTilePB = HG_TILE_PB,
               kTileSpanPitch = kTileCap + 8;         // words between the rows' span blocks: 8 mod 64, so the eight rows a wave looks up at once start 8 banks apart (96: 4-way conflicts)
 

@@ -69,16 +69,14 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t phase;                  // k_pw_rows: windows whose gathers are issued before their stores (1, 2 or 4)
     int32_t xcc_rotate;             // 1: XCD x takes band (x + frame) mod XCCs instead of band x (uneven rows, or no source shared between frames)
     int32_t xcc_log2;               // log2 of the device's XCC count (8 on an unpartitioned MI355X): block id -> XCD row band
-    int32_t patch_blocks;           // k_pw_patch: 64-pixel column blocks per gather / store phase (1, 2, 4, 8)
     int32_t lds_pad_kb;             // option "lds_pad": KB of unused dynamic LDS per k_pw_rows workgroup (caps the workgroups resident per CU)
     int32_t lds_pad_patch_kb;       // the same for k_pw_patch / k_pw_tile (explicit option only: they lose with fewer workgroups)
     int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only
     int32_t no_hi_bounds;           // option "hi_bounds" = 0: keep the fp64 bounds compares (parity suite runs both forms)
-    int32_t rows8;                  // k_pw_rows<SELF> with 8 rows per workgroup (512 threads) instead of 4
     int32_t safe_spans;             // 1: the row kernel flags every span whose two end pixels pass the source bounds test and runs windows made of such spans
                                     // without the per-pixel test (k_pw_rows); 0: no flags (rows of many short spans, where flagging costs more than it saves)
     int32_t safe_spans_patch;       // the same flags in k_pw_patch<SELF> (per 64-pixel x 4-row block)
-    int32_t self_spans;             // 1 / 2 (small frame sets: the prologue with all three edge equations in flight): no row lists -- k_tri_setup ran, the
+    int32_t self_spans;             // 1: no row lists -- k_tri_setup ran, the
                                     // warp kernel's workgroups evaluate the spans of their own rows in their prologue
     // Candidate bands of the self-span path for meshes too large to scan per workgroup (k_tri_setup files every triangle under the
     // bands of 1 << band_rows_log2 output rows it can reach; a row workgroup tests only its band's entries).  band_ent == nullptr:
@@ -132,6 +130,7 @@ constexpr int kPatchMaxW = 8192, kPatchMaxRowSpans = 215, kPatchMaxGroupTris = 2
 constexpr int kPatchMaxRowSpansDense = 480;
 int launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int32_t *status_next, bool global_records, hipStream_t stream);
 // Sheared meshes (self-span path only): tiles of 8 rows x <= 2048 columns whose gathers follow the source rows (hg_k_tile.hip).
+constexpr int kTileRowSpanCap = 96;       // k_pw_tile: spans per row and tile (its LDS span blocks); beyond: the frame is flagged and redone, the mesh goes back to k_pw_patch
 int launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *out, int max_obj_w, int32_t *status_next, hipStream_t stream);
 
 // Materialised-map path for ONE frame (index f): map32 := -1; atomicMax rasteriser (:845-861 + :1111-1126); then

@@ -245,7 +245,14 @@ int hg_warp_forward_piecewise_batch_device(hg_ctx *ctx, const float *dst_points,
  * FORWARD matrices as they were last solved (6 floats per triangle, hg_solve_affine_triangles of the snapshot) and the definition
  * of the map the field holds (the point set + triangles fillTriangle rasterised, matrix_width, height = length / width, yOffset).
  * Exact for any input (materialised map: atomicMax rasteriser + the pixel loop reading it), synchronous, host output of
- * 4 * obj_w * obj_h bytes.  HG_ERR_RANGE when a cell the loop reads holds an id >= n_mats (JS: TypeError at that pixel). */
+ * 4 * obj_w * obj_h bytes.  HG_ERR_RANGE when a cell the loop reads holds an id >= n_mats (JS: TypeError at that pixel); the forward
+ * form makes that check for a blank window too (the reference's loop runs over the source bounding box whatever the output size).
+ * LIMITS of these two forms (HG_ERR_INVALID, a string error in the class, where the reference would still produce pixels or fail
+ * differently -- none of them reachable from finite pixel coordinates of images that fit the other entry points): a map coordinate
+ * that is infinite or beyond 2^24 in magnitude (NaN is legal: such a triangle rasterises nothing); |map y_off| > 2^26; a map of 2^31
+ * cells or more; forward form: a source-point bounding box of 2^31 pixels or more, or taller than 65 535 rows.  Triangle ids are the
+ * reference's Int16Array values: with more than 32 767 triangles they wrap (id 32 768 reads back as -32 768 = "no triangle"),
+ * reproduced as such. */
 typedef struct hg_tri_map_def {
     const float *points; int n_points;              /* interleaved x,y of the point set the map was rasterised from */
     const uint32_t *triangles; int n_triangles;
@@ -318,7 +325,7 @@ int hg_multi_frame(hg_multi *multi, int frame, int *device_index, void **d_ptr, 
 int hg_last_piecewise_kernel(hg_ctx *ctx);
 /* ... and which template instantiation of it (tools/census.py: the census of what the layout policy really picks): kind * 100000 +
  * (512-slot rows) * 10000 + windows / blocks per phase * 1000 + (8-byte row entries) * 100 + (bounds on the high dwords) * 10 + self-span
- * form; kind 1 k_pw_rows, 2 k_pw_rows8, 3 k_pw_rows_s80, 4 k_pw_patch, 5 k_pw_tile, 6 k_pw_fused, 8 k_pw_patch with records in global memory. */
+ * form; kind 1 k_pw_rows, 3 k_pw_rows_s80, 4 k_pw_patch, 5 k_pw_tile, 6 k_pw_fused, 8 k_pw_patch with records in global memory. */
 int hg_last_piecewise_variant(hg_ctx *ctx);
 /* 1 if that run's row workgroups evaluated their own spans (k_tri_setup + k_pw_rows<SELF>: no row lists, no slot atomics, option
  * "self_spans"), 0 if they read the per-output-row span lists of k_tri_spans. */
@@ -352,7 +359,8 @@ long hg_layout_walks(hg_ctx *ctx);
  *           each frame reads its own source): 0 never use k_pw_patch, 1 use it whenever the frame width allows, 2 the same in its
  *           global-record variant;
  *   "phase" (default -1 = 2 for a shared source -- 4 when the rows carry 3 or more spans per window --, 1 with one source per frame):
- *           windows per k_pw_rows gather/store phase, 1, 2 or 4;
+ *           windows per gather/store phase of k_pw_rows on ROW LISTS, 1, 2 or 4 (the self-span form always takes 4, k_pw_patch 8 column
+ *           blocks: the other depths were never picked by the policy and are gone since round 6);
  *   "geo_windows" (default 8): 256-pixel windows per wave of the affine / projective kernel, 1, 2, 4 or 8;
  *   "self_spans" (default -1 = by policy; 1 = whenever eligible: sparse meshes of up to 8192 triangles; 0 never): no span
  *           producer kernel and no per-output-row span lists -- k_tri_setup writes every triangle's edge equations, inverse matrix
@@ -376,15 +384,13 @@ long hg_layout_walks(hg_ctx *ctx);
  *   "upload_kernel" (default -1 = on): frame-set blocks of up to 1 MB go from their page-locked staging slot to the device by a small kernel
  *           that reads host memory instead of a stream-ordered hipMemcpyAsync (whose copy-engine start-up cost 10-15 us per set); 0: always
  *           the copy engine;
- *   "rows8" (default -1 = one source per frame and a mesh of up to 256 triangles; 1 / 0 force / forbid): the self-span form of k_pw_rows
- *           with 8 rows per workgroup (512 threads) instead of 4: half as many candidate scans and launch slots per pixel (a loss with a
- *           shared source, a gain where every frame streams its own and k_pw_tile does not apply);
  *   "safe_spans" (default -1 = rows of fewer than 3 spans per 256-pixel window; 1 / 0 force / forbid): k_pw_rows flags every span whose two end
  *           pixels pass the source bounds test :1047 (then every pixel between them does: the affine coordinates are monotone along a row) and
  *           runs windows made only of such spans without the per-pixel test, Math.round with one add per coordinate;
  *           k_pw_patch<SELF> does the same per 64-pixel x 4-row block (on unless the option says 0);
- *   "tile" (default -1 = whenever every frame reads its own source and k_pw_patch would evaluate its own spans; 1 = with a shared
- *           source too; 0 never): k_pw_tile instead of k_pw_patch -- 8 x 2048-pixel tiles, gathers in 8-pixel runs along the source
+ *   "tile" (default -1 = wherever k_pw_patch would evaluate its own spans and either every frame reads its own source or, on a shared
+ *           source, the mesh is steeply sheared (estimate >= 0.3) or packs more than two spans into a 64-pixel block -- and the host's
+ *           estimate says a tile row holds its spans; 1 = whenever k_pw_patch<SELF> would run; 0 never): k_pw_tile instead of k_pw_patch -- 8 x 2048-pixel tiles, gathers in 8-pixel runs along the source
  *           rows; a tile beyond its limits (96 spans per row and tile, 128 triangle pieces) flags its frame, hg_sync
  *           redoes it and the mesh goes back to k_pw_patch;
  *   "fwd_tiles": see hg_last_forward_kernel.

@@ -26,8 +26,7 @@ LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds":
            "patch": {"min_row_groups": 0, "patch": 1, "phase": 2, "tri_group": 64}, "patch_global": {"min_row_groups": 0, "patch": 2, "hi_bounds": 0, "xcc": 2},
            "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0, "self_spans": 1, "safe_spans": 0},
            "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16, "self_spans": 0, "xcc_rotate": 1, "tri_group": 0},
-           "tile": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 1, "xcc_rotate": 1},
-           "rows8": {"min_row_groups": 0, "patch": 0, "self_spans": 1, "rows8": 1, "safe_spans": 1}}
+           "tile": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 1, "xcc_rotate": 1}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))
@@ -1173,8 +1172,8 @@ def test_self_span_path_policy_flags_and_falls_back():
             c.set_option("min_row_groups", 0); c.set_option("patch", 0); c.set_option("tile", -1)
             c.piecewise_set_mesh(sp, tris, ms[0], ms[1])
             want = [O.warp_inverse_piecewise(sp, frames[f], tris, img, ms[0], ms[1], *geoms[f]) for f in range(F)]
-            for opt, rows8 in ((-1, 0), (-1, 1), (0, 0)):
-                c.set_option("self_spans", opt); c.set_option("rows8", rows8)
+            for opt in (-1, 0):
+                c.set_option("self_spans", opt)
                 c.piecewise_set_frames(np.concatenate(frames), geoms, offs)
                 c.warp_inverse_piecewise_frames_device(d_out)
                 c.warp_inverse_piecewise_frames_device(d_out)          # (queued twice: the band counters clean themselves)
@@ -1182,10 +1181,10 @@ def test_self_span_path_policy_flags_and_falls_back():
                 assert c.last_piecewise_kernel() == 1 and c.last_piecewise_self() == (1 if opt else 0), (opt, c.last_piecewise_kernel(), c.last_piecewise_self())
                 for f in range(F):
                     g = geoms[f]
-                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), ("row bands", opt, rows8, f)
+                    assert np.array_equal(c.to_host(d_out, g[2] * g[3] * 4, offs[f]).reshape(g[3], g[2], 4), want[f]), ("row bands", opt, f)
             assert c.redone_frames() == 0
         finally:
-            c.set_option("rows8", -1); c.set_option("patch", -1); c.set_option("self_spans", -1)
+            c.set_option("patch", -1); c.set_option("self_spans", -1)
             c.free(d_out)
         # (c) 320 x 1 cells, 7 small frames: the host skips its per-triangle walk for such sets and guesses ~63 spans per row, every row is
         #     crossed by ~640 -> the one-row self-span blocks (255) overflow -> frames flagged -> map path; then row lists for this mesh
@@ -1299,6 +1298,44 @@ def test_reference_state_entry_points_match_oracle_on_fresh_seeds():
         assert np.array_equal(c.warp_inverse_piecewise(), first) and np.array_equal(first, O.warp_inverse_piecewise(sp0, dp0, tr0, img0, 0, 0, *g0))
     finally:
         c.close()
+
+
+def test_reference_state_forms_with_more_than_32767_triangles():
+    """The state forms over a mesh whose ids do not fit the reference's Int16Array (A-Q9): 134 x 133 cells = 35 644 triangles; ids from 32 768
+    on wrap to negative values, which both loops read as "no triangle".  Forward form over the stale inverse map (wider than the source bounding
+    box's row length, so rows of the held map straddle the forward index), inverse form over the current map; both against the oracle's pieces."""
+    W, H, nx, ny = 420, 400, 134, 133
+    img = G.lcg_image(W, H, 91)
+    sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+    assert tris.size // 3 > 32767
+    dst_map = (WL.sin_dst(sp, 3.0, 8).reshape(-1, 2) * np.float32([1.12, 1.05]) + np.float32([4, 2])).astype(np.float32).ravel()
+    dst_now = (WL.sin_dst(sp, 2.0, 9).reshape(-1, 2) * np.float32([0.97, 0.99])).astype(np.float32).ravel()
+    mats = HG.solve_affine_triangles(sp, dst_now, tris)
+    mm = [int(v) for v in O.minmax_xy(sp)]
+    gm, geom = WL.piecewise_geom(dst_map), WL.piecewise_geom(dst_now)
+    assert gm[2] > mm[2] - mm[0]                                  # the held map's rows are longer than the forward index's
+    held = O.build_tri_map(dst_map, tris, gm[2], gm[1], gm[2] * gm[3])
+    assert held.min() < -1                                        # wrapped ids are in the map
+    cells = (mm[2] - mm[0]) * (mm[3] - mm[1])
+    eff = np.full(cells, -1, np.int16)
+    eff[:min(held.size, cells)] = held[:min(held.size, cells)]
+    with HG.Context(0) as c:
+        c.set_image(img)
+        got = c.warp_forward_piecewise_state(mats, dst_map, tris, gm[2], gm[3], gm[1], mm[0], mm[1], mm[2], mm[3], geom)
+        assert np.array_equal(got, O.warp_forward_piecewise(eff, mats, img, mm[0], mm[1], mm[2], mm[3], *geom))
+        imap = O.build_tri_map(dst_now, tris, geom[2], geom[1], geom[2] * geom[3])
+        assert imap.min() < -1
+        got = c.warp_inverse_piecewise_state(mats, dst_now, tris, mm[0], mm[1], geom)
+        inv = np.stack([O.inverse_affine(m) for m in mats])
+        assert np.array_equal(got, O.warp_inverse_piecewise_loop(imap, inv, img, mm[0], mm[1], *geom))
+        # the documented limits are string errors, not pixels
+        far = dst_map.copy(); far[0] = np.float32(2.0 ** 25)
+        with pytest.raises(HG.HgError) as e:
+            c.warp_forward_piecewise_state(mats, far, tris, gm[2], gm[3], gm[1], mm[0], mm[1], mm[2], mm[3], geom)
+        assert e.value.code == 1                                  # HG_ERR_INVALID
+        with pytest.raises(HG.HgError) as e:
+            c.warp_forward_piecewise_state(mats, dst_map, tris, gm[2], gm[3], (1 << 26) + 1, mm[0], mm[1], mm[2], mm[3], geom)
+        assert e.value.code == 1
 
 
 def test_general_path_between_two_banded_fast_path_sets():
@@ -1637,10 +1674,11 @@ def test_dense_sheared_mesh_takes_the_patch_kernel():
     c = HG.Context(0)
     c.set_option("min_row_groups", 0)            # (these frame sets are small: without this they would all run one row per workgroup)
     try:
-        # (dense sheared -> k_pw_tile (5; round 6, EXPERIMENTS.md R6.4: before that k_pw_patch); dense flat -> k_pw_patch since round 4 (its self-span form needs no producer kernel);
+        # (dense sheared, more spans per row than a tile holds -> k_pw_patch; dense sheared within the tile's limits -> k_pw_tile (5; round 6, EXPERIMENTS.md R6.4:
+        #  before that k_pw_patch); dense flat -> k_pw_patch since round 4 (its self-span form needs no producer kernel);
         #  dense rows too narrow for its bins -> k_pw_rows one row per workgroup; sparse -> 4-row groups; very dense, ~300 spans per
         #  row -> k_pw_patch in its global-record variant)
-        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 5), (3200, 150, 17, 3, 0.5, 3), (640, 150, 60, 3, 0.5, 2),
+        for (W, H, nx, ny, A, want_kernel) in [(1600, 150, 56, 3, 14.0, 3), (3200, 150, 32, 3, 40.0, 5), (3200, 150, 17, 3, 0.5, 3), (640, 150, 60, 3, 0.5, 2),
                                                (640, 150, 8, 3, 18.0, 1), (3000, 100, 110, 2, 5.0, 3)]:
             img = G.lcg_image(W, H, 31)
             sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)

@@ -16,7 +16,7 @@ def load(name, rel):
     m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
 
 
-KIND = {1: "k_pw_rows", 2: "k_pw_rows8", 3: "k_pw_rows_s80", 4: "k_pw_patch", 5: "k_pw_tile", 6: "k_pw_fused", 8: "k_pw_patch<GLOBALREC>"}
+KIND = {1: "k_pw_rows", 3: "k_pw_rows_s80", 4: "k_pw_patch", 5: "k_pw_tile", 6: "k_pw_fused", 8: "k_pw_patch<GLOBALREC>"}
 
 
 def describe(code):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wide fuzz of the HIP path against the CPU oracle (run on the GPU box): tools/fuzz_gpu.py [trials] [seed].
 FUZZ_TILE=1: wide frames, every trial also as a 3-frame batch (shared source and one source per frame) with k_pw_tile forced half of the time.
-FUZZ_ROWS=1: the same frames through the self-span row kernel (4- and 8-row workgroups at random)."""
+FUZZ_ROWS=1: the same frames through the self-span row kernel."""
 import os
 import sys
 
@@ -35,7 +35,6 @@ for t in range(trials):
     ctx.set_option("hi_bounds", int(rng.choice([1, 1, 0])))
     ctx.set_option("self_spans", int(rng.choice([-1, 1, 0])))
     ctx.set_option("tile", int(rng.choice([-1, 1, 1, 0])))
-    ctx.set_option("rows8", int(rng.choice([-1, 1, 0])))
     ctx.set_option("safe_spans", int(rng.choice([-1, 1, 0])))
     if TILE:
         ctx.set_option("self_spans", 1); ctx.set_option("patch", 0 if ROWS else 1); ctx.set_option("min_row_groups", 0)

@@ -113,7 +113,7 @@ for seq in range(n_seq):
                     c.piecewise_set_mesh(sp32, tris, int(ms[0]), int(ms[1]))
                 continue
             if r < 0.3:
-                c.set_option(str(rng.choice(["phase", "patch", "tri_group", "xcc_rotate", "self_spans", "rows8", "tile", "min_row_groups"])), int(rng.choice([-1, 0, 1, 2])))
+                c.set_option(str(rng.choice(["phase", "patch", "tri_group", "xcc_rotate", "self_spans", "tile", "min_row_groups"])), int(rng.choice([-1, 0, 1, 2])))
                 continue
             k = int(rng.integers(0, 3))
             n = int(rng.integers(1, 4))
