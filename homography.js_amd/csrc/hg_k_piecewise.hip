@@ -474,7 +474,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // housekeeping for the NEXT step (saves its memset): the next status set is cleared here, and every workgroup zeroes the
     // span counters of its rows in the OTHER of the two counter sets -- the one the previous step consumed and the next step's
     // k_tri_spans will count into (ping-pong: nobody reads it during this launch, so no ordering against this launch's readers)
-    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;       // 256 threads (512: k_pw_rows8)
+    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;       // 256 threads
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += nthreads) status_next[i] = 0;
     // (every row of the frame's counter block, not only the rows of THIS step's window: the other set was filled under the
     //  previous step's geometry, whose frame may have been a row taller)

@@ -1338,6 +1338,35 @@ def test_reference_state_forms_with_more_than_32767_triangles():
         assert e.value.code == 1
 
 
+def test_forward_state_form_checks_the_held_map_for_a_blank_window_too():
+    """A forward frame with a blank window (:440) does not stop the reference's loop :955-969: it walks the source bounding box over the held map
+    and throws where a cell names a matrix that does not exist.  hg_warp_forward_piecewise_state therefore checks the ids BEFORE it returns for an
+    empty window (HG_ERR_RANGE -> the class's TypeError); with every id in range nothing is written and the call succeeds."""
+    W, H, nx, ny = 96, 80, 4, 3
+    img = G.lcg_image(W, H, 17)
+    sp, tris = WL.grid_points(W, H, nx, ny), WL.grid_triangles(nx, ny)
+    dst = (WL.sin_dst(sp, 2.0, 8).reshape(-1, 2) * np.float32(1.2)).astype(np.float32).ravel()
+    gm = WL.piecewise_geom(dst)
+    mats = HG.solve_affine_triangles(sp, dst, tris)
+    mm = [int(v) for v in O.minmax_xy(sp)]
+    T = tris.size // 3
+    with HG.Context(0) as c:
+        c.set_image(img)
+        for geom in ((0, 0, 0, 0), (3, 2, 0, 17), (5, 5, 40, 0)):
+            out = c.warp_forward_piecewise_state(mats, dst, tris, gm[2], gm[3], gm[1], mm[0], mm[1], mm[2], mm[3], geom)
+            assert out.size == 0
+            with pytest.raises(HG.HgError) as e:
+                c.warp_forward_piecewise_state(mats[:2], dst, tris, gm[2], gm[3], gm[1], mm[0], mm[1], mm[2], mm[3], geom)     # (the cells the loop reads hold ids beyond 1)
+            assert e.value.code == 6                              # HG_ERR_RANGE
+        # ... and the context goes on as usual
+        geom = WL.piecewise_geom(dst)
+        held = O.build_tri_map(dst, tris, gm[2], gm[1], gm[2] * gm[3])
+        cells = (mm[2] - mm[0]) * (mm[3] - mm[1])
+        eff = np.full(cells, -1, np.int16); eff[:min(held.size, cells)] = held[:min(held.size, cells)]
+        got = c.warp_forward_piecewise_state(mats, dst, tris, gm[2], gm[3], gm[1], mm[0], mm[1], mm[2], mm[3], geom)
+        assert np.array_equal(got, O.warp_forward_piecewise(eff, mats, img, mm[0], mm[1], mm[2], mm[3], *geom))
+
+
 def test_general_path_between_two_banded_fast_path_sets():
     """A context that ran the self-span path WITH candidate bands (a mesh beyond 256 triangles on k_pw_patch<SELF>), then a frame set
     the fast kernels do not take (source minimum beyond 2^22: k_pw_fused through k_tri_setup alone) with MORE frames and TALLER windows
