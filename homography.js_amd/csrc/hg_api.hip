@@ -243,7 +243,6 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "tri_group")) c->opt_tri_group = value < 0 ? -1 : (value >= 64 ? 64 : (value ? 16 : 0));
     else if (!std::strcmp(key, "safe_spans")) c->opt_safe_spans = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "upload_kernel")) c->opt_upload_kernel = value < 0 ? -1 : (value ? 1 : 0);
-    else if (!std::strcmp(key, "lds_pad")) c->opt_lds_pad = std::min(std::max(value, -1), 40);
     else if (!std::strcmp(key, "xcc")) {                      // block id -> XCD band mapping for `value` XCCs (a power of two <= 64); speed only
         if (value < 1 || value > 64 || (value & (value - 1))) return fail(c, HG_ERR_INVALID, "hg_set_option: xcc must be a power of two in 1..64");
         c->xcc_log2 = 0;

@@ -324,8 +324,7 @@ PwFrames frames_of(const hg_ctx *c)
     f.xcc_rotate = c->opt_xcc_rotate >= 0 ? (c->opt_xcc_rotate != 0) : (c->n_imgs > 1 || c->pw_fill > 1.08);
     f.xcc_log2 = c->xcc_log2; f.no_hi_bounds = c->opt_hi_bounds ? 0 : 1;
     f.sgpr_cap = c->n_imgs <= 1;
-    f.lds_pad_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : (c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0);
-    f.lds_pad_patch_kb = c->opt_lds_pad >= 0 ? c->opt_lds_pad : 0;
+    f.lds_pad_kb = c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0;
     // (self-span path: its instantiations fit 56 VGPRs / 78 SGPRs whatever the phase depth -- 8 workgroups per CU where the list-reading
     //  4-window form admits 7.  Same box, alternating order, 2 -> 4 windows per phase: C3 0.5697 -> 0.5685 ms, C4 0.2220 -> 0.2228, 512-triangle
     //  grid 0.6323 -> 0.6267: a wash to a slight gain, so one depth for every self-span set; EXPERIMENTS.md R4.10)

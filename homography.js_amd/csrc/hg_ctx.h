@@ -86,7 +86,6 @@ struct hg_ctx {
     long pw_redone = 0;                                        // frames redone through the materialised map (hg_redone_frames())
     int opt_min_row_groups = 1152, opt_patch = -1, opt_phase = -1, opt_geo_nw = 8;   // hg_set_option()
     int xcc_log2 = 3;                                          // log2(XCCs of the device): hipDeviceAttributeNumberOfXccs at hg_create, option "xcc"
-    int opt_lds_pad = -1;                                       // KB of dynamic LDS padding per k_pw_rows workgroup (occupancy experiments)
     int opt_hi_bounds = 1;                                     // 0: fp64 bounds compares instead of the high-dword form (hg_dev.h)
     // fused runs whose per-frame status words have not been checked yet: up to kStatusRing - 1 calls are queued back to back
     // with nothing but their two kernels in the stream; each flags into its own set of status words, read back by hg_sync

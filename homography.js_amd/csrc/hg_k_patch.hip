@@ -406,7 +406,7 @@ int launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     const dim3 grid((unsigned)gpx * (unsigned)nx * (unsigned)fr.n_frames);
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
 #define HG_PATCH(G, HB, PBV, SF) do { code = ((G) ? 800000 : 400000) + (PBV) * 1000 + ((HB) ? 10 : 0) + ((SF) ? 1 : 0); \
-        hipLaunchKernelGGL((k_pw_patch<G, HB, PBV, SF>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, status_next); } while (0)
+        hipLaunchKernelGGL((k_pw_patch<G, HB, PBV, SF>), grid, dim3(256), 0, stream, mesh, fr, rl, out, gpx, status_next); } while (0)
     // ONE depth: 8 column blocks per gather / store phase (the census of round 6 found the 1- / 2- / 4-block instantiations never picked
     // by the layout policy: deleted, EXPERIMENTS.md R6.6); the fp64-bounds form keeps its single block
     if (fr.self_spans && !global_records) {                  // own spans (k_tri_setup in front, no row lists)

@@ -326,8 +326,8 @@ int launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, u
     const int tile_cols = (((max_obj_w + cts - 1) / cts) + 63) & ~63;          // the width split evenly over the column tiles (a 2170-pixel row: 2 x 1088, not 2048 + 122)
     const dim3 grid((unsigned)gpx * (unsigned)nx * (unsigned)cts * (unsigned)fr.n_frames);
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-    if (hib) hipLaunchKernelGGL((k_pw_tile<true>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, cts, tile_cols, status_next);
-    else     hipLaunchKernelGGL((k_pw_tile<false>), grid, dim3(256), (size_t)fr.lds_pad_patch_kb * 1024, stream, mesh, fr, rl, out, gpx, cts, tile_cols, status_next);
+    if (hib) hipLaunchKernelGGL((k_pw_tile<true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, gpx, cts, tile_cols, status_next);
+    else     hipLaunchKernelGGL((k_pw_tile<false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, gpx, cts, tile_cols, status_next);
     return 500000 + kTilePB * 1000 + (hib ? 11 : 1);         // (variant code: see launch_pw_rows)
 }
 

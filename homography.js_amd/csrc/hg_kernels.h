@@ -69,8 +69,7 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t phase;                  // k_pw_rows: windows whose gathers are issued before their stores (1, 2 or 4)
     int32_t xcc_rotate;             // 1: XCD x takes band (x + frame) mod XCCs instead of band x (uneven rows, or no source shared between frames)
     int32_t xcc_log2;               // log2 of the device's XCC count (8 on an unpartitioned MI355X): block id -> XCD row band
-    int32_t lds_pad_kb;             // option "lds_pad": KB of unused dynamic LDS per k_pw_rows workgroup (caps the workgroups resident per CU)
-    int32_t lds_pad_patch_kb;       // the same for k_pw_patch / k_pw_tile (explicit option only: they lose with fewer workgroups)
+    int32_t lds_pad_kb;             // KB of unused dynamic LDS per k_pw_rows workgroup (caps the workgroups resident per CU: row lists with one source per frame)
     int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only
     int32_t no_hi_bounds;           // option "hi_bounds" = 0: keep the fp64 bounds compares (parity suite runs both forms)
     int32_t safe_spans;             // 1: the row kernel flags every span whose two end pixels pass the source bounds test and runs windows made of such spans

@@ -379,8 +379,6 @@ long hg_layout_walks(hg_ctx *ctx);
  *           rows differ in cost or the frames share no source; 0: fixed bands (a shared source's band stays in that XCD's L2);
  *   "xcc" (default: hipDeviceAttributeNumberOfXccs of the device, 8 on an unpartitioned MI355X): number of XCCs the
  *           block id -> row band mapping of the warp kernels assumes; a power of two in 1..64;
- *   "lds_pad" (default -1 = 12-16 KB with one source per frame on 4-row groups, else 0): KB of unused dynamic LDS per k_pw_rows
- *           workgroup, 0..40: fewer, deeper-queued workgroups per CU where the kernel is HBM-bound;
  *   "upload_kernel" (default -1 = on): frame-set blocks of up to 1 MB go from their page-locked staging slot to the device by a small kernel
  *           that reads host memory instead of a stream-ordered hipMemcpyAsync (whose copy-engine start-up cost 10-15 us per set); 0: always
  *           the copy engine;
