@@ -17,6 +17,11 @@ __device__ __forceinline__ void flag_frame(const PwFrames &fr, int f, int32_t bi
 
 
 
+// A dword gather by ELEMENT index: `buffer_load_dword ... idxen` through a descriptor of stride 4 (address = base + index * 4; out of range
+// -- 0, the JS `undefined -> 0` -- when index >= NUM_RECORDS, counted in elements).  Saves the `<< 2` of the byte-offset form in every pixel
+// of the kernels that run on their vector port.  clang has no builtin for the structured form; this is the LLVM intrinsic itself.
+extern "C" __device__ uint32_t hg_struct_load_u32(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.ptr.buffer.load.i32");
+
 // ------------------------------------------------------------------------------------------------ bounds on the high dwords
 // The bounds tests :1047 / :1001 are made on h = RTN(s + 0.5):  a <= s < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).
 // When 0 <= a and b < 2^20, both limits are doubles >= 0.5 whose LOW dword is zero (at most 21 significant bits), and then

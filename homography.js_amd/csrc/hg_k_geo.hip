@@ -126,12 +126,11 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
     double m[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) m[k] = mp[k];
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), 0, W * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), 4, W * H, 0x00020000);       // (records of 4 bytes: gathers by pixel index)
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r * OW * 4, 0, OW * 4, 0x00020000);
     const double y = (double)(r + fd.y_off);
     // :1001 on the high dwords of h = RTN(s + 0.5) (hg_dev.h; the launcher admits only W, H < 2^20 here)
     const HiBounds hb = make_hi_bounds(0.5, (double)W + 0.5, 0.5, (double)H + 0.5);
-    const int pitch4 = W * 4;
     // row constants, once per wave: fl(m2*y), fl(m3*y) (affine) / fl(m1*y), fl(m4*y), fl(m7*y) (projective)   :1383-1384 / :1402-1403
     const double cx = (KIND == 0 || KIND == 2) ? m[2] * y : m[1] * y, cy = (KIND == 0 || KIND == 2) ? m[3] * y : m[4] * y, ad = m[7] * y;
     // KIND 4: matrices solved on the device (k_solve_frames), which also proved (or not) the plain range per frame
@@ -168,8 +167,8 @@ __global__ __launch_bounds__(256) void k_geo_fast(const FrameDesc *__restrict__ 
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const bool inb = hi_inb(hb, h[2 * k], h[2 * k + 1]);                                     // :1001 (NaN fails)
-                const uint32_t off = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2)); // :1005
-                px[p][k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? off : 0xffffffffu, 0, 0);
+                const int idx = __mul24((int)dlo(rd[2 * k + 1]), W) + (int)dlo(rd[2 * k]);                            // :1005, in pixels
+                px[p][k] = hg_struct_load_u32(src, inb ? idx : -1, 0, 0, 0);
             }
         }
     };

@@ -283,14 +283,13 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
 #pragma unroll
     for (int k = 0; k < 4; k++) ck[k] = (lane & 15) + 16 * k;
     const double y = (double)(r0 + rr + fd.y_off);
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 0, mesh.W * mesh.H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 4, mesh.W * mesh.H, 0x00020000);   // (records of 4 bytes: gathers by pixel index, hg_struct_load_u32)
     // output: the group's rows as one raw buffer; lanes of rows past the frame end and pixels past the row end get an
     // offset the hardware range check drops
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r0 * W * 4, 0, nrows * W * 4, 0x00020000);
     const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
     const double by_lo = (double)mesh.min_src_y + 0.5, by_hi = (double)mesh.H + (double)mesh.min_src_y + 0.5;
     const HiBounds hb = make_hi_bounds(bx_lo, bx_hi, by_lo, by_hi);      // HIB: :1047 on the high dwords of h (hg_dev.h)
-    const int pitch4 = mesh.W * 4;
     const int nan_key = GLOBALREC ? -1 : ((int)0x80000000u | (RECS * 48) | 1);      // ("no triangle" is unsafe: its pixels must come out as offset 0xffffffff)
     const int row_base = rr * CAPR;
     const int my_cnt = cnts[0] * (rr == 0) + cnts[1] * (rr == 1) + cnts[2] * (rr == 2) + cnts[3] * (rr == 3);
@@ -350,7 +349,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
             int r[8];
             round_half_x4(h, r); round_half_x4(h + 4, r + 4);
 #pragma unroll
-            for (int k = 0; k < 4; k++) px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, (uint32_t)(__mul24(r[2 * k + 1], pitch4) + (r[2 * k] << 2)), 0, 0);
+            for (int k = 0; k < 4; k++)
+                px[k] = hg_struct_load_u32(src, __mul24(r[2 * k + 1], mesh.W) + r[2 * k], 0, 0, 0);
             return;
         }
         round_x8(h, rd);
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
         for (int k = 0; k < 4; k++) {
             const bool inb = HIB ? hi_inb(hb, h[2 * k], h[2 * k + 1])
                                  : (bool)((int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi));   // :1047 (NaN fails)
-            const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
-            px[k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
+            const int o = __mul24((int)dlo(rd[2 * k + 1]), mesh.W) + (int)dlo(rd[2 * k]);                                   // :1048-1049, in pixels
+            px[k] = hg_struct_load_u32(src, inb ? o : -1, 0, 0, 0);
         }
     };
     // 64 x 4 transpose through this wave's LDS tile (wave-synchronous: no barrier), so that each store instruction

@@ -520,9 +520,10 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     }
     const bool packed = SELF ? rows_per_group == RG : (rows_per_group == RG && __builtin_amdgcn_readfirstlane(cmax) <= 63);
 
-    // Source: raw buffer of 4*W*H bytes: an offset at or beyond its end (and the 0xffffffff of rejected pixels) returns 0
-    // from the hardware range check == the JS `undefined` -> 0 of :1051.
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 0, mesh.W * mesh.H * 4, 0x00020000);
+    // Source: buffer of W*H records of 4 bytes, gathered by PIXEL index (`buffer_load_dword ... idxen`: one v_mad per address instead of a
+    // mad and a shift, EXPERIMENTS.md R6.9): an index at or beyond its end (and the -1 of rejected pixels) returns 0 from the hardware
+    // range check == the JS `undefined` -> 0 of :1051.
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 4, mesh.W * mesh.H, 0x00020000);   // (records of 4 bytes: gathers by pixel index, hg_struct_load_u32)
     // :1047 on h = RTN(s + 0.5):  minSrcX <= sx < W + minSrcX  <=>  minSrcX + 0.5 <= hx < W + minSrcX + 0.5, same for y.
     // All four are tested on the doubles: the rounded coordinates are only 32-bit (a source row of 300 * 2^24 must be
     // rejected, not wrapped back into the image); what the range check of the buffer load still provides is the `undefined`
@@ -532,7 +533,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // HIB (host: hi_bounds_ok): the same four tests as two 32-bit compares on the high dwords of h (hg_dev.h)
     const HiBounds hb = make_hi_bounds((double)mesh.min_src_x + 0.5, (double)mesh.W + (double)mesh.min_src_x + 0.5,
                                        (double)mesh.min_src_y + 0.5, (double)mesh.H + (double)mesh.min_src_y + 0.5);
-    const int pitch4 = mesh.W * 4;
     // 1 unless both end pixels lo, hi - 1 of a span with record {m0, m2*y, m4, m1, m3*y, m5} are inside the source window, computed as
     // the pixel body computes them (same fma, same rounding, same compares)
     const bool flag_spans = fr.safe_spans != 0;             // (wave-uniform; host: by the rows' span density)
@@ -837,7 +837,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                             round_half_x4(v, r);
 #pragma unroll
                             for (int k = kk; k < kk + 2; k++)
-                                px[p][k] = __builtin_amdgcn_raw_buffer_load_b32(src, (uint32_t)(__mul24(r[2 * (k - kk) + 1], pitch4) + (r[2 * (k - kk)] << 2)), 0, 0);     // :1048-1049
+                                px[p][k] = hg_struct_load_u32(src, __mul24(r[2 * (k - kk) + 1], mesh.W) + r[2 * (k - kk)], 0, 0, 0);     // :1048-1049, in pixels
                         }
                     } else
 #pragma unroll
@@ -853,9 +853,8 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
                             const int q = 2 * (k - kk);
                             const bool inb = HIB ? hi_inb(hb, h[q], h[q + 1])
                                                  : (bool)((int)(h[q] >= bx_lo) & (int)(h[q] < bx_hi) & (int)(h[q + 1] >= by_lo) & (int)(h[q + 1] < by_hi));   // NaN fails
-                            const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[q + 1]), pitch4) + ((int)dlo(rd[q]) << 2));     // :1048-1049
-                            const uint32_t off = inb ? o : 0xffffffffu;
-                            px[p][k] = __builtin_amdgcn_raw_buffer_load_b32(src, off, 0, 0);                 // range-checked buffer load: outside the array -> 0
+                            const int o = __mul24((int)dlo(rd[q + 1]), mesh.W) + (int)dlo(rd[q]);                           // :1048-1049, in pixels
+                            px[p][k] = hg_struct_load_u32(src, inb ? o : -1, 0, 0, 0);                       // range-checked buffer load: outside the array -> 0
                         }
                     }
                 }

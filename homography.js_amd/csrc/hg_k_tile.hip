@@ -190,12 +190,11 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
     }
 
     const int c = lane & 7, q = lane >> 3;
-    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 0, mesh.W * mesh.H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(frame_img(mesh, f)), 4, mesh.W * mesh.H, 0x00020000);   // (records of 4 bytes: gathers by pixel index, hg_struct_load_u32)
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + (int64_t)r0 * W * 4, 0, nrows * W * 4, 0x00020000);
     const double bx_lo = (double)mesh.min_src_x + 0.5, bx_hi = (double)mesh.W + (double)mesh.min_src_x + 0.5;
     const double by_lo = (double)mesh.min_src_y + 0.5, by_hi = (double)mesh.H + (double)mesh.min_src_y + 0.5;
     const HiBounds hb = make_hi_bounds(bx_lo, bx_hi, by_lo, by_hi);
-    const int pitch4 = mesh.W * 4;
     const int nan_key = (int)0x80000000u | (kTileRecs * 48);
     uint32_t *tile = s_tile + wave * (kTileRows * kTilePitch);
 
@@ -257,8 +256,8 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
             for (int k = 0; k < 4; k++) {
                 const bool inb = HIB ? hi_inb(hb, h[2 * k], h[2 * k + 1])
                                      : (bool)((int)(h[2 * k] >= bx_lo) & (int)(h[2 * k] < bx_hi) & (int)(h[2 * k + 1] >= by_lo) & (int)(h[2 * k + 1] < by_hi));   // :1047 (NaN fails)
-                const uint32_t o = (uint32_t)(__mul24((int)dlo(rd[2 * k + 1]), pitch4) + ((int)dlo(rd[2 * k]) << 2));     // :1048-1049
-                px[4 * half + k] = __builtin_amdgcn_raw_buffer_load_b32(src, inb ? o : 0xffffffffu, 0, 0);
+                const int o = __mul24((int)dlo(rd[2 * k + 1]), mesh.W) + (int)dlo(rd[2 * k]);                               // :1048-1049, in pixels
+                px[4 * half + k] = hg_struct_load_u32(src, inb ? o : -1, 0, 0, 0);
             }
         }
     };
