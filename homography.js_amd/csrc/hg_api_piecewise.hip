@@ -323,6 +323,13 @@ PwFrames frames_of(const hg_ctx *c)
     // stay in that XCD's L2 from frame to frame), rotating with the frame otherwise (even load; measured in hg_k_piecewise.hip)
     f.xcc_rotate = c->opt_xcc_rotate >= 0 ? (c->opt_xcc_rotate != 0) : (c->n_imgs > 1 || c->pw_fill > 1.08);
     f.xcc_log2 = c->xcc_log2; f.no_hi_bounds = c->opt_hi_bounds ? 0 : 1;
+    {   // sub-bands (shared source, fixed bands, several frames): as many per XCD as it takes to bring a sub-band's share of the source to
+        // ~2.2 MB -- a 4K source: 2; 1080p: none (its whole band fits the L2) -- R6.12
+        const int64_t band_bytes = (int64_t)c->W * c->H * 4 >> c->xcc_log2;
+        const int S = c->opt_sub_bands >= 0 ? c->opt_sub_bands : (int)std::min<int64_t>(16, (band_bytes + 2300000 - 1) / 2300000);
+        f.sub_bands = (S > 1 && c->n_imgs <= 1 && !f.xcc_rotate && f.n_frames > 1) ? S : 0;
+        f.sub_groups = 0;                                    // (the launchers set it for their kernel's row-group height)
+    }
     f.sgpr_cap = c->n_imgs <= 1;
     f.lds_pad_kb = c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0;
     // (self-span path: its instantiations fit 56 VGPRs / 78 SGPRs whatever the phase depth -- 8 workgroups per CU where the list-reading

@@ -22,6 +22,26 @@ __device__ __forceinline__ void flag_frame(const PwFrames &fr, int f, int32_t bi
 // of the kernels that run on their vector port.  clang has no builtin for the structured form; this is the LLVM intrinsic itself.
 extern "C" __device__ uint32_t hg_struct_load_u32(__amdgpu_buffer_rsrc_t rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.ptr.buffer.load.i32");
 
+// Which frame and which row group of it the `bi`-th workgroup of XCD `xcd` takes (k_pw_rows / k_pw_patch / k_pw_tile); false: padding.
+//   * plain: the XCD walks its contiguous band of `groups_per_xcd` groups frame by frame (band xcd, or xcd + frame where the bands rotate);
+//   * fr.sub_groups > 0 (shared source, fixed bands; PwFrames): the frame's groups are cut into sub-bands of sub_groups groups, sub-band j belongs
+//     to XCD j mod XCCs, and the XCD takes all frames of one of its sub-bands before the next.
+__device__ __forceinline__ bool frame_group(const PwFrames &fr, int xcd, int bi, int groups_per_xcd, int &f, int &g)
+{
+    if (fr.sub_groups > 0) {
+        const int per_sub = fr.sub_groups * fr.n_frames, sb = bi / per_sub, rem = bi - sb * per_sub;
+        f = rem / fr.sub_groups;
+        g = ((sb << fr.xcc_log2) + xcd) * fr.sub_groups + (rem - f * fr.sub_groups);
+        return g < (groups_per_xcd << fr.xcc_log2);
+    }
+    f = bi / groups_per_xcd;
+    g = ((xcd + (fr.xcc_rotate ? f : 0)) & ((1 << fr.xcc_log2) - 1)) * groups_per_xcd + (bi - f * groups_per_xcd);
+    return true;
+}
+// (launchers: groups per sub-band and the padded number of group slots per XCD and frame)
+inline int sub_groups_of(const PwFrames &fr, int groups_per_xcd) { return fr.sub_bands > 1 ? (groups_per_xcd + fr.sub_bands - 1) / fr.sub_bands : 0; }
+inline int padded_groups(int groups_per_xcd, int sub_groups) { return sub_groups > 0 ? ((groups_per_xcd + sub_groups - 1) / sub_groups) * sub_groups : groups_per_xcd; }
+
 // ------------------------------------------------------------------------------------------------ bounds on the high dwords
 // The bounds tests :1047 / :1001 are made on h = RTN(s + 0.5):  a <= s < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).
 // When 0 <= a and b < 2^20, both limits are doubles >= 0.5 whose LOW dword is zero (at most 21 significant bits), and then

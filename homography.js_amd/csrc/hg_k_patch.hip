@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void k_pw_patch(PwMesh mesh, PwFrames fr, RowL
     constexpr int CAPR = GLOBALREC ? kPatchCapDense : kPatchCap;            // spans per row
     using slot_t = typename std::conditional<GLOBALREC, uint16_t, uint8_t>::type;
     const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1), bi = bid >> fr.xcc_log2;
-    const int f = bi / groups_per_xcd;
-    const int band = (xcd + (fr.xcc_rotate ? f : 0)) & ((1 << fr.xcc_log2) - 1);  // (rotates with the frame: see k_pw_rows)
-    const int r0 = (band * groups_per_xcd + (bi - f * groups_per_xcd)) * kPatchRows;
+    int f, gi;
+    if (!frame_group(fr, xcd, bi, groups_per_xcd, f, gi)) return;           // (bands, rotating bands or dealt sub-bands: hg_dev.h)
+    const int r0 = gi * kPatchRows;
     const FrameDesc fd = fr.frames[f];
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;   // (see k_pw_rows)
     // the OTHER counter set, every row of the frame's block: clean for the next step's k_tri_spans (ping-pong, see k_pw_rows)
@@ -403,10 +403,12 @@ int launch_pw_patch(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, 
     int code = 0;                                            // (variant code: see launch_pw_rows)
     const int nx = 1 << fr.xcc_log2;
     const int gpx = ((fr.max_obj_h + kPatchRows - 1) / kPatchRows + nx - 1) / nx;
-    const dim3 grid((unsigned)gpx * (unsigned)nx * (unsigned)fr.n_frames);
+    PwFrames frs = fr;
+    frs.sub_groups = sub_groups_of(fr, gpx);
+    const dim3 grid((unsigned)padded_groups(gpx, frs.sub_groups) * (unsigned)nx * (unsigned)fr.n_frames);
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
 #define HG_PATCH(G, HB, PBV, SF) do { code = ((G) ? 800000 : 400000) + (PBV) * 1000 + ((HB) ? 10 : 0) + ((SF) ? 1 : 0); \
-        hipLaunchKernelGGL((k_pw_patch<G, HB, PBV, SF>), grid, dim3(256), 0, stream, mesh, fr, rl, out, gpx, status_next); } while (0)
+        hipLaunchKernelGGL((k_pw_patch<G, HB, PBV, SF>), grid, dim3(256), 0, stream, mesh, frs, rl, out, gpx, status_next); } while (0)
     // ONE depth: 8 column blocks per gather / store phase (the census of round 6 found the 1- / 2- / 4-block instantiations never picked
     // by the layout policy: deleted, EXPERIMENTS.md R6.6); the fp64-bounds form keeps its single block
     if (fr.self_spans && !global_records) {                  // own spans (k_tri_setup in front, no row lists)

@@ -463,13 +463,13 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
     // output rows share source cache lines, which then stay in that XCD's L2 instead of being fetched by up to 8 of them.
     const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1);
     const int bi = bid >> fr.xcc_log2;
-    const int f = bi / groups_per_xcd;
+    int f, gi;                                              // frame and row group of it (frame_group, hg_dev.h: bands, rotating bands or dealt sub-bands)
+    if (!frame_group(fr, xcd, bi, groups_per_xcd, f, gi)) return;
     // (fr.xcc_rotate: the band an XCD takes rotates with the frame.  Where rows differ in cost -- C4's face mesh fills the middle
     //  bands and leaves the top and bottom ones nearly empty -- a fixed band per XCD hands the same XCD the expensive band of EVERY
     //  frame: C4 0.234 -> 0.220 ms.  Where they do not and the frames share one source, the fixed band is what keeps that band's
     //  source rows in the XCD's L2 from frame to frame: C3 0.551 fixed, 0.607 rotating.  The host decides, hg_api_piecewise.hip.)
-    const int band = (xcd + (fr.xcc_rotate ? f : 0)) & ((1 << fr.xcc_log2) - 1);
-    const int r0 = (band * groups_per_xcd + (bi - f * groups_per_xcd)) * rows_per_group;
+    const int r0 = gi * rows_per_group;
     const FrameDesc fd = fr.frames[f];
     // housekeeping for the NEXT step (saves its memset): the next status set is cleared here, and every workgroup zeroes the
     // span counters of its rows in the OTHER of the two counter sets -- the one the previous step consumed and the next step's
@@ -1001,14 +1001,16 @@ int launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, u
     const int rg = fr.row_group == kRowGroup ? kRowGroup : 1;
     const int nx = 1 << fr.xcc_log2;                                            // XCCs of this device (partition mode), hg_create
     const int rpx = ((fr.max_obj_h + rg - 1) / rg + nx - 1) / nx;               // row groups per XCD band
-    dim3 grid((unsigned)rpx * (unsigned)nx * (unsigned)fr.n_frames);
+    PwFrames frs = fr;
+    frs.sub_groups = sub_groups_of(fr, rpx);                                    // (sub-bands: the grid is padded to whole sub-bands)
+    dim3 grid((unsigned)padded_groups(rpx, frs.sub_groups) * (unsigned)nx * (unsigned)fr.n_frames);
     // bounds :1047 on the high dwords of the rounded coordinates (hg_dev.h) whenever the source window allows it; the fp64
     // compares otherwise (negative source minimum, sources beyond 2^20 pixels a side) and in the parity-tap instantiations
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
     const dim3 block(256);
     const size_t pad = (size_t)fr.lds_pad_kb * 1024;
 #define HG_ROWS(CAP, MAPF, PHV, CMP, HB, SF) do { code = 100000 + ((CAP) > kRowSpanCapFast ? 10000 : 0) + (PHV) * 1000 + ((CMP) ? 100 : 0) + ((HB) ? 10 : 0) + (int)(SF) + ((MAPF) ? 50 : 0); \
-        hipLaunchKernelGGL((k_pw_rows<CAP, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, fr, rl, out, map_out, rpx, rg, status_next); } while (0)
+        hipLaunchKernelGGL((k_pw_rows<CAP, MAPF, PHV, CMP, HB, SF>), grid, block, pad, stream, mesh, frs, rl, out, map_out, rpx, rg, status_next); } while (0)
 #define HG_ROWS_B(CAP, PHV, CMP) do { if (hib) HG_ROWS(CAP, false, PHV, CMP, true, 0); else HG_ROWS(CAP, false, 1, CMP, false, 0); } while (0)
     if (fr.self_spans) {                                     // spans evaluated by the row workgroups themselves (sparse meshes: CAP 256, no row lists, k_tri_setup in front)
         // ONE depth: 4 windows per phase (R4.10: a wash to a slight gain over 2 for every self-span set; the census of round 6 found the
@@ -1032,7 +1034,7 @@ int launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, u
     case 4:  HG_ROWS_B(kRowSpanCapFast, 4, false); break;
     case 2:
         if (hib && fr.sgpr_cap) { code = 302010; hipLaunchKernelGGL((k_pw_rows_s80<kRowSpanCapFast, false, 2, false, true, false>), grid, block, pad, stream,
-                                                   mesh, fr, rl, out, map_out, rpx, rg, status_next); }
+                                                   mesh, frs, rl, out, map_out, rpx, rg, status_next); }
         else HG_ROWS_B(kRowSpanCapFast, 2, false);
         break;
     default: HG_ROWS_B(kRowSpanCapFast, 1, false); break;

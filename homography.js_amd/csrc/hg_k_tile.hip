@@ -32,11 +32,10 @@ __global__ __launch_bounds__(256) void k_pw_tile(PwMesh mesh, PwFrames fr, RowLi
                                                  int tile_cols, int32_t *__restrict__ status_next)
 {
     const int bid = blockIdx.x, xcd = bid & ((1 << fr.xcc_log2) - 1), bi = bid >> fr.xcc_log2;
-    const int per_frame = groups_per_xcd * col_tiles;
-    const int f = bi / per_frame, rem = bi - f * per_frame;
-    const int band = (xcd + (fr.xcc_rotate ? f : 0)) & ((1 << fr.xcc_log2) - 1);  // (rotates with the frame: see k_pw_rows)
-    const int g_in = rem / col_tiles, ct = rem - g_in * col_tiles;
-    const int r0 = (band * groups_per_xcd + g_in) * kTileRows, t0 = ct * tile_cols;      // (tile_cols: the frame width split evenly, a multiple of 64, <= kTileCols)
+    const int bg = bi / col_tiles, ct = bi - bg * col_tiles;                // (the column tiles of a row group are neighbours in the grid)
+    int f, gi;
+    if (!frame_group(fr, xcd, bg, groups_per_xcd, f, gi)) return;           // (bands, rotating bands or dealt sub-bands: hg_dev.h)
+    const int r0 = gi * kTileRows, t0 = ct * tile_cols;                     // (tile_cols: the frame width split evenly, a multiple of 64, <= kTileCols)
     const FrameDesc fd = fr.frames[f];
     if (bid == 0 && status_next) for (int i = threadIdx.x; i < fr.n_frames; i += 256) status_next[i] = 0;   // (see k_pw_rows)
     // the OTHER counter set, every row of the frame's block: clean for the next step (ping-pong, see k_pw_rows; the band counters live there)
@@ -323,10 +322,12 @@ int launch_pw_tile(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, u
     const int gpx = ((fr.max_obj_h + kTileRows - 1) / kTileRows + nx - 1) / nx;
     const int cts = (max_obj_w + kTileCols - 1) / kTileCols;
     const int tile_cols = (((max_obj_w + cts - 1) / cts) + 63) & ~63;          // the width split evenly over the column tiles (a 2170-pixel row: 2 x 1088, not 2048 + 122)
-    const dim3 grid((unsigned)gpx * (unsigned)nx * (unsigned)cts * (unsigned)fr.n_frames);
+    PwFrames frs = fr;
+    frs.sub_groups = sub_groups_of(fr, gpx);
+    const dim3 grid((unsigned)padded_groups(gpx, frs.sub_groups) * (unsigned)nx * (unsigned)cts * (unsigned)fr.n_frames);
     const bool hib = !fr.no_hi_bounds && hi_bounds_ok(mesh.min_src_x, (int64_t)mesh.W + mesh.min_src_x, mesh.min_src_y, (int64_t)mesh.H + mesh.min_src_y);
-    if (hib) hipLaunchKernelGGL((k_pw_tile<true>), grid, dim3(256), 0, stream, mesh, fr, rl, out, gpx, cts, tile_cols, status_next);
-    else     hipLaunchKernelGGL((k_pw_tile<false>), grid, dim3(256), 0, stream, mesh, fr, rl, out, gpx, cts, tile_cols, status_next);
+    if (hib) hipLaunchKernelGGL((k_pw_tile<true>), grid, dim3(256), 0, stream, mesh, frs, rl, out, gpx, cts, tile_cols, status_next);
+    else     hipLaunchKernelGGL((k_pw_tile<false>), grid, dim3(256), 0, stream, mesh, frs, rl, out, gpx, cts, tile_cols, status_next);
     return 500000 + kTilePB * 1000 + (hib ? 11 : 1);         // (variant code: see launch_pw_rows)
 }
 

@@ -68,6 +68,10 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t tri_group;              // 16 / 64: k_tri_spans_grouped (that many triangles per workgroup, their solves one per lane) instead of k_tri_spans; 0: k_tri_spans
     int32_t phase;                  // k_pw_rows: windows whose gathers are issued before their stores (1, 2 or 4)
     int32_t xcc_rotate;             // 1: XCD x takes band (x + frame) mod XCCs instead of band x (uneven rows, or no source shared between frames)
+    int32_t sub_bands;              // host: sub-bands per XCD (0 / 1: none); the launcher derives sub_groups from it for its kernel's row-group height
+    int32_t sub_groups;             // shared source, fixed bands: 0, or the row groups of a SUB-band.  The frame's rows are cut into sub-bands of that many groups, dealt to the XCDs round
+                                    // robin (sub-band j -> XCD j mod XCCs), and an XCD takes ALL FRAMES of one of its sub-bands before the next (loop interchange): the slice of the source a
+                                    // sub-band reads (a few hundred rows) then stays in that XCD's 4 MiB L2 from frame to frame, which a whole band of a 4K source does not (R6.12)
     int32_t xcc_log2;               // log2 of the device's XCC count (8 on an unpartitioned MI355X): block id -> XCD row band
     int32_t lds_pad_kb;             // KB of unused dynamic LDS per k_pw_rows workgroup (caps the workgroups resident per CU: row lists with one source per frame)
     int32_t sgpr_cap;               // k_pw_rows PH = 2: the 80-SGPR instantiation (8 workgroups per CU); host: shared source only

@@ -377,6 +377,10 @@ long hg_layout_walks(hg_ctx *ctx);
  *           lower-latency choice for a single frame and for sparse meshes); 0: never;
  *   "xcc_rotate" (default -1 = by estimate): 1: XCD x walks row band (x + frame) mod XCCs instead of band x -- even load where
  *           rows differ in cost or the frames share no source; 0: fixed bands (a shared source's band stays in that XCD's L2);
+ *   "sub_bands" (default -1 = by the source's size: as many as bring a sub-band's share of the source to ~2.2 MB -- 2 for a 4K source, none for
+ *           1080p; 0 / 1 none; 2..64): with ONE source shared by several frames and fixed bands, the rows of a frame are cut into sub-bands that are
+ *           dealt to the XCDs round robin, and an XCD takes all frames of one of its sub-bands before the next: the slice of the source a sub-band
+ *           reads then stays in that XCD's 4 MiB L2 from frame to frame (k_pw_rows / k_pw_patch / k_pw_tile);
  *   "xcc" (default: hipDeviceAttributeNumberOfXccs of the device, 8 on an unpartitioned MI355X): number of XCCs the
  *           block id -> row band mapping of the warp kernels assumes; a power of two in 1..64;
  *   "upload_kernel" (default -1 = on): frame-set blocks of up to 1 MB go from their page-locked staging slot to the device by a small kernel

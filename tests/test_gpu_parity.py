@@ -23,10 +23,10 @@ GOLD = G.load()
 # ("hi_bounds": 0 keeps the fp64 form of the source-bounds tests, "xcc" changes the block id -> row band mapping: both are folded
 #  into the existing layouts so that every kernel runs under either form without multiplying the suite.)
 LAYOUTS = {"auto": {}, "groups4": {"min_row_groups": 0, "patch": 0, "hi_bounds": 0, "xcc": 4, "self_spans": 0, "tri_group": 1, "compact": 1, "safe_spans": 1}, "rows1": {"min_row_groups": 1 << 30, "patch": 0, "xcc": 1, "xcc_rotate": 0, "compact": 0},
-           "patch": {"min_row_groups": 0, "patch": 1, "phase": 2, "tri_group": 64}, "patch_global": {"min_row_groups": 0, "patch": 2, "hi_bounds": 0, "xcc": 2},
-           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0, "self_spans": 1, "safe_spans": 0},
+           "patch": {"min_row_groups": 0, "patch": 1, "phase": 2, "tri_group": 64, "xcc_rotate": 0, "sub_bands": 2}, "patch_global": {"min_row_groups": 0, "patch": 2, "hi_bounds": 0, "xcc": 2},
+           "phase1": {"phase": 1, "patch": 0, "geo_windows": 1, "fwd_tiles": 1, "hi_bounds": 0, "self_spans": 1, "safe_spans": 0, "xcc_rotate": 0, "sub_bands": 3},
            "phase4": {"phase": 4, "patch": 0, "min_row_groups": 0, "geo_windows": 2, "fwd_tiles": 0, "xcc": 16, "self_spans": 0, "xcc_rotate": 1, "tri_group": 0},
-           "tile": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 1, "xcc_rotate": 1}}
+           "tile": {"min_row_groups": 0, "patch": 1, "self_spans": 1, "tile": 1, "xcc_rotate": 0, "sub_bands": 5}}
 
 
 @pytest.fixture(scope="module", params=list(LAYOUTS))
