@@ -238,7 +238,6 @@ extern "C" int hg_set_option(hg_ctx *c, const char *key, int value)
     else if (!std::strcmp(key, "hi_bounds")) c->opt_hi_bounds = value != 0;
     else if (!std::strcmp(key, "xcc_rotate")) c->opt_xcc_rotate = value;
     else if (!std::strcmp(key, "sub_bands")) c->opt_sub_bands = std::min(value, 64);
-    else if (!std::strcmp(key, "span_major")) c->opt_span_major = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "compact")) c->opt_compact = value < 0 ? -1 : (value ? 1 : 0);
     else if (!std::strcmp(key, "tile")) { c->opt_tile = value < 0 ? -1 : (value ? 1 : 0); c->pw_tile_disabled = false; }
     else if (!std::strcmp(key, "self_spans")) { c->opt_self = value < 0 ? -1 : (value ? 1 : 0); c->pw_self_disabled = false; }

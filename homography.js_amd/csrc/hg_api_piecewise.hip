@@ -330,7 +330,6 @@ PwFrames frames_of(const hg_ctx *c)
         f.sub_bands = (S > 1 && c->n_imgs <= 1 && !f.xcc_rotate && f.n_frames > 1) ? S : 0;
         f.sub_groups = 0;                                    // (the launchers set it for their kernel's row-group height)
     }
-    f.span_major = c->opt_span_major >= 0 ? c->opt_span_major : 0;
     f.sgpr_cap = c->n_imgs <= 1;
     f.lds_pad_kb = c->n_imgs > 1 && c->pw_row_group == kRowGroup ? (c->pw_shear >= 0.1 ? 16 : 12) : 0;
     // (self-span path: its instantiations fit 56 VGPRs / 78 SGPRs whatever the phase depth -- 8 workgroups per CU where the list-reading

@@ -75,7 +75,6 @@ struct hg_ctx {
     bool pw_patch = false;                                     // dense mesh that fits k_pw_patch (4-row groups, 2-D gather patches)
     bool pw_patch_fits = false;                                // ... the frame set is within k_pw_patch's limits (it may be preferred later: one source per frame)
     double pw_fill = 1.0;                                      // heaviest XCD row band / mean band (span counts per row), 1 = even rows
-    int opt_span_major = -1;                                   // option "span_major": k_pw_rows<SELF>'s pixel phase span by span (1 / 0 force / forbid, -1 by policy)
     int opt_sub_bands = -1;                                    // option "sub_bands": sub-bands per XCD of the warp kernels on a shared source with fixed bands (0 / 1 off, -1 by the source's size)
     int opt_xcc_rotate = -1;                                   // -1 by estimate, 0 / 1
     int opt_compact = -1;                                      // span-list entry format: 1 = 8-byte entries, 0 = 32-byte entries with the matrix, -1 by estimate

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kTriGroupThreads) void k_tri_spans_grouped(PwMesh m
 }
 
 
-template <int CAP, bool MAP, int PH, bool COMPACT, bool HIB, int SELF>      // SELF: 0 row lists, 1 own spans, 2 own spans + the pixel phase span by span
+template <int CAP, bool MAP, int PH, bool COMPACT, bool HIB, int SELF>      // SELF: 0 row lists, 1 own spans
 __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, uint8_t *__restrict__ out,
                                              int16_t *__restrict__ map_out, int groups_per_xcd, int rows_per_group,
                                              int32_t *__restrict__ status_next)
@@ -879,115 +879,6 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
         }
     };
 
-    // SELF == 2: the pixel phase SPAN by span instead of window by window (round 6, EXPERIMENTS.md R6.15).  A packed row has at most 63 spans, a span
-    // has ONE record: the wave takes the row's spans in ascending key order (key = id << KS | slot: ascending triangle id), reads the record once
-    // per span (every lane the same LDS address: a broadcast), and walks the span in pieces of 64 consecutive pixels, lane l = pixel lo + 64 j + l:
-    // no span search (no per-pixel compares against every span of the window), no per-pixel record read, store addresses in the instruction's scalar
-    // offset.  Pixels under several spans are written once per span, the LARGEST id last: the stores of one wave to one address are performed in
-    // program order, and a row is written by exactly one wave -- the last writer is the map's winner (:852-858), and a winner whose coordinates fail
-    // :1047 writes its zeros over the loser's pixels exactly as the reference takes 0 for that pixel.  Pixels under NO span are zeroed first: the
-    // spans sorted by their start (ranks by counting, one ds_permute), a prefix maximum of their ends, and the gaps between them.
-    auto do_row_spans = [&](int row, int cnt, int base) {
-        const int r = r0 + row;
-        const int64_t row_px = (int64_t)r * W;
-        const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(out + fd.out_off + row_px * 4, 0, W * 4, 0x00020000);
-        // lane i: span i of the row (idle lanes: an empty span at the row's end with the largest key)
-        uint32_t lohi = (uint32_t)W;                        // lo | hi << 16
-        int key = 0x7fffffff;
-        if (lane < cnt) { lohi = (uint32_t)s_lo[base + lane] | ((uint32_t)s_hi[base + lane] << 16); key = s_key[base + lane]; }
-        const uint32_t lok = ((lohi & 0xffffu) << 6) | (uint32_t)lane;      // start, made unique
-        int rk = 0, rs = 0;                                 // ranks by key and by start
-        for (int j = 0; j < cnt; j++) {
-            const int kj = __builtin_amdgcn_readlane(key, j);
-            const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)lok, j);
-            rk += kj < key ? 1 : 0; rs += lj < lok ? 1 : 0;
-        }
-        if (lane >= cnt) { rk = lane; rs = lane; }
-        const uint32_t k_lohi = (uint32_t)__builtin_amdgcn_ds_permute(rk << 2, (int)lohi);   // lane s: the span of rank s by key
-        const int k_key = __builtin_amdgcn_ds_permute(rk << 2, key);
-        const uint32_t s_lohi = (uint32_t)__builtin_amdgcn_ds_permute(rs << 2, (int)lohi);   // lane s: the span of rank s by start
-        // ---- gaps: [max end of the spans that start earlier, this start) wherever that is not empty; the idle lane cnt (start = W) closes the row
-        {
-            const int slo = (int)(s_lohi & 0xffffu), shi = lane < cnt ? (int)(s_lohi >> 16) : 0;
-            int pm = shi;                                   // inclusive prefix maximum of the ends
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(pm, d); if (lane >= d) pm = max(pm, t); }
-            int prev = __shfl_up(pm, 1);
-            if (lane == 0) prev = 0;
-            unsigned long long gm = __builtin_amdgcn_ballot_w64(lane <= cnt && prev < slo);
-            while (gm) {
-                const int bit = __ffsll((long long)gm) - 1;
-                gm &= gm - 1;
-                const int g0 = __builtin_amdgcn_readlane(prev, bit), g1 = __builtin_amdgcn_readlane(slo, bit);
-                for (int p0 = g0; p0 < g1; p0 += 64)
-                    if (p0 + lane < g1) __builtin_amdgcn_raw_buffer_store_b32(0u, dst, lane * 4, p0 * 4, kStoreNT);
-            }
-        }
-        // ---- the spans, smallest key first
-#ifndef HG_SM_NP
-#define HG_SM_NP 4
-#endif
-#ifndef HG_SM_NT
-#define HG_SM_NT kStoreNT
-#endif
-        constexpr int NP = HG_SM_NP;                        // pieces whose gathers are issued before their stores
-        const int lane4 = lane * 4;
-        auto spans = [&](auto one_tag) {                    // (one_fma is uniform for the workgroup: two copies of the loop, no per-pixel select)
-        constexpr bool ONE = decltype(one_tag)::value;
-        for (int sidx = 0; sidx < cnt; sidx++) {
-            const uint32_t lh = (uint32_t)__builtin_amdgcn_readlane((int)k_lohi, sidx);
-            const int ks = __builtin_amdgcn_readlane(k_key, sidx);
-            const int lo = (int)(lh & 0xffffu), n = (int)(lh >> 16) - lo;
-            const double2 *mrec = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(s_m) + (ks & KADDR));
-            const double2 ra = mrec[0], rb = mrec[1];
-            double2 rc = make_double2(0.0, 0.0);
-            if constexpr (!ONE) rc = mrec[2];
-            const bool safe = flag_spans && (ks & 1) == 0;  // both end pixels inside the source window: so is every pixel between them
-            // pieces on the row's 64-pixel grid (a store instruction then covers whole 128-byte lines wherever the span does): the span is
-            // [d0, tot) relative to the piece its first pixel lies in
-            const int d0 = lo & 63, base_px = lo - d0, tot = d0 + n;
-            double x = (double)(base_px + lane + fd.x_off);     // exact: integers far below 2^53
-            for (int j0 = 0; j0 < tot; j0 += 64 * NP) {
-                uint32_t px[NP];
-#pragma unroll
-                for (int q = 0; q < NP; q += 2) {
-                    if (j0 + 64 * q >= tot) break;          // (wave-uniform; a pair's second piece past the span end is computed and never stored)
-                    double v[4];
-                    v[0] = fma(ra.x, x, ra.y); v[1] = fma(rb.x, x, rb.y);
-                    const double x1 = x + 64.0;
-                    v[2] = fma(ra.x, x1, ra.y); v[3] = fma(rb.x, x1, rb.y);
-                    x = x1 + 64.0;
-                    if constexpr (!ONE) { v[0] += rc.x; v[1] += rc.y; v[2] += rc.x; v[3] += rc.y; }
-                    if (safe) {
-                        int ri[4];
-                        round_half_x4(v, ri);
-                        px[q] = hg_struct_load_u32(src, __mul24(ri[1], mesh.W) + ri[0], 0, 0, 0);
-                        px[q + 1] = hg_struct_load_u32(src, __mul24(ri[3], mesh.W) + ri[2], 0, 0, 0);
-                    } else {
-                        double rd[4];
-                        round_x4(v, rd);
-#pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const bool inb = HIB ? hi_inb(hb, v[2 * k], v[2 * k + 1])
-                                                 : (bool)((int)(v[2 * k] >= bx_lo) & (int)(v[2 * k] < bx_hi) & (int)(v[2 * k + 1] >= by_lo) & (int)(v[2 * k + 1] < by_hi));
-                            const int o = __mul24((int)dlo(rd[2 * k + 1]), mesh.W) + (int)dlo(rd[2 * k]);
-                            px[q + k] = hg_struct_load_u32(src, inb ? o : -1, 0, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < NP; q++) {
-                    const int off = j0 + 64 * q;
-                    if (off >= tot) break;
-                    if ((off >= d0 && off + 64 <= tot) || (unsigned)(off + lane - d0) < (unsigned)n)
-                        __builtin_amdgcn_raw_buffer_store_b32(px[q], dst, lane4, (base_px + off) * 4, HG_SM_NT);
-                }
-            }
-        }
-        };
-        if (one_fma) spans(std::true_type{}); else spans(std::false_type{});
-    };
-
     // One window per wave iteration.  Measured alternatives (EXPERIMENTS.md): two windows in flight per wave (74 VGPRs, 6
     // waves/SIMD) and a phased variant (4 windows resolved, then 16 gathers, then 16 stores) are both ~4 % slower: with
     // 8 waves/SIMD the other waves already cover a window's memory latency, and reads + writes together run at ~5.2 TB/s.
@@ -1001,11 +892,7 @@ __device__ __forceinline__ void pw_rows_body(const PwMesh &mesh, const PwFrames 
 #pragma unroll
         for (int j = 0; j < RG; j++) cnt_row += cnts[j] * (row == j);
         const int cnt = __builtin_amdgcn_readfirstlane(cnt_row);
-        if constexpr (SELF == 2) {                          // (the launcher picks this instantiation for 4-row groups only: every row is packed)
-            if (row < nrows) do_row_spans(row, cnt, wave * 64);
-        } else {
-            if (row < nrows) do_row(row, cnt, packed ? wave * 64 : 0, packed ? 63 : CAP - 1, w_lo + (packed ? 0 : wave), packed ? 1 : nwaves);
-        }
+        if (row < nrows) do_row(row, cnt, packed ? wave * 64 : 0, packed ? 63 : CAP - 1, w_lo + (packed ? 0 : wave), packed ? 1 : nwaves);
         return;
     }
     const int npass = packed ? 1 : nrows;
@@ -1130,7 +1017,6 @@ int launch_pw_rows(const PwMesh &mesh, const PwFrames &fr, const RowLists &rl, u
         // 1- / 2-window, the 80-SGPR and the three-edges-in-flight instantiations never picked: deleted, EXPERIMENTS.md R6.6)
         if (map_out) HG_ROWS(kRowSpanCapFast, true, 1, false, false, 1);
         else if (!hib) HG_ROWS(kRowSpanCapFast, false, 1, false, false, 1);
-        else if (fr.span_major && rg == kRowGroup) HG_ROWS(kRowSpanCapFast, false, 4, false, true, 2);      // pixel phase span by span (packed rows; R6.15)
         else HG_ROWS(kRowSpanCapFast, false, 4, false, true, 1);
         return code;
     }

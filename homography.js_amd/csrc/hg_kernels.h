@@ -79,7 +79,6 @@ struct PwFrames {                   // per-frame device arrays, frame-major
     int32_t safe_spans;             // 1: the row kernel flags every span whose two end pixels pass the source bounds test and runs windows made of such spans
                                     // without the per-pixel test (k_pw_rows); 0: no flags (rows of many short spans, where flagging costs more than it saves)
     int32_t safe_spans_patch;       // the same flags in k_pw_patch<SELF> (per 64-pixel x 4-row block)
-    int32_t span_major;             // 1 (self-span row kernel, packed rows): the pixel phase walks the row span by span instead of window by window (k_pw_rows<SELF = 2>)
     int32_t self_spans;             // 1: no row lists -- k_tri_setup ran, the
                                     // warp kernel's workgroups evaluate the spans of their own rows in their prologue
     // Candidate bands of the self-span path for meshes too large to scan per workgroup (k_tri_setup files every triangle under the
