@@ -147,10 +147,13 @@ constexpr int kKeyShift = 14, kKeyOffMask = (1 << kKeyShift) - 1;
 // for every finite double (RTN never crosses an integer upward; this also gets 0.49999999999999994 right), and it appears
 // as the low dword of r.  h itself serves the bounds test:  a <= v < b  <=>  a + 0.5 <= h < b + 0.5  (a, b integers).
 // (h is an in/out operand so that the 8 inputs and the 8 h share registers: 32 VGPRs for the block instead of 48.)
+// (NOT `asm volatile`: the block is a pure function of its operands -- it switches the rounding mode and switches it back -- and without the
+//  qualifier the compiler may move the NEXT window's arithmetic across it, ahead of this window's gathers: k_geo_fast with one source per
+//  frame - 4.6 % on two boxes, nothing with a shared source, EXPERIMENTS.md R6.16; the other blocks below measured the same either way)
 __device__ __forceinline__ void round_x8(double h[8], double r[8])
 {
     const double M = 6755399441055744.0;
-    asm volatile(
+    asm(
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\t"
         "v_add_f64 %0, %0, 0.5\n\t"  "v_add_f64 %1, %1, 0.5\n\t"  "v_add_f64 %2, %2, 0.5\n\t"  "v_add_f64 %3, %3, 0.5\n\t"
         "v_add_f64 %4, %4, 0.5\n\t"  "v_add_f64 %5, %5, 0.5\n\t"  "v_add_f64 %6, %6, 0.5\n\t"  "v_add_f64 %7, %7, 0.5\n\t"
